@@ -1,0 +1,412 @@
+// Context creation (weight packing), error reporting and the resampler of the C ABI.
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "ctx.h"
+
+static thread_local char g_err[512] = "";
+
+void cn_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* conette_last_error(void) { return g_err; }
+extern "C" int conette_abi_version(void) { return CONETTE_ABI_VERSION; }
+
+// ---- packing kernels --------------------------------------------------------------------------
+template <typename T>
+__global__ void pk_copy(const float* __restrict__ src, T* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = cn_from_f32<T>(src[i]);
+}
+// (C, 1, KH, KW) -> [KH*KW][C]
+__global__ void pk_taps_last(const float* __restrict__ src, float* __restrict__ dst, int C, int taps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < C * taps) dst[(i % taps) * C + i / taps] = src[i];
+}
+// (N, C, 2, 2) -> [N][(kh*2+kw)*C + c]
+template <typename T>
+__global__ void pk_down(const float* __restrict__ src, T* __restrict__ dst, int N, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)N * C * 4) return;
+  const int kk = (int)(i % 4);
+  const size_t nc = i / 4;
+  const int c = (int)(nc % C);
+  const size_t n = nc / C;
+  dst[(n * 4 + kk) * C + c] = cn_from_f32<T>(src[i]);
+}
+__global__ void pk_bn(const float* w, const float* b, const float* mean, const float* var, float* scale, float* shift,
+                      int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float sc = w[i] / sqrtf(var[i] + 1e-5f);
+    scale[i] = sc;
+    shift[i] = b[i] - mean[i] * sc;
+  }
+}
+
+// ---- host-side builder --------------------------------------------------------------------------
+struct Builder {
+  conette_ctx* ctx;
+  std::unordered_map<std::string, int> index;
+  const void* const* tensors;
+  const int64_t* numel;
+  int err = CN_OK;
+
+  const float* find(const std::string& name, int64_t expect) {
+    auto it = index.find(name);
+    if (it == index.end()) {
+      if (err == CN_OK) cn_set_error("create: missing tensor '%s'", name.c_str());
+      err = CN_ERR_WEIGHT;
+      return nullptr;
+    }
+    if (expect >= 0 && numel[it->second] != expect) {
+      if (err == CN_OK)
+        cn_set_error("create: tensor '%s' has %lld elements, expected %lld", name.c_str(),
+                     (long long)numel[it->second], (long long)expect);
+      err = CN_ERR_WEIGHT;
+      return nullptr;
+    }
+    return (const float*)tensors[it->second];
+  }
+  int64_t count(const std::string& name) {
+    auto it = index.find(name);
+    return it == index.end() ? -1 : numel[it->second];
+  }
+  void* alloc(size_t bytes) {
+    size_t off = cn_align(ctx->arena_used);
+    if (off + bytes > ctx->arena_bytes) {
+      if (err == CN_OK) cn_set_error("create: arena overflow");
+      err = CN_ERR_WEIGHT;
+      return ctx->arena;  // keep going, error reported at the end
+    }
+    ctx->arena_used = off + bytes;
+    return ctx->arena + off;
+  }
+  // fp32 copy
+  const float* f32(const std::string& name, int64_t n) {
+    const float* src = find(name, n);
+    if (n < 0) n = 0;
+    float* dst = (float*)alloc((size_t)n * 4);
+    if (src) hipLaunchKernelGGL((pk_copy<float>), dim3(256), dim3(256), 0, 0, src, dst, (size_t)n);
+    return dst;
+  }
+  // operand-type copy of a sub-range [first, first + n) of a tensor
+  const void* operand(const std::string& name, int64_t total, int64_t first, int64_t n) {
+    const float* src = find(name, total);
+    void* dst = alloc((size_t)n * ctx->esize);
+    if (src) {
+      if (ctx->esize == 2)
+        hipLaunchKernelGGL((pk_copy<bf16_t>), dim3(256), dim3(256), 0, 0, src + first, (bf16_t*)dst, (size_t)n);
+      else
+        hipLaunchKernelGGL((pk_copy<float>), dim3(256), dim3(256), 0, 0, src + first, (float*)dst, (size_t)n);
+    }
+    return dst;
+  }
+};
+
+extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, const char* const* names,
+                              const void* const* tensors, const int64_t* numel, conette_ctx** out) {
+  if (!cfg || !names || !tensors || !numel || !out || n_tensors <= 0) {
+    cn_set_error("create: bad argument");
+    return CN_ERR_ARG;
+  }
+  if (cfg->precision != CONETTE_PREC_F32 && cfg->precision != CONETTE_PREC_BF16) {
+    cn_set_error("create: unknown precision %d", cfg->precision);
+    return CN_ERR_ARG;
+  }
+  if (cfg->n_layers < 1 || cfg->n_layers > CN_MAX_LAYERS || cfg->d_model != 256 || cfg->nhead != 8 ||
+      cfg->d_ff % 32 != 0 || cfg->vocab_size < 4) {
+    cn_set_error("create: unsupported decoder geometry (d_model=%d nhead=%d layers=%d d_ff=%d)", cfg->d_model,
+                 cfg->nhead, cfg->n_layers, cfg->d_ff);
+    return CN_ERR_ARG;
+  }
+  conette_ctx* ctx = new conette_ctx();
+  memset(ctx, 0, sizeof(*ctx));
+  ctx->cfg = *cfg;
+  ctx->esize = cfg->precision == CONETTE_PREC_BF16 ? 2 : 4;
+  size_t total = 1 << 20;
+  for (int i = 0; i < n_tensors; ++i) total += cn_align((size_t)numel[i] * 4) + 256;
+  ctx->arena_bytes = total;
+  hipError_t e = hipMalloc((void**)&ctx->arena, total);
+  if (e != hipSuccess) {
+    cn_set_error("create: hipMalloc(%zu) -> %s", total, hipGetErrorString(e));
+    delete ctx;
+    return CN_ERR_HIP;
+  }
+  Builder B;
+  B.ctx = ctx;
+  B.tensors = tensors;
+  B.numel = numel;
+  for (int i = 0; i < n_tensors; ++i) B.index[names[i]] = i;
+  const int d = cfg->d_model, V = cfg->vocab_size, dff = cfg->d_ff;
+  const std::string E = "preprocessor.encoder.";
+
+  // ---- frontend tables ----
+  {
+    const float* cr = B.find(E + "spectrogram_extractor.stft.conv_real.weight", (int64_t)CN_N_BINS * CN_N_FFT);
+    float* win = (float*)B.alloc(CN_N_FFT * 4);
+    if (cr) hipMemcpy(win, cr, CN_N_FFT * 4, hipMemcpyDeviceToDevice);  // row k = 0: cos(0) * window
+    ctx->window = win;
+    std::vector<float2> t512(512), t1024(513);
+    for (int j = 0; j < 512; ++j) {
+      const double a = -2.0 * M_PI * j / 512.0;
+      t512[j] = float2{(float)cos(a), (float)sin(a)};
+    }
+    for (int j = 0; j <= 512; ++j) {
+      const double a = -2.0 * M_PI * j / 1024.0;
+      t1024[j] = float2{(float)cos(a), (float)sin(a)};
+    }
+    float2* d512 = (float2*)B.alloc(512 * 8);
+    float2* d1024 = (float2*)B.alloc(513 * 8);
+    hipMemcpy(d512, t512.data(), 512 * 8, hipMemcpyHostToDevice);
+    hipMemcpy(d1024, t1024.data(), 513 * 8, hipMemcpyHostToDevice);
+    ctx->tw512 = d512;
+    ctx->tw1024 = d1024;
+    const float* mw = B.find(E + "logmel_extractor.melW", (int64_t)CN_N_BINS * CN_N_MELS);
+    ctx->melW = B.f32(E + "logmel_extractor.melW", (int64_t)CN_N_BINS * CN_N_MELS);
+    std::vector<int> band(2 * CN_N_MELS, 0);
+    if (mw) {
+      std::vector<float> h((size_t)CN_N_BINS * CN_N_MELS);
+      hipMemcpy(h.data(), mw, h.size() * 4, hipMemcpyDeviceToHost);
+      for (int m = 0; m < CN_N_MELS; ++m) {
+        int lo = CN_N_BINS, hi = 0;
+        for (int k = 0; k < CN_N_BINS; ++k)
+          if (h[(size_t)k * CN_N_MELS + m] != 0.0f) {
+            lo = k < lo ? k : lo;
+            hi = k + 1;
+          }
+        if (hi == 0) lo = 0;
+        band[2 * m] = lo;
+        band[2 * m + 1] = hi;
+      }
+    }
+    int* dband = (int*)B.alloc(band.size() * 4);
+    hipMemcpy(dband, band.data(), band.size() * 4, hipMemcpyHostToDevice);
+    ctx->band = dband;
+    float* sc = (float*)B.alloc(CN_N_MELS * 4);
+    float* sh = (float*)B.alloc(CN_N_MELS * 4);
+    const float *bw = B.find(E + "bn0.weight", CN_N_MELS), *bb = B.find(E + "bn0.bias", CN_N_MELS),
+                *bm = B.find(E + "bn0.running_mean", CN_N_MELS), *bv = B.find(E + "bn0.running_var", CN_N_MELS);
+    if (bw && bb && bm && bv) hipLaunchKernelGGL(pk_bn, dim3(1), dim3(256), 0, 0, bw, bb, bm, bv, sc, sh, CN_N_MELS);
+    ctx->bn_scale = sc;
+    ctx->bn_shift = sh;
+  }
+  // ---- stem ----
+  {
+    const float* w = B.find(E + "downsample_layers.0.0.weight", 96 * 16);
+    float* dst = (float*)B.alloc(96 * 16 * 4);
+    if (w) hipLaunchKernelGGL(pk_taps_last, dim3(6), dim3(256), 0, 0, w, dst, 96, 16);
+    ctx->stem_w = dst;
+    ctx->stem_b = B.f32(E + "downsample_layers.0.0.bias", 96);
+    ctx->stem_ln_w = B.f32(E + "downsample_layers.0.1.weight", 96);
+    ctx->stem_ln_b = B.f32(E + "downsample_layers.0.1.bias", 96);
+  }
+  // ---- downsample layers 1..3 ----
+  for (int i = 0; i < 3; ++i) {
+    const int C = CN_DIMS[i], C2 = CN_DIMS[i + 1];
+    const std::string p = E + "downsample_layers." + std::to_string(i + 1) + ".";
+    ctx->down[i].ln_w = B.f32(p + "0.weight", C);
+    ctx->down[i].ln_b = B.f32(p + "0.bias", C);
+    const float* w = B.find(p + "1.weight", (int64_t)C2 * C * 4);
+    void* dst = B.alloc((size_t)C2 * C * 4 * ctx->esize);
+    if (w) {
+      const unsigned blocks = (unsigned)(((size_t)C2 * C * 4 + 255) / 256);
+      if (ctx->esize == 2) hipLaunchKernelGGL((pk_down<bf16_t>), dim3(blocks), dim3(256), 0, 0, w, (bf16_t*)dst, C2, C);
+      else hipLaunchKernelGGL((pk_down<float>), dim3(blocks), dim3(256), 0, 0, w, (float*)dst, C2, C);
+    }
+    ctx->down[i].w = dst;
+    ctx->down[i].bias = B.f32(p + "1.bias", C2);
+  }
+  // ---- ConvNeXt blocks ----
+  {
+    int blk = 0;
+    for (int s = 0; s < 4; ++s) {
+      const int C = CN_DIMS[s];
+      for (int b = 0; b < CN_DEPTHS[s]; ++b, ++blk) {
+        const std::string p = E + "stages." + std::to_string(s) + "." + std::to_string(b) + ".";
+        CnBlockW& bw = ctx->blocks[blk];
+        // old checkpoints call the layer scale "gamma" (convnext.py:76-102)
+        const std::string sname = B.count(p + "scale_layer") >= 0 ? p + "scale_layer" : p + "gamma";
+        bw.scale = B.f32(sname, C);
+        const float* w = B.find(p + "dwconv.weight", (int64_t)C * 49);
+        float* dst = (float*)B.alloc((size_t)C * 49 * 4);
+        if (w) hipLaunchKernelGGL(pk_taps_last, dim3((C * 49 + 255) / 256), dim3(256), 0, 0, w, dst, C, 49);
+        bw.dw_w = dst;
+        bw.dw_b = B.f32(p + "dwconv.bias", C);
+        bw.ln_w = B.f32(p + "norm.weight", C);
+        bw.ln_b = B.f32(p + "norm.bias", C);
+        bw.w1 = B.operand(p + "pwconv1.weight", (int64_t)4 * C * C, 0, (int64_t)4 * C * C);
+        bw.b1 = B.f32(p + "pwconv1.bias", 4 * C);
+        bw.w2 = B.operand(p + "pwconv2.weight", (int64_t)4 * C * C, 0, (int64_t)4 * C * C);
+        bw.b2 = B.f32(p + "pwconv2.bias", C);
+      }
+    }
+  }
+  ctx->norm_w = B.f32(E + "norm.weight", CN_FEAT);
+  ctx->norm_b = B.f32(E + "norm.bias", CN_FEAT);
+  ctx->head_w = B.operand(E + "head_audioset.weight", (int64_t)CN_N_TAGS * CN_FEAT, 0, (int64_t)CN_N_TAGS * CN_FEAT);
+  ctx->head_b = B.f32(E + "head_audioset.bias", CN_N_TAGS);
+
+  // ---- decoder ----
+  ctx->proj_w = B.operand("model.projection.2.weight", (int64_t)d * CN_FEAT, 0, (int64_t)d * CN_FEAT);
+  ctx->proj_b = B.f32("model.projection.2.bias", d);
+  const std::string D = "model.decoder.";
+  {
+    char* kvw = (char*)B.alloc((size_t)cfg->n_layers * 2 * d * d * ctx->esize);
+    float* kvb = (float*)B.alloc((size_t)cfg->n_layers * 2 * d * 4);
+    ctx->kv_w = kvw;
+    ctx->kv_b = kvb;
+    for (int l = 0; l < cfg->n_layers; ++l) {
+      const std::string p = D + "layers." + std::to_string(l) + ".";
+      CnLayerW& lw = ctx->layers[l];
+      lw.sa_in_w = B.operand(p + "self_attn.in_proj_weight", (int64_t)3 * d * d, 0, (int64_t)3 * d * d);
+      lw.sa_in_b = B.f32(p + "self_attn.in_proj_bias", 3 * d);
+      lw.sa_out_w = B.operand(p + "self_attn.out_proj.weight", (int64_t)d * d, 0, (int64_t)d * d);
+      lw.sa_out_b = B.f32(p + "self_attn.out_proj.bias", d);
+      lw.ca_q_w = B.operand(p + "multihead_attn.in_proj_weight", (int64_t)3 * d * d, 0, (int64_t)d * d);
+      const float* cab = B.find(p + "multihead_attn.in_proj_bias", 3 * d);
+      float* qb = (float*)B.alloc((size_t)d * 4);
+      if (cab) {
+        hipMemcpy(qb, cab, (size_t)d * 4, hipMemcpyDeviceToDevice);
+        hipMemcpy(kvb + (size_t)l * 2 * d, cab + d, (size_t)2 * d * 4, hipMemcpyDeviceToDevice);
+      }
+      lw.ca_q_b = qb;
+      const float* caw = B.find(p + "multihead_attn.in_proj_weight", (int64_t)3 * d * d);
+      if (caw) {
+        const size_t n = (size_t)2 * d * d;
+        if (ctx->esize == 2)
+          hipLaunchKernelGGL((pk_copy<bf16_t>), dim3(256), dim3(256), 0, 0, caw + (size_t)d * d,
+                             (bf16_t*)kvw + (size_t)l * n, n);
+        else
+          hipLaunchKernelGGL((pk_copy<float>), dim3(256), dim3(256), 0, 0, caw + (size_t)d * d,
+                             (float*)kvw + (size_t)l * n, n);
+      }
+      lw.ca_out_w = B.operand(p + "multihead_attn.out_proj.weight", (int64_t)d * d, 0, (int64_t)d * d);
+      lw.ca_out_b = B.f32(p + "multihead_attn.out_proj.bias", d);
+      lw.ff1_w = B.operand(p + "linear1.weight", (int64_t)dff * d, 0, (int64_t)dff * d);
+      lw.ff1_b = B.f32(p + "linear1.bias", dff);
+      lw.ff2_w = B.operand(p + "linear2.weight", (int64_t)dff * d, 0, (int64_t)dff * d);
+      lw.ff2_b = B.f32(p + "linear2.bias", d);
+      lw.n1w = B.f32(p + "norm1.weight", d);
+      lw.n1b = B.f32(p + "norm1.bias", d);
+      lw.n2w = B.f32(p + "norm2.weight", d);
+      lw.n2b = B.f32(p + "norm2.bias", d);
+      lw.n3w = B.f32(p + "norm3.weight", d);
+      lw.n3b = B.f32(p + "norm3.bias", d);
+    }
+  }
+  ctx->emb = B.f32(D + "emb_layer.weight", (int64_t)V * d);
+  {
+    const int64_t n = B.count(D + "pos_encoding.pos_embedding");
+    ctx->pe_len = n > 0 ? (int)(n / d) : 0;
+    ctx->pe = B.f32(D + "pos_encoding.pos_embedding", n);
+  }
+  ctx->cls_w = B.operand(D + "classifier.weight", (int64_t)V * d, 0, (int64_t)V * d);
+  ctx->cls_b = B.f32(D + "classifier.bias", V);
+
+  hipError_t se = hipDeviceSynchronize();
+  if (B.err == CN_OK && se != hipSuccess) {
+    cn_set_error("create: packing failed -> %s", hipGetErrorString(se));
+    B.err = CN_ERR_HIP;
+  }
+  if (B.err != CN_OK) {
+    hipFree(ctx->arena);
+    delete ctx;
+    return B.err;
+  }
+  *out = ctx;
+  return CN_OK;
+}
+
+extern "C" void conette_destroy(conette_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->arena) hipFree(ctx->arena);
+  delete ctx;
+}
+
+// ---- resampler (row a1): torchaudio.functional.resample, sinc_interpolation, width 6, rolloff 0.99
+static int gcd_i(int a, int b) { return b == 0 ? a : gcd_i(b, a % b); }
+
+extern "C" int32_t conette_resample_len(int32_t n_in, int32_t orig_sr, int32_t new_sr) {
+  const int g = gcd_i(orig_sr, new_sr);
+  const long o = orig_sr / g, n = new_sr / g;
+  return (int32_t)((n * (long)n_in + o - 1) / o);
+}
+
+__global__ void cn_resample_kernel(const float* __restrict__ in, int n_in, int n_out, int o, int n, int width, int K,
+                                   const float* __restrict__ kern, float* __restrict__ out) {
+  const int row = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  const int j = i % n, m = i / n;
+  const int start = m * o - width;
+  const float* x = in + (size_t)row * n_in;
+  const float* kk = kern + (size_t)j * K;
+  float acc = 0.f;
+  for (int t = 0; t < K; ++t) {
+    const int q = start + t;
+    const float v = (q >= 0 && q < n_in) ? x[q] : 0.f;
+    acc = fmaf(kk[t], v, acc);
+  }
+  out[(size_t)row * n_out + i] = acc;
+}
+
+struct ResampleTable {
+  int o, n, width, K;
+  float* dev;
+};
+static std::unordered_map<long, ResampleTable> g_resample;
+
+extern "C" int conette_resample(const float* in, int32_t rows, int32_t n_in, int32_t orig_sr, int32_t new_sr,
+                                float* out, void* stream) {
+  if (!in || !out || rows <= 0 || n_in <= 0 || orig_sr <= 0 || new_sr <= 0) {
+    cn_set_error("resample: bad argument");
+    return CN_ERR_ARG;
+  }
+  const long key = (long)orig_sr * 1000003L + new_sr;
+  auto it = g_resample.find(key);
+  if (it == g_resample.end()) {
+    // kernel table in fp32 arithmetic, as torchaudio 0.13.1 builds it in the waveform dtype
+    const int g = gcd_i(orig_sr, new_sr);
+    ResampleTable t;
+    t.o = orig_sr / g;
+    t.n = new_sr / g;
+    const float lpw = 6.0f;
+    float base = (float)(t.o < t.n ? t.o : t.n);
+    base *= 0.99f;
+    t.width = (int)ceil((double)lpw * t.o / (double)base);
+    t.K = 2 * t.width + t.o;
+    std::vector<float> h((size_t)t.n * t.K);
+    const float scale = base / (float)t.o;
+    for (int j = 0; j < t.n; ++j)
+      for (int c = 0; c < t.K; ++c) {
+        const float idx = (float)(c - t.width) / (float)t.o;
+        float tt = (float)(-j) / (float)t.n + idx;
+        tt *= base;
+        tt = fminf(fmaxf(tt, -lpw), lpw);
+        const float cw = cosf(tt * (float)M_PI / lpw / 2.0f);
+        const float window = cw * cw;
+        tt *= (float)M_PI;
+        const float sinc = tt == 0.0f ? 1.0f : sinf(tt) / tt;
+        h[(size_t)j * t.K + c] = sinc * window * scale;
+      }
+    CN_HIP(hipMalloc((void**)&t.dev, h.size() * 4));
+    CN_HIP(hipMemcpy(t.dev, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    it = g_resample.emplace(key, t).first;
+  }
+  const ResampleTable& t = it->second;
+  const int n_out = conette_resample_len(n_in, orig_sr, new_sr);
+  hipLaunchKernelGGL(cn_resample_kernel, dim3((unsigned)((n_out + 255) / 256), (unsigned)rows), dim3(256), 0,
+                     (hipStream_t)stream, in, n_in, n_out, t.o, t.n, t.width, t.K, t.dev, out);
+  CN_LAUNCH_CHECK();
+  return CN_OK;
+}

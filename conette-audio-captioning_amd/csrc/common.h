@@ -1,0 +1,77 @@
+// Shared device/host helpers for the conette gfx950 library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define CN_OK 0
+#define CN_ERR_ARG 1
+#define CN_ERR_HIP 2
+#define CN_ERR_WEIGHT 3
+#define CN_ERR_WORKSPACE 4
+
+void cn_set_error(const char* fmt, ...);
+
+#define CN_HIP(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      cn_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));   \
+      return CN_ERR_HIP;                                                                  \
+    }                                                                                     \
+  } while (0)
+
+#define CN_LAUNCH_CHECK()                                                                 \
+  do {                                                                                    \
+    hipError_t _e = hipGetLastError();                                                    \
+    if (_e != hipSuccess) {                                                               \
+      cn_set_error("%s:%d launch -> %s", __FILE__, __LINE__, hipGetErrorString(_e));      \
+      return CN_ERR_HIP;                                                                  \
+    }                                                                                     \
+  } while (0)
+
+#define CN_TRY(expr)                 \
+  do {                               \
+    int _s = (expr);                 \
+    if (_s != CN_OK) return _s;      \
+  } while (0)
+
+static inline size_t cn_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+static inline int cn_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- element conversion -------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T cn_from_f32(float x);
+template <> __device__ __forceinline__ float cn_from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t cn_from_f32<bf16_t>(float x) { return (bf16_t)x; }
+__device__ __forceinline__ float cn_to_f32(float x) { return x; }
+__device__ __forceinline__ float cn_to_f32(bf16_t x) { return (float)x; }
+
+// exact-erf GELU (torch F.gelu default; reference convnext.py:47, aac_tfmer.py:36)
+__device__ __forceinline__ float cn_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// 64-lane butterfly reductions
+__device__ __forceinline__ float cn_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float cn_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// store 4 consecutive values (n-contiguous) as T; p must be 4-element aligned
+__device__ __forceinline__ void cn_store4(float* p, float a, float b, float c, float d) {
+  *(f32x4*)p = f32x4{a, b, c, d};
+}
+__device__ __forceinline__ void cn_store4(bf16_t* p, float a, float b, float c, float d) {
+  *(bf16x4*)p = bf16x4{(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+}

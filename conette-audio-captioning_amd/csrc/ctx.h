@@ -1,0 +1,93 @@
+// Internal context: packed weights (GEMM operands in the context's operand type, everything
+// else fp32) + constant tables, all inside one device arena allocated by conette_create.
+#pragma once
+#include "../../include/conette_hip.h"
+#include "common.h"
+
+#define CN_N_MELS 224
+#define CN_N_FFT 1024
+#define CN_HOP 320
+#define CN_N_BINS 513
+#define CN_N_TAGS 527
+#define CN_FEAT 768
+#define CN_MAX_LAYERS 12
+
+static const int CN_DEPTHS[4] = {3, 3, 9, 3};
+static const int CN_DIMS[4] = {96, 192, 384, 768};
+
+struct CnBlockW {
+  const float* dw_w;  // [49][C]
+  const float* dw_b;
+  const float* ln_w;
+  const float* ln_b;
+  const void* w1;  // [4C][C] operand type
+  const float* b1;
+  const void* w2;  // [C][4C]
+  const float* b2;
+  const float* scale;
+};
+
+struct CnDownW {
+  const float* ln_w;
+  const float* ln_b;
+  const void* w;  // [2C][(kh,kw,c)] operand type
+  const float* bias;
+};
+
+struct CnLayerW {
+  const void* sa_in_w;  // [768][256]
+  const float* sa_in_b;
+  const void* sa_out_w;  // [256][256]
+  const float* sa_out_b;
+  const void* ca_q_w;  // [256][256]
+  const float* ca_q_b;
+  const void* ca_out_w;
+  const float* ca_out_b;
+  const void* ff1_w;  // [d_ff][256]
+  const float* ff1_b;
+  const void* ff2_w;  // [256][d_ff]
+  const float* ff2_b;
+  const float *n1w, *n1b, *n2w, *n2b, *n3w, *n3b;
+};
+
+struct conette_ctx {
+  conette_config cfg;
+  int esize;  // operand element size (2 or 4)
+  // frontend tables
+  const float* window;     // [1024]
+  const float2* tw512;     // [512]
+  const float2* tw1024;    // [513]
+  const float* melW;       // [513][224]
+  const int* band;         // [224][2] lo, hi
+  const float* bn_scale;   // [224]
+  const float* bn_shift;   // [224]
+  // stem
+  const float* stem_w;  // [16][96]
+  const float* stem_b;
+  const float* stem_ln_w;
+  const float* stem_ln_b;
+  CnBlockW blocks[18];
+  CnDownW down[3];
+  const float* norm_w;
+  const float* norm_b;
+  const void* head_w;  // [527][768]
+  const float* head_b;
+  // decoder
+  const void* proj_w;  // [256][768]
+  const float* proj_b;
+  const void* kv_w;  // [n_layers*2*d][d]  (k rows then v rows per layer)
+  const float* kv_b;
+  CnLayerW layers[CN_MAX_LAYERS];
+  const float* emb;  // [V][d] fp32
+  const float* pe;   // [5000][d] fp32
+  int pe_len;
+  const void* cls_w;  // [V][d]
+  const float* cls_b;
+  // arena
+  char* arena;
+  size_t arena_bytes;
+  size_t arena_used;
+};
+
+// ---- stage entry points implemented in the .hip files ---------------------------------------
+int cn_frontend(conette_ctx* ctx, const float* wave, int B, int L, float* out, hipStream_t s);

@@ -1,0 +1,535 @@
+// Task-embedded Transformer decoder under beam search, KV-cached, whole loop on device
+// (rows a9-a14 of SURVEY.md section 8a).
+//
+// Reference: pl_modules/conette.py:452-467 (projection + pad mask), nn/decoders/aac_tfmer.py:71-118
+// (embedding * sqrt(d) + PE, 6 post-norm torch TransformerDecoderLayer, classifier),
+// nn/decoding/beam.py:22-269 (search).  The reference re-decodes the whole prefix and
+// re-projects the audio memory at every step, and replicates the memory per beam; here
+//   * the cross-attention K/V of all layers are projected once per clip and shared by its beams,
+//   * self-attention K/V are cached per (layer, step, row); beams are re-ordered through a
+//     small ancestor table instead of moving the cache,
+//   * EOS floor, forbid-repeat mask, log-softmax, running sums, per-clip top-k and the
+//     finished / shrinking-k bookkeeping run in one kernel per step with no host sync.
+#include "ctx.h"
+#include "gemm.h"
+
+#define CN_MAX_BEAM 8
+#define CN_MAX_PRED 64
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void cn_cvt_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = cn_from_f32<T>(in[i]);
+}
+
+__global__ void cn_init_state_kernel(int B, int beam, int maxp, const int* __restrict__ bos, int* n_active, int* slot,
+                                     float* sum_lp, int* prefix, int* anc, int* cur_tok, int* out_preds,
+                                     float* out_avg, int* out_len, int* sizes, int pad_id) {
+  const int R = B * beam;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+  for (int i = gid; i < B; i += gsz) n_active[i] = beam;
+  for (int i = gid; i < R; i += gsz) {
+    slot[i] = i % beam;
+    sum_lp[i] = 0.f;
+    cur_tok[i] = bos[i / beam];
+    out_avg[i] = 0.f;
+    out_len[i] = 0;
+  }
+  for (int i = gid; i < R * (maxp + 1); i += gsz) prefix[i] = (i % (maxp + 1)) == 0 ? bos[i / ((maxp + 1) * beam)] : pad_id;
+  for (int i = gid; i < R * maxp; i += gsz) {
+    anc[i] = 0;
+    out_preds[i] = pad_id;
+  }
+  if (gid < 2) sizes[gid] = 0;
+}
+
+// x = E[tok] * sqrt(d) + PE[step]   (aac_tfmer.py:100-106); d == 256, one wave per row
+template <typename T>
+__global__ __launch_bounds__(256) void cn_embed_kernel(const int* __restrict__ tok, const float* __restrict__ emb,
+                                                       const float* __restrict__ pe, int step, int R, float scale,
+                                                       float* __restrict__ x, T* __restrict__ xt) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const f32x4 e = *(const f32x4*)(emb + (size_t)tok[r] * 256 + 4 * lane);
+  const f32x4 p = *(const f32x4*)(pe + (size_t)step * 256 + 4 * lane);
+  f32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = e[i] * scale + p[i];
+  *(f32x4*)(x + (size_t)r * 256 + 4 * lane) = o;
+  cn_store4(xt + (size_t)r * 256 + 4 * lane, o[0], o[1], o[2], o[3]);
+}
+
+// x = LayerNorm(tmp) (eps 1e-5, d == 256); one wave per row
+template <typename T>
+__global__ __launch_bounds__(256) void cn_ln256_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                       const float* __restrict__ b, int R, float* __restrict__ x,
+                                                       T* __restrict__ xt) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const f32x4 v = *(const f32x4*)(in + (size_t)r * 256 + 4 * lane);
+  const float mean = cn_wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s2 = fmaf(v[i] - mean, v[i] - mean, s2);
+  const float rstd = 1.0f / sqrtf(cn_wave_sum(s2) * (1.0f / 256.0f) + 1e-5f);
+  const f32x4 ww = *(const f32x4*)(w + 4 * lane), bb = *(const f32x4*)(b + 4 * lane);
+  f32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (v[i] - mean) * rstd * ww[i] + bb[i];
+  *(f32x4*)(x + (size_t)r * 256 + 4 * lane) = o;
+  cn_store4(xt + (size_t)r * 256 + 4 * lane, o[0], o[1], o[2], o[3]);
+}
+
+template <typename T> __device__ __forceinline__ f32x4 cn_load4(const T* p);
+template <> __device__ __forceinline__ f32x4 cn_load4<float>(const float* p) { return *(const f32x4*)p; }
+template <> __device__ __forceinline__ f32x4 cn_load4<bf16_t>(const bf16_t* p) {
+  const bf16x4 v = *(const bf16x4*)p;
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+
+__device__ __forceinline__ float cn_dot8(f32x4 a, f32x4 b) {  // 32-dim head dot: 4 local + 8-lane reduce
+  float d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+  d += __shfl_xor(d, 1);
+  d += __shfl_xor(d, 2);
+  d += __shfl_xor(d, 4);
+  return d;
+}
+
+// Causal self-attention of ONE new position per row over the cached prefix (8 heads x 32).
+// lane l owns dims 4l..4l+3 (head l>>3).  Writes this step's K/V into the cache.
+template <typename T>
+__global__ __launch_bounds__(256) void cn_self_attn_kernel(const float* __restrict__ qkv, T* __restrict__ kc,
+                                                           T* __restrict__ vc, const int* __restrict__ anc, int step,
+                                                           int R, int beam, int maxp, float scale,
+                                                           T* __restrict__ out) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float* row = qkv + (size_t)r * 768 + 4 * lane;
+  f32x4 q = *(const f32x4*)row;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] *= scale;
+  const f32x4 kn = *(const f32x4*)(row + 256), vn = *(const f32x4*)(row + 512);
+  T* kdst = kc + ((size_t)step * R + r) * 256 + 4 * lane;
+  T* vdst = vc + ((size_t)step * R + r) * 256 + 4 * lane;
+  cn_store4(kdst, kn[0], kn[1], kn[2], kn[3]);
+  cn_store4(vdst, vn[0], vn[1], vn[2], vn[3]);
+  const int rb = (r / beam) * beam;
+  float m = -INFINITY, l = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s <= step; ++s) {
+    f32x4 kk, vv;
+    if (s < step) {
+      const int src = rb + anc[(size_t)r * maxp + s];
+      kk = cn_load4<T>(kc + ((size_t)s * R + src) * 256 + 4 * lane);
+      vv = cn_load4<T>(vc + ((size_t)s * R + src) * 256 + 4 * lane);
+    } else {  // own entry, at cache precision
+      kk = f32x4{cn_to_f32(cn_from_f32<T>(kn[0])), cn_to_f32(cn_from_f32<T>(kn[1])), cn_to_f32(cn_from_f32<T>(kn[2])),
+                 cn_to_f32(cn_from_f32<T>(kn[3]))};
+      vv = f32x4{cn_to_f32(cn_from_f32<T>(vn[0])), cn_to_f32(cn_from_f32<T>(vn[1])), cn_to_f32(cn_from_f32<T>(vn[2])),
+                 cn_to_f32(cn_from_f32<T>(vn[3]))};
+    }
+    const float sc = cn_dot8(q, kk);
+    const float mn = fmaxf(m, sc);
+    const float corr = __expf(m - mn), p = __expf(sc - mn);
+    l = l * corr + p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = acc[i] * corr + p * vv[i];
+    m = mn;
+  }
+  const float inv = 1.0f / l;
+  cn_store4(out + (size_t)r * 256 + 4 * lane, acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+}
+
+// Cross-attention of one query per row over its clip's projected audio memory (shared by beams);
+// frames >= frame_lens[clip] are masked (key_padding_mask, conette.py:460-462).
+template <typename T>
+__global__ __launch_bounds__(256) void cn_cross_attn_kernel(const float* __restrict__ q, const T* __restrict__ kv,
+                                                            int kv_ld, int kv_off, const int* __restrict__ lens,
+                                                            int R, int beam, int Ta, float scale,
+                                                            T* __restrict__ out) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const int b = r / beam;
+  f32x4 qq = *(const f32x4*)(q + (size_t)r * 256 + 4 * lane);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) qq[i] *= scale;
+  int n = lens[b];
+  n = n < 1 ? 1 : (n > Ta ? Ta : n);
+  const T* base = kv + (size_t)b * Ta * kv_ld + kv_off + 4 * lane;
+  float m = -INFINITY, l = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < n; ++t) {
+    const f32x4 kk = cn_load4<T>(base + (size_t)t * kv_ld);
+    const f32x4 vv = cn_load4<T>(base + (size_t)t * kv_ld + 256);
+    const float sc = cn_dot8(qq, kk);
+    const float mn = fmaxf(m, sc);
+    const float corr = __expf(m - mn), p = __expf(sc - mn);
+    l = l * corr + p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = acc[i] * corr + p * vv[i];
+    m = mn;
+  }
+  const float inv = 1.0f / l;
+  cn_store4(out + (size_t)r * 256 + 4 * lane, acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+}
+
+// ---------------------------------------------------------------------------------------------
+// one search step for one clip (beam.py:125-203, _select_k_next_toks :230-269)
+// ---------------------------------------------------------------------------------------------
+struct ValIdx {
+  float v;
+  int i;
+};
+__device__ __forceinline__ ValIdx vi_better(ValIdx a, ValIdx b) {  // larger value, then lower flat index
+  return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+__device__ __forceinline__ ValIdx vi_wave(ValIdx x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ValIdx y;
+    y.v = __shfl_xor(x.v, o);
+    y.i = __shfl_xor(x.i, o);
+    x = vi_better(x, y);
+  }
+  return x;
+}
+
+__global__ __launch_bounds__(256) void cn_search_step_kernel(float* __restrict__ logits, int ldv, int V, int beam,
+                                                             int maxp, int step, int min_pred, int eos_id,
+                                                             const uint8_t* __restrict__ forbid, int* n_active,
+                                                             int* slot, float* sum_lp, int* prefix, int* anc,
+                                                             int* cur_tok, int* out_preds, float* out_avg,
+                                                             int* out_len) {
+  __shared__ float s_red[8];
+  __shared__ ValIdx s_vi[4];
+  __shared__ float s_mx[CN_MAX_BEAM], s_lg[CN_MAX_BEAM], s_base[CN_MAX_BEAM];
+  __shared__ float s_selv[CN_MAX_BEAM];
+  __shared__ int s_self[CN_MAX_BEAM];
+  __shared__ int s_prefix[CN_MAX_BEAM][CN_MAX_PRED + 1];
+  __shared__ int s_anc[CN_MAX_BEAM][CN_MAX_PRED];
+  __shared__ int s_slot[CN_MAX_BEAM];
+  __shared__ int s_newpos[CN_MAX_BEAM];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int k = n_active[b];
+  if (k == 0) return;
+  const int rb = b * beam;
+  const int nrows = step == 0 ? 1 : k;
+
+  // old state -> LDS
+  for (int i = tid; i < k * (maxp + 1); i += 256) s_prefix[i / (maxp + 1)][i % (maxp + 1)] = prefix[(size_t)rb * (maxp + 1) + i];
+  for (int i = tid; i < k * maxp; i += 256) s_anc[i / maxp][i % maxp] = anc[(size_t)rb * maxp + i];
+  if (tid < k) {
+    s_slot[tid] = slot[rb + tid];
+    s_base[tid] = step == 0 ? 0.f : sum_lp[rb + tid];
+  }
+  __syncthreads();
+  // EOS floor (beam.py:129-130) + forbid-repeat (beam.py:146-156), in place
+  for (int i = tid; i < nrows * (step + 2); i += 256) {
+    const int p = i / (step + 2), j = i % (step + 2);
+    float* lg = logits + (size_t)(rb + p) * ldv;
+    if (j == step + 1) {
+      if (step < min_pred) lg[eos_id] = -INFINITY;
+    } else if (forbid != nullptr) {
+      const int tok = s_prefix[p][j];
+      if (forbid[tok]) lg[tok] = -INFINITY;
+    }
+  }
+  __syncthreads();
+  // log-softmax statistics per row
+  for (int p = 0; p < nrows; ++p) {
+    const float* lg = logits + (size_t)(rb + p) * ldv;
+    float mx = -INFINITY;
+    for (int v = tid; v < V; v += 256) mx = fmaxf(mx, lg[v]);
+    mx = cn_wave_max(mx);
+    if (lane == 0) s_red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    float sm = 0.f;
+    for (int v = tid; v < V; v += 256) sm += expf(lg[v] - mx);
+    sm = cn_wave_sum(sm);
+    if (lane == 0) s_red[4 + wv] = sm;
+    __syncthreads();
+    if (tid == 0) {
+      s_mx[p] = mx;
+      s_lg[p] = logf(s_red[4] + s_red[5] + s_red[6] + s_red[7]);
+    }
+    __syncthreads();
+  }
+  // top-k over the nrows * V candidates, k rounds of block arg-max (ties -> lowest flat index)
+  for (int c = 0; c < k; ++c) {
+    ValIdx best{-INFINITY, 0x7fffffff};
+    for (int p = 0; p < nrows; ++p) {
+      const float* lg = logits + (size_t)(rb + p) * ldv;
+      const float mx = s_mx[p], lgs = s_lg[p], base = s_base[p];
+      for (int v = tid; v < V; v += 256) {
+        const int flat = p * V + v;
+        bool taken = false;
+        for (int d = 0; d < c; ++d) taken |= (s_self[d] == flat);
+        if (taken) continue;
+        float cand = (lg[v] - mx) - lgs;
+        if (step != 0) cand = base + cand;
+        best = vi_better(best, ValIdx{cand, flat});
+      }
+    }
+    best = vi_wave(best);
+    if (lane == 0) s_vi[wv] = best;
+    __syncthreads();
+    if (tid == 0) {
+      ValIdx r0 = vi_better(vi_better(s_vi[0], s_vi[1]), vi_better(s_vi[2], s_vi[3]));
+      s_selv[c] = r0.v;
+      s_self[c] = r0.i;
+    }
+    __syncthreads();
+  }
+  // bookkeeping (beam.py:164-203)
+  if (tid == 0) {
+    int cnt = 0;
+    for (int c = 0; c < k; ++c) {
+      const int token = s_self[c] % V;
+      const bool fin = (token == eos_id) || (step == maxp - 1);
+      s_newpos[c] = fin ? -1 : cnt++;
+    }
+    n_active[b] = cnt;
+  }
+  __syncthreads();
+  for (int c = 0; c < k; ++c) {
+    const int flat = s_self[c];
+    const int parent = flat / V, token = flat % V;
+    const int np = s_newpos[c];
+    if (np < 0) {  // finished: write to the slot of this row position
+      const int sl = rb + s_slot[c];
+      for (int j = tid; j <= step; j += 256) out_preds[(size_t)sl * maxp + j] = (j == step) ? token : s_prefix[parent][j + 1];
+      if (tid == 0) {
+        out_avg[sl] = s_selv[c] / (float)(step + 1);
+        out_len[sl] = step + 1;
+      }
+    } else {
+      const int dst = rb + np;
+      for (int j = tid; j <= step + 1; j += 256) prefix[(size_t)dst * (maxp + 1) + j] = (j == step + 1) ? token : s_prefix[parent][j];
+      for (int j = tid; j <= step; j += 256) anc[(size_t)dst * maxp + j] = (j == step) ? parent : s_anc[parent][j];
+      if (tid == 0) {
+        sum_lp[dst] = s_selv[c];
+        slot[dst] = s_slot[c];
+        cur_tok[dst] = token;
+      }
+    }
+  }
+}
+
+// best beam per clip (beam.py:205-220): first max of the averaged log-prob; pred_size via atomicMax
+__global__ void cn_finalize_kernel(int B, int beam, int maxp, int eos_id, const int* __restrict__ out_preds,
+                                   const float* __restrict__ out_avg, const int* __restrict__ out_len,
+                                   int* __restrict__ best_preds, float* __restrict__ best_lp,
+                                   int* __restrict__ eos_idx, int* sizes) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int best = 0, mlen = 0;
+  float bv = out_avg[b * beam];
+  for (int s = 0; s < beam; ++s) {
+    if (out_avg[b * beam + s] > bv) {
+      bv = out_avg[b * beam + s];
+      best = s;
+    }
+    mlen = max(mlen, out_len[b * beam + s]);
+  }
+  atomicMax(&sizes[0], mlen);
+  best_lp[b] = bv;
+  int e = -1;
+  for (int j = 0; j < maxp; ++j) {
+    const int t = out_preds[((size_t)b * beam + best) * maxp + j];
+    best_preds[(size_t)b * maxp + j] = t;
+    if (e < 0 && t == eos_id) e = j;
+  }
+  eos_idx[b] = e;
+}
+// best_maxlen = max_b(first EOS index, or pred_size when absent) + 1 (beam.py:222-225)
+__global__ void cn_finalize2_kernel(int B, const int* __restrict__ eos_idx, int* sizes) {
+  __shared__ int s_m;
+  if (threadIdx.x == 0) s_m = 0;
+  __syncthreads();
+  const int ps = sizes[0];
+  int m = 0;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const int e = eos_idx[b];
+    m = max(m, (e >= 0 && e < ps) ? e : ps);
+  }
+  atomicMax(&s_m, m);
+  __syncthreads();
+  if (threadIdx.x == 0) sizes[1] = min(s_m + 1, ps);
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace + orchestration
+// ---------------------------------------------------------------------------------------------
+struct DecWs {
+  void *fe_t, *mem, *kvc, *xt, *attn_t, *ffh, *kc, *vc;
+  float *x, *qkv, *q, *tmp, *logits;
+  int *n_active, *slot, *prefix, *anc, *cur_tok, *out_len, *eos_idx;
+  float* sum_lp;
+  int ldv;
+  size_t total;
+};
+
+static DecWs dec_ws(const conette_ctx* ctx, int B, int Ta, int beam, int maxp, char* base) {
+  const size_t es = ctx->esize;
+  const int d = ctx->cfg.d_model, NL = ctx->cfg.n_layers, R = B * beam;
+  DecWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += cn_align(bytes);
+    return p;
+  };
+  w.ldv = (ctx->cfg.vocab_size + 7) / 8 * 8;
+  w.fe_t = take((size_t)B * Ta * CN_FEAT * es);
+  w.mem = take((size_t)B * Ta * d * es);
+  w.kvc = take((size_t)B * Ta * NL * 2 * d * es);
+  w.x = (float*)take((size_t)R * d * 4);
+  w.xt = take((size_t)R * d * es);
+  w.qkv = (float*)take((size_t)R * 3 * d * 4);
+  w.q = (float*)take((size_t)R * d * 4);
+  w.attn_t = take((size_t)R * d * es);
+  w.tmp = (float*)take((size_t)R * d * 4);
+  w.ffh = take((size_t)R * ctx->cfg.d_ff * es);
+  w.logits = (float*)take((size_t)R * w.ldv * 4);
+  w.kc = take((size_t)NL * maxp * R * d * es);
+  w.vc = take((size_t)NL * maxp * R * d * es);
+  w.n_active = (int*)take((size_t)B * 4);
+  w.slot = (int*)take((size_t)R * 4);
+  w.sum_lp = (float*)take((size_t)R * 4);
+  w.prefix = (int*)take((size_t)R * (maxp + 1) * 4);
+  w.anc = (int*)take((size_t)R * maxp * 4);
+  w.cur_tok = (int*)take((size_t)R * 4);
+  w.out_len = (int*)take((size_t)R * 4);
+  w.eos_idx = (int*)take((size_t)B * 4);
+  w.total = off;
+  return w;
+}
+
+extern "C" size_t conette_decode_workspace_bytes(const conette_ctx* ctx, int32_t batch, int32_t t_audio, int32_t beam,
+                                                 int32_t max_pred) {
+  return dec_ws(ctx, batch, t_audio, beam, max_pred, nullptr).total;
+}
+
+template <typename T>
+static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t* frame_lens, const int32_t* bos_ids,
+                       const uint8_t* forbid, int B, int Ta, int beam, int min_pred, int maxp, int32_t* best_preds,
+                       float* best_lprobs, int32_t* mult_preds, float* mult_lprobs, int32_t* out_sizes,
+                       float* step0_logits, char* wsp, hipStream_t s) {
+  const conette_config& cfg = ctx->cfg;
+  const int d = cfg.d_model, NL = cfg.n_layers, R = B * beam, V = cfg.vocab_size, dff = cfg.d_ff;
+  DecWs w = dec_ws(ctx, B, Ta, beam, maxp, wsp);
+  T* fe_t = (T*)w.fe_t;
+  T* mem = (T*)w.mem;
+  T* kvc = (T*)w.kvc;
+  T* xt = (T*)w.xt;
+  T* attn_t = (T*)w.attn_t;
+  T* ffh = (T*)w.ffh;
+  const int kv_ld = NL * 2 * d;
+  const float scale = 1.0f / sqrtf((float)(d / cfg.nhead));
+  const int rblocks = cn_cdiv(R, 4);
+
+  // ---- once per batch: projection (conette.py:457) and cross K/V of every layer ---------------
+  {
+    const size_t n = (size_t)B * Ta * CN_FEAT;
+    hipLaunchKernelGGL((cn_cvt_kernel<T>), dim3((unsigned)((n + 1023) / 1024 < 4096 ? (n + 1023) / 1024 : 4096)), dim3(256), 0, s,
+                       frame_embs, fe_t, n);
+    CN_LAUNCH_CHECK();
+    EpiBiasAct<T> ep{ctx->proj_b, mem, d, ACT_RELU};
+    CN_TRY((cn_gemm<T>(fe_t, CN_FEAT, (const T*)ctx->proj_w, CN_FEAT, B * Ta, d, CN_FEAT, ep, s)));
+    EpiBiasAct<T> ekv{ctx->kv_b, kvc, kv_ld, ACT_NONE};
+    CN_TRY((cn_gemm<T>(mem, d, (const T*)ctx->kv_w, d, B * Ta, kv_ld, d, ekv, s)));
+  }
+  hipLaunchKernelGGL(cn_init_state_kernel, dim3(64), dim3(256), 0, s, B, beam, maxp, bos_ids, w.n_active, w.slot,
+                     w.sum_lp, w.prefix, w.anc, w.cur_tok, mult_preds, mult_lprobs, w.out_len, out_sizes, cfg.pad_id);
+  CN_LAUNCH_CHECK();
+
+  for (int step = 0; step < maxp; ++step) {
+    hipLaunchKernelGGL((cn_embed_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.cur_tok, ctx->emb, ctx->pe, step, R,
+                       sqrtf((float)d), w.x, xt);
+    CN_LAUNCH_CHECK();
+    for (int l = 0; l < NL; ++l) {
+      const CnLayerW& lw = ctx->layers[l];
+      T* kc = (T*)w.kc + (size_t)l * maxp * R * d;
+      T* vc = (T*)w.vc + (size_t)l * maxp * R * d;
+      EpiBiasAct<float> eq{lw.sa_in_b, w.qkv, 3 * d, ACT_NONE};
+      CN_TRY((cn_gemm<T>(xt, d, (const T*)lw.sa_in_w, d, R, 3 * d, d, eq, s)));
+      hipLaunchKernelGGL((cn_self_attn_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.qkv, kc, vc, w.anc, step, R, beam,
+                         maxp, scale, attn_t);
+      CN_LAUNCH_CHECK();
+      EpiResid eo{lw.sa_out_b, nullptr, w.x, w.tmp, d};
+      CN_TRY((cn_gemm<T>(attn_t, d, (const T*)lw.sa_out_w, d, R, d, d, eo, s)));
+      hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, lw.n1w, lw.n1b, R, w.x, xt);
+      CN_LAUNCH_CHECK();
+
+      EpiBiasAct<float> ecq{lw.ca_q_b, w.q, d, ACT_NONE};
+      CN_TRY((cn_gemm<T>(xt, d, (const T*)lw.ca_q_w, d, R, d, d, ecq, s)));
+      hipLaunchKernelGGL((cn_cross_attn_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.q, kvc, kv_ld, l * 2 * d,
+                         frame_lens, R, beam, Ta, scale, attn_t);
+      CN_LAUNCH_CHECK();
+      EpiResid eco{lw.ca_out_b, nullptr, w.x, w.tmp, d};
+      CN_TRY((cn_gemm<T>(attn_t, d, (const T*)lw.ca_out_w, d, R, d, d, eco, s)));
+      hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, lw.n2w, lw.n2b, R, w.x, xt);
+      CN_LAUNCH_CHECK();
+
+      EpiBiasAct<T> e1{lw.ff1_b, ffh, dff, ACT_GELU};
+      CN_TRY((cn_gemm<T>(xt, d, (const T*)lw.ff1_w, d, R, dff, d, e1, s)));
+      EpiResid e2{lw.ff2_b, nullptr, w.x, w.tmp, d};
+      CN_TRY((cn_gemm<T>(ffh, dff, (const T*)lw.ff2_w, dff, R, d, dff, e2, s)));
+      hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, lw.n3w, lw.n3b, R, w.x, xt);
+      CN_LAUNCH_CHECK();
+    }
+    EpiBiasAct<float> ec{ctx->cls_b, w.logits, w.ldv, ACT_NONE};
+    CN_TRY((cn_gemm<T>(xt, d, (const T*)ctx->cls_w, d, R, V, d, ec, s)));
+    if (step == 0 && step0_logits)
+      CN_HIP(hipMemcpyAsync(step0_logits, w.logits, (size_t)R * w.ldv * 4, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(cn_search_step_kernel, dim3(B), dim3(256), 0, s, w.logits, w.ldv, V, beam, maxp, step, min_pred,
+                       cfg.eos_id, forbid, w.n_active, w.slot, w.sum_lp, w.prefix, w.anc, w.cur_tok, mult_preds,
+                       mult_lprobs, w.out_len);
+    CN_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(cn_finalize_kernel, dim3(cn_cdiv(B, 64)), dim3(64), 0, s, B, beam, maxp, cfg.eos_id, mult_preds,
+                     mult_lprobs, w.out_len, best_preds, best_lprobs, w.eos_idx, out_sizes);
+  CN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(cn_finalize2_kernel, dim3(1), dim3(256), 0, s, B, w.eos_idx, out_sizes);
+  CN_LAUNCH_CHECK();
+  return CN_OK;
+}
+
+extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const int32_t* frame_lens,
+                              const int32_t* bos_ids, const uint8_t* forbid_mask, int32_t batch, int32_t t_audio,
+                              int32_t beam, int32_t min_pred, int32_t max_pred, int32_t* best_preds,
+                              float* best_lprobs, int32_t* mult_preds, float* mult_lprobs, int32_t* out_sizes,
+                              float* step0_logits, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!ctx || !frame_embs || !frame_lens || !bos_ids || !best_preds || !best_lprobs || !mult_preds || !mult_lprobs ||
+      !out_sizes || !workspace || batch <= 0 || t_audio <= 0) {
+    cn_set_error("decode: bad argument");
+    return CN_ERR_ARG;
+  }
+  if (beam < 1 || beam > CN_MAX_BEAM || max_pred < 1 || max_pred > CN_MAX_PRED || min_pred < 0) {
+    cn_set_error("decode: beam=%d (1..%d) max_pred=%d (1..%d) min_pred=%d unsupported", beam, CN_MAX_BEAM, max_pred,
+                 CN_MAX_PRED, min_pred);
+    return CN_ERR_ARG;
+  }
+  if (ctx->cfg.d_model != 256 || ctx->cfg.nhead != 8) {
+    cn_set_error("decode: kernels are specialised for d_model=256, nhead=8");
+    return CN_ERR_ARG;
+  }
+  if (max_pred > ctx->pe_len) {
+    cn_set_error("decode: max_pred exceeds positional table");
+    return CN_ERR_ARG;
+  }
+  const size_t need = conette_decode_workspace_bytes(ctx, batch, t_audio, beam, max_pred);
+  if (workspace_bytes < need) {
+    cn_set_error("decode: workspace %zu < %zu", workspace_bytes, need);
+    return CN_ERR_WORKSPACE;
+  }
+  if (ctx->cfg.precision == CONETTE_PREC_BF16)
+    return decode_impl<bf16_t>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, beam, min_pred,
+                               max_pred, best_preds, best_lprobs, mult_preds, mult_lprobs, out_sizes, step0_logits,
+                               (char*)workspace, (hipStream_t)stream);
+  return decode_impl<float>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, beam, min_pred,
+                            max_pred, best_preds, best_lprobs, mult_preds, mult_lprobs, out_sizes, step0_logits,
+                            (char*)workspace, (hipStream_t)stream);
+}

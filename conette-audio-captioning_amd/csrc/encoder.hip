@@ -1,0 +1,444 @@
+// ConvNeXt-tiny audio encoder for gfx950 (rows a3-a7 of SURVEY.md section 8a).
+//
+// Reference: nn/encoders/convnext.py:61-74 (block), :207-217 (stem / downsample), :264-336
+// (forward), nn/modules/norm.py:31-40 (LayerNorm).  Activations are channels-last (B, H, W, C)
+// with H = time, W = frequency; the residual stream stays fp32, GEMM operands are the context's
+// operand type (bf16 or fp32).  Depthwise 7x7 + LayerNorm run on the VALU, the pointwise and
+// downsample contractions on MFMA through cn_gemm (north_star).
+#include "ctx.h"
+#include "gemm.h"
+
+// ---------------------------------------------------------------------------------------------
+// stem: Conv2d(1 -> 96, k 4x4, s 4x4, pad (4, 0)) + LayerNorm(channels_first, eps 1e-6)
+// in: logmel (B, F, 224) fp32; out: (B, H0, 56, 96) fp32.  4 lanes per output position.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cn_stem_kernel(const float* __restrict__ in, int F, int H0, long n_pos,
+                                                      const float* __restrict__ w /*[16][96]*/,
+                                                      const float* __restrict__ bias, const float* __restrict__ ln_w,
+                                                      const float* __restrict__ ln_b, float* __restrict__ out) {
+  __shared__ float s_w[16 * 96];
+  for (int i = threadIdx.x; i < 16 * 96; i += 256) s_w[i] = w[i];
+  __syncthreads();
+  const int q = threadIdx.x & 3;
+  const long pos = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
+  const bool act = pos < n_pos;
+  const long p = act ? pos : n_pos - 1;
+  const int wq = (int)(p % 56);
+  const long t = p / 56;
+  const int h = (int)(t % H0);
+  const int b = (int)(t / H0);
+  float xin[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 4 * h - 4 + i;
+    if (r >= 0 && r < F) {
+      const f32x4 v = *(const f32x4*)(in + ((size_t)b * F + r) * CN_N_MELS + 4 * wq);
+      xin[4 * i] = v[0], xin[4 * i + 1] = v[1], xin[4 * i + 2] = v[2], xin[4 * i + 3] = v[3];
+    } else {
+      xin[4 * i] = xin[4 * i + 1] = xin[4 * i + 2] = xin[4 * i + 3] = 0.f;
+    }
+  }
+  float acc[24];
+#pragma unroll
+  for (int j = 0; j < 24; ++j) acc[j] = bias[q * 24 + j];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int j = 0; j < 24; ++j) acc[j] = fmaf(xin[i], s_w[i * 96 + q * 24 + j], acc[j]);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 24; ++j) s += acc[j];
+  s += __shfl_xor(s, 1);
+  s += __shfl_xor(s, 2);
+  const float mean = s * (1.0f / 96.0f);
+  float v2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 24; ++j) {
+    const float d = acc[j] - mean;
+    v2 = fmaf(d, d, v2);
+  }
+  v2 += __shfl_xor(v2, 1);
+  v2 += __shfl_xor(v2, 2);
+  const float rstd = 1.0f / sqrtf(v2 * (1.0f / 96.0f) + 1e-6f);
+  if (act) {
+    float* o = out + (size_t)pos * 96 + q * 24;
+#pragma unroll
+    for (int j = 0; j < 24; j += 4) {
+      f32x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = (acc[j + e] - mean) * rstd * ln_w[q * 24 + j + e] + ln_b[q * 24 + j + e];
+      *(f32x4*)(o + j) = r;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// depthwise 7x7 (pad 3) + LayerNorm over C (eps 1e-6): x fp32 (B,H,W,C) -> y T (B,H,W,C)
+// One thread = one channel x a 4(h) x 4(w) output patch: 100 loads feed 784 FMAs; the block is
+// C x S threads covering a 4 x (4S) tile for all channels, so the LayerNorm over C is local to
+// the block: conv results go through an LDS tile [pos][C] and one wave normalises a position.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int C, int S>
+__global__ __launch_bounds__(C* S) void cn_dwconv_ln_kernel(const float* __restrict__ x, int H, int W, int tiles_h,
+                                                            int tiles_w, const float* __restrict__ dw_w /*[49][C]*/,
+                                                            const float* __restrict__ dw_b,
+                                                            const float* __restrict__ ln_w,
+                                                            const float* __restrict__ ln_b, T* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* s_v = (float*)smem_raw;  // [16*S][C]
+  const int tid = threadIdx.x;
+  const int c = tid % C, sidx = tid / C;
+  int bid = blockIdx.x;
+  const int tw = bid % tiles_w;
+  bid /= tiles_w;
+  const int th = bid % tiles_h;
+  const int b = bid / tiles_h;
+  const int h0 = th * 4, w0 = tw * (4 * S) + sidx * 4;
+
+  float k[49];
+#pragma unroll
+  for (int i = 0; i < 49; ++i) k[i] = dw_w[i * C + c];
+  float acc[4][4];
+  const float bias = dw_b[c];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[a][e] = bias;
+
+  const float* xb = x + (size_t)b * H * W * C + c;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const int hh = h0 - 3 + r;
+    if (hh < 0 || hh >= H) continue;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+      const int ww = w0 - 3 + q;
+      float v = 0.f;
+      if (ww >= 0 && ww < W) v = xb[((size_t)hh * W + ww) * C];
+#pragma unroll
+      for (int oh = 0; oh < 4; ++oh) {
+        const int i = r - oh;
+        if (i < 0 || i > 6) continue;
+#pragma unroll
+        for (int ow = 0; ow < 4; ++ow) {
+          const int j = q - ow;
+          if (j < 0 || j > 6) continue;
+          acc[oh][ow] = fmaf(v, k[i * 7 + j], acc[oh][ow]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int oh = 0; oh < 4; ++oh)
+#pragma unroll
+    for (int ow = 0; ow < 4; ++ow) s_v[((sidx * 16) + oh * 4 + ow) * C + c] = acc[oh][ow];
+  __syncthreads();
+
+  constexpr int NW = C * S / 64;
+  constexpr int PER = (C + 63) / 64;
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int p = wv; p < 16 * S; p += NW) {
+    const int ps = p >> 4, oh = (p >> 2) & 3, ow = p & 3;
+    const int h = h0 + oh, w = tw * (4 * S) + ps * 4 + ow;
+    if (h >= H || w >= W) continue;  // wave-uniform
+    float v[PER];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int cc = lane + 64 * i;
+      v[i] = cc < C ? s_v[p * C + cc] : 0.f;
+      s += v[i];
+    }
+    const float mean = cn_wave_sum(s) * (1.0f / C);
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int cc = lane + 64 * i;
+      const float d = cc < C ? v[i] - mean : 0.f;
+      s2 = fmaf(d, d, s2);
+    }
+    const float rstd = 1.0f / sqrtf(cn_wave_sum(s2) * (1.0f / C) + 1e-6f);
+    T* o = y + (((size_t)b * H + h) * W + w) * C;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int cc = lane + 64 * i;
+      if (cc < C) o[cc] = cn_from_f32<T>((v[i] - mean) * rstd * ln_w[cc] + ln_b[cc]);
+    }
+  }
+}
+
+template <typename T, int C, int S>
+static int launch_dwconv(const float* x, int B, int H, int W, const CnBlockW& bw, T* y, hipStream_t s) {
+  const int tiles_h = cn_cdiv(H, 4), tiles_w = cn_cdiv(W, 4 * S);
+  const size_t smem = (size_t)16 * S * C * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    CN_HIP(hipFuncSetAttribute((const void*)cn_dwconv_ln_kernel<T, C, S>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)smem));
+    configured = true;
+  }
+  hipLaunchKernelGGL((cn_dwconv_ln_kernel<T, C, S>), dim3((unsigned)(B * tiles_h * tiles_w)), dim3(C * S), smem, s, x,
+                     H, W, tiles_h, tiles_w, bw.dw_w, bw.dw_b, bw.ln_w, bw.ln_b, y);
+  CN_LAUNCH_CHECK();
+  return CN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// downsample input: LayerNorm(channels_first == per-position over C, eps 1e-6) + 2x2/2 patchify
+// x fp32 (B,H,W,C) -> p T (B, H/2, W/2, (kh, kw, C)); rows/cols beyond 2*floor() are dropped.
+// One wave per input position.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cn_ln_patchify_kernel(const float* __restrict__ x, int H, int W, int C,
+                                                             long n_pos, const float* __restrict__ ln_w,
+                                                             const float* __restrict__ ln_b, T* __restrict__ p) {
+  const int lane = threadIdx.x & 63;
+  const long pos = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pos >= n_pos) return;
+  const int H2 = H / 2, W2 = W / 2;
+  const int w = (int)(pos % W);
+  const long t = pos / W;
+  const int h = (int)(t % H);
+  const int b = (int)(t / H);
+  if (h >= 2 * H2 || w >= 2 * W2) return;
+  const float* xi = x + (size_t)pos * C;
+  float v[12];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const int cc = lane + 64 * i;
+    v[i] = cc < C ? xi[cc] : 0.f;
+    s += v[i];
+  }
+  const float mean = cn_wave_sum(s) / (float)C;
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const int cc = lane + 64 * i;
+    const float d = cc < C ? v[i] - mean : 0.f;
+    s2 = fmaf(d, d, s2);
+  }
+  const float rstd = 1.0f / sqrtf(cn_wave_sum(s2) / (float)C + 1e-6f);
+  T* o = p + ((((size_t)b * H2 + (h >> 1)) * W2 + (w >> 1)) * 4 + ((h & 1) * 2 + (w & 1))) * C;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < C) o[cc] = cn_from_f32<T>((v[i] - mean) * rstd * ln_w[cc] + ln_b[cc]);
+  }
+}
+
+// frame_embs[b][t][c] = mean over the W freq positions (convnext.py:306); also an operand-type copy
+template <typename T>
+__global__ __launch_bounds__(256) void cn_frame_mean_kernel(const float* __restrict__ x, int W, int C,
+                                                            float* __restrict__ fe, T* __restrict__ fe_t) {
+  const size_t bt = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int w = 0; w < W; ++w) s += x[(bt * W + w) * C + c];
+    const float m = s / (float)W;
+    fe[bt * C + c] = m;
+    if (fe_t) fe_t[bt * C + c] = cn_from_f32<T>(m);
+  }
+}
+
+// clip head input: max_t + mean_t -> nn.LayerNorm(768, eps 1e-6) (convnext.py:324-330)
+template <typename T>
+__global__ __launch_bounds__(256) void cn_clip_pool_ln_kernel(const float* __restrict__ fe, int Tn,
+                                                              const float* __restrict__ ln_w,
+                                                              const float* __restrict__ ln_b, T* __restrict__ out) {
+  __shared__ float s_red[8];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float v[3];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = tid + 256 * i;
+    float mx = -INFINITY, sm = 0.f;
+    for (int t = 0; t < Tn; ++t) {
+      const float a = fe[((size_t)b * Tn + t) * CN_FEAT + c];
+      mx = fmaxf(mx, a);
+      sm += a;
+    }
+    v[i] = mx + sm / (float)Tn;
+    s += v[i];
+  }
+  s = cn_wave_sum(s);
+  if ((tid & 63) == 0) s_red[tid >> 6] = s;
+  __syncthreads();
+  const float mean = (s_red[0] + s_red[1] + s_red[2] + s_red[3]) * (1.0f / CN_FEAT);
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float d = v[i] - mean;
+    s2 = fmaf(d, d, s2);
+  }
+  s2 = cn_wave_sum(s2);
+  if ((tid & 63) == 0) s_red[4 + (tid >> 6)] = s2;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf((s_red[4] + s_red[5] + s_red[6] + s_red[7]) * (1.0f / CN_FEAT) + 1e-6f);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int c = tid + 256 * i;
+    out[(size_t)b * CN_FEAT + c] = cn_from_f32<T>((v[i] - mean) * rstd * ln_w[c] + ln_b[c]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// orchestration
+// ---------------------------------------------------------------------------------------------
+struct EncGeom {
+  int F, H[4], W[4];
+};
+static EncGeom enc_geom(int L) {
+  EncGeom g;
+  g.F = L / CN_HOP + 1;
+  g.H[0] = (g.F + 8 - 4) / 4 + 1;
+  g.W[0] = 56;
+  for (int i = 1; i < 4; ++i) {
+    g.H[i] = g.H[i - 1] / 2;
+    g.W[i] = g.W[i - 1] / 2;
+  }
+  return g;
+}
+
+extern "C" int32_t conette_num_frames(int32_t n_samples) { return n_samples / CN_HOP + 1; }
+extern "C" int32_t conette_num_audio_frames(int32_t n_samples) { return enc_geom(n_samples).H[3]; }
+
+struct EncWs {
+  float* logmel;
+  float* x;
+  void* y;
+  void* h;
+  void* fe_t;
+  void* clip_t;
+  size_t total;
+};
+static EncWs enc_ws(const conette_ctx* ctx, int B, int L, char* base) {
+  const EncGeom g = enc_geom(L);
+  const size_t es = ctx->esize;
+  const size_t n0 = (size_t)B * g.H[0] * g.W[0] * 96;
+  EncWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += cn_align(bytes);
+    return p;
+  };
+  w.logmel = (float*)take((size_t)B * g.F * CN_N_MELS * 4);
+  w.x = (float*)take(n0 * 4);
+  w.y = take(n0 * es);
+  w.h = take(n0 * 4 * es);
+  w.fe_t = take((size_t)B * g.H[3] * CN_FEAT * es);
+  w.clip_t = take((size_t)B * CN_FEAT * es);
+  w.total = off;
+  return w;
+}
+
+extern "C" size_t conette_encode_workspace_bytes(const conette_ctx* ctx, int32_t batch, int32_t n_samples) {
+  return enc_ws(ctx, batch, n_samples, nullptr).total;
+}
+
+template <typename T>
+static int dwconv_dispatch(int C, const float* x, int B, int H, int W, const CnBlockW& bw, T* y, hipStream_t s) {
+  switch (C) {
+    case 96: return launch_dwconv<T, 96, 2>(x, B, H, W, bw, y, s);
+    case 192: return launch_dwconv<T, 192, 1>(x, B, H, W, bw, y, s);
+    case 384: return launch_dwconv<T, 384, 1>(x, B, H, W, bw, y, s);
+    case 768: return launch_dwconv<T, 768, 1>(x, B, H, W, bw, y, s);
+  }
+  cn_set_error("dwconv: unsupported C=%d", C);
+  return CN_ERR_ARG;
+}
+
+static int tap_copy(float* dst, const float* src, size_t n, hipStream_t s) {
+  if (dst) CN_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return CN_OK;
+}
+
+template <typename T>
+static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float* frame_embs, float* clip_probs,
+                       const conette_encode_taps* taps, char* wsp, hipStream_t s) {
+  const EncGeom g = enc_geom(L);
+  EncWs ws = enc_ws(ctx, B, L, wsp);
+  T* y = (T*)ws.y;
+  T* hbuf = (T*)ws.h;
+  CN_TRY(cn_frontend(ctx, wave, B, L, ws.logmel, s));
+  if (taps) CN_TRY(tap_copy(taps->logmel, ws.logmel, (size_t)B * g.F * CN_N_MELS, s));
+  {
+    const long n_pos = (long)B * g.H[0] * g.W[0];
+    hipLaunchKernelGGL(cn_stem_kernel, dim3((unsigned)((n_pos + 63) / 64)), dim3(256), 0, s, ws.logmel, g.F, g.H[0],
+                       n_pos, ctx->stem_w, ctx->stem_b, ctx->stem_ln_w, ctx->stem_ln_b, ws.x);
+    CN_LAUNCH_CHECK();
+    if (taps) CN_TRY(tap_copy(taps->stem, ws.x, (size_t)n_pos * 96, s));
+  }
+  int blk = 0;
+  for (int st = 0; st < 4; ++st) {
+    const int C = CN_DIMS[st], H = g.H[st], W = g.W[st];
+    const long P = (long)B * H * W;
+    if (st > 0) {
+      const int Cp = CN_DIMS[st - 1], Hp = g.H[st - 1], Wp = g.W[st - 1];
+      const long n_in = (long)B * Hp * Wp;
+      const CnDownW& dw = ctx->down[st - 1];
+      hipLaunchKernelGGL((cn_ln_patchify_kernel<T>), dim3((unsigned)((n_in + 3) / 4)), dim3(256), 0, s, ws.x, Hp, Wp,
+                         Cp, n_in, dw.ln_w, dw.ln_b, y);
+      CN_LAUNCH_CHECK();
+      EpiBiasAct<float> epi{dw.bias, ws.x, C, ACT_NONE};
+      CN_TRY((cn_gemm<T>(y, 4 * Cp, (const T*)dw.w, 4 * Cp, (int)P, C, 4 * Cp, epi, s)));
+      if (taps) CN_TRY(tap_copy(taps->down[st], ws.x, (size_t)P * C, s));
+    }
+    for (int b = 0; b < CN_DEPTHS[st]; ++b, ++blk) {
+      const CnBlockW& bw = ctx->blocks[blk];
+      CN_TRY(dwconv_dispatch<T>(C, ws.x, B, H, W, bw, y, s));
+      EpiBiasAct<T> e1{bw.b1, hbuf, 4 * C, ACT_GELU};
+      CN_TRY((cn_gemm<T>(y, C, (const T*)bw.w1, C, (int)P, 4 * C, C, e1, s)));
+      EpiResid e2{bw.b2, bw.scale, ws.x, ws.x, C};
+      CN_TRY((cn_gemm<T>(hbuf, 4 * C, (const T*)bw.w2, 4 * C, (int)P, C, 4 * C, e2, s)));
+      if (taps && b == 0) CN_TRY(tap_copy(taps->stage_block0[st], ws.x, (size_t)P * C, s));
+    }
+    if (taps) CN_TRY(tap_copy(taps->stage[st], ws.x, (size_t)P * C, s));
+  }
+  const int Tn = g.H[3];
+  hipLaunchKernelGGL((cn_frame_mean_kernel<T>), dim3((unsigned)(B * Tn)), dim3(256), 0, s, ws.x, g.W[3], CN_FEAT,
+                     frame_embs, (T*)nullptr);
+  CN_LAUNCH_CHECK();
+  if (clip_probs) {
+    hipLaunchKernelGGL((cn_clip_pool_ln_kernel<T>), dim3((unsigned)B), dim3(256), 0, s, frame_embs, Tn, ctx->norm_w,
+                       ctx->norm_b, (T*)ws.clip_t);
+    CN_LAUNCH_CHECK();
+    EpiBiasAct<float> eh{ctx->head_b, clip_probs, CN_N_TAGS, ACT_SIGMOID};
+    CN_TRY((cn_gemm<T>((const T*)ws.clip_t, CN_FEAT, (const T*)ctx->head_w, CN_FEAT, B, CN_N_TAGS, CN_FEAT, eh, s)));
+  }
+  return CN_OK;
+}
+
+extern "C" int conette_frontend_logmel(conette_ctx* ctx, const float* wave, int32_t batch, int32_t n_samples,
+                                       float* out, void* stream) {
+  if (!ctx || !wave || !out || batch <= 0) {
+    cn_set_error("frontend_logmel: bad argument");
+    return CN_ERR_ARG;
+  }
+  return cn_frontend(ctx, wave, batch, n_samples, out, (hipStream_t)stream);
+}
+
+extern "C" int conette_encode(conette_ctx* ctx, const float* wave, int32_t batch, int32_t n_samples,
+                              float* frame_embs, float* clip_probs, const conette_encode_taps* taps, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  if (!ctx || !wave || !frame_embs || !workspace || batch <= 0) {
+    cn_set_error("encode: bad argument");
+    return CN_ERR_ARG;
+  }
+  if (conette_num_audio_frames(n_samples) < 1) {
+    cn_set_error("encode: n_samples=%d too short", n_samples);
+    return CN_ERR_ARG;
+  }
+  const size_t need = conette_encode_workspace_bytes(ctx, batch, n_samples);
+  if (workspace_bytes < need) {
+    cn_set_error("encode: workspace %zu < %zu", workspace_bytes, need);
+    return CN_ERR_WORKSPACE;
+  }
+  if (ctx->cfg.precision == CONETTE_PREC_BF16)
+    return encode_impl<bf16_t>(ctx, wave, batch, n_samples, frame_embs, clip_probs, taps, (char*)workspace,
+                               (hipStream_t)stream);
+  return encode_impl<float>(ctx, wave, batch, n_samples, frame_embs, clip_probs, taps, (char*)workspace,
+                            (hipStream_t)stream);
+}

@@ -1,0 +1,259 @@
+"""ctypes binding of libconette_hip.so (include/conette_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every dense stage of the hot
+path runs in the hand-written HIP library.  There is NO CPU / eager fallback: if the library
+is missing or a call fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libconette_hip.so")
+
+PREC_F32 = 0
+PREC_BF16 = 1
+N_MELS = 224
+FEAT = 768
+N_TAGS = 527
+
+EXPORTS = (
+    "conette_last_error", "conette_abi_version", "conette_create", "conette_destroy", "conette_num_frames",
+    "conette_num_audio_frames", "conette_encode_workspace_bytes", "conette_decode_workspace_bytes",
+    "conette_frontend_logmel", "conette_encode", "conette_decode", "conette_resample", "conette_resample_len",
+)
+
+
+class ConetteConfigC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("precision", "vocab_size", "d_model", "nhead", "n_layers", "d_ff", "pad_id",
+                                         "bos_id", "eos_id")] + [("reserved", C.c_int32 * 7)]
+
+
+class EncodeTapsC(C.Structure):
+    _fields_ = [("logmel", C.c_void_p), ("stem", C.c_void_p), ("stage_block0", C.c_void_p * 4),
+                ("stage", C.c_void_p * 4), ("down", C.c_void_p * 4)]
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the in-tree library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(the MI355X path has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    lib.conette_last_error.restype = C.c_char_p
+    lib.conette_abi_version.restype = C.c_int
+    lib.conette_create.restype = C.c_int
+    lib.conette_create.argtypes = [C.POINTER(ConetteConfigC), C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p),
+                                   C.POINTER(C.c_int64), C.POINTER(C.c_void_p)]
+    lib.conette_destroy.restype = None
+    lib.conette_destroy.argtypes = [C.c_void_p]
+    lib.conette_num_frames.restype = C.c_int32
+    lib.conette_num_frames.argtypes = [C.c_int32]
+    lib.conette_num_audio_frames.restype = C.c_int32
+    lib.conette_num_audio_frames.argtypes = [C.c_int32]
+    lib.conette_encode_workspace_bytes.restype = C.c_size_t
+    lib.conette_encode_workspace_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.conette_decode_workspace_bytes.restype = C.c_size_t
+    lib.conette_decode_workspace_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    lib.conette_frontend_logmel.restype = C.c_int
+    lib.conette_frontend_logmel.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.conette_encode.restype = C.c_int
+    lib.conette_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                   C.POINTER(EncodeTapsC), C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.conette_decode.restype = C.c_int
+    lib.conette_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.conette_resample.restype = C.c_int
+    lib.conette_resample.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.conette_resample_len.restype = C.c_int32
+    lib.conette_resample_len.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    if lib.conette_abi_version() != 1:
+        raise RuntimeError("libconette_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(status: int, what: str) -> None:
+    if status != 0:
+        raise RuntimeError(f"{what} failed ({status}): {load_library().conette_last_error().decode()}")
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def encoder_geometry(n_samples: int) -> Tuple[int, list, list]:
+    """(F, H[4], W[4]) -- SURVEY.md A.6."""
+    f = n_samples // 320 + 1
+    h = [(f + 8 - 4) // 4 + 1]
+    w = [56]
+    for _ in range(3):
+        h.append(h[-1] // 2)
+        w.append(w[-1] // 2)
+    return f, h, w
+
+
+class Engine:
+    """Opaque context (packed weights) + caller-owned workspaces for one device."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], *, precision: str = "bf16", d_model: int = 256,
+                 nhead: int = 8, n_layers: int = 6, d_ff: int = 2048, pad_id: int = 0, bos_id: int = 1,
+                 eos_id: int = 2, device: Optional[torch.device] = None) -> None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("conette_amd.Engine needs a ROCm GPU (no CPU fallback)")
+        self.lib = load_library()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.precision = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16}[precision]
+        self.precision_name = "bf16" if self.precision == PREC_BF16 else "fp32"
+        vocab = int(state_dict["model.decoder.classifier.weight"].shape[0])
+        self.vocab_size = vocab
+        self.d_model, self.nhead, self.n_layers, self.d_ff = d_model, nhead, n_layers, d_ff
+        cfg = ConetteConfigC(self.precision, vocab, d_model, nhead, n_layers, d_ff, pad_id, bos_id, eos_id)
+        keep, names, ptrs, numel = [], [], [], []
+        with torch.cuda.device(self.device):
+            for k, v in state_dict.items():
+                if not isinstance(v, torch.Tensor) or k == "_extra_state_":
+                    continue
+                if v.dtype == torch.bool:
+                    v = v.to(torch.uint8)
+                elif v.is_floating_point():
+                    v = v.to(torch.float32)
+                v = v.to(self.device).contiguous()
+                keep.append(v)
+                names.append(k.encode())
+                ptrs.append(v.data_ptr())
+                numel.append(v.numel())
+            n = len(names)
+            handle = C.c_void_p()
+            torch.cuda.synchronize(self.device)
+            st = self.lib.conette_create(C.byref(cfg), n, (C.c_char_p * n)(*names), (C.c_void_p * n)(*ptrs),
+                                         (C.c_int64 * n)(*numel), C.byref(handle))
+            _check(st, "conette_create")
+            torch.cuda.synchronize(self.device)
+        self._ctx = handle
+        self._ws: Dict[str, torch.Tensor] = {}
+        del keep
+
+    def __del__(self) -> None:
+        ctx = getattr(self, "_ctx", None)
+        if ctx:
+            try:
+                self.lib.conette_destroy(ctx)
+            except Exception:
+                pass
+            self._ctx = None
+
+    def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    # ---- a2 --------------------------------------------------------------------------------
+    def frontend_logmel(self, wave: torch.Tensor) -> torch.Tensor:
+        wave = wave.to(self.device, torch.float32).contiguous()
+        b, l = wave.shape
+        out = torch.empty((b, self.lib.conette_num_frames(l), N_MELS), dtype=torch.float32, device=self.device)
+        _check(self.lib.conette_frontend_logmel(self._ctx, _ptr(wave), b, l, _ptr(out), _stream()), "frontend_logmel")
+        return out
+
+    # ---- a2-a7 -----------------------------------------------------------------------------
+    def encode(self, wave: torch.Tensor, taps: bool = False, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        """wave (B, L) fp32 on device -> frame_embs (B, T, 768), clip_probs (B, 527) [, taps dict]."""
+        wave = wave.to(self.device, torch.float32).contiguous()
+        b, l = wave.shape
+        f, hs, ws_ = encoder_geometry(l)
+        t = hs[3]
+        if out is None:
+            frame_embs = torch.empty((b, t, FEAT), dtype=torch.float32, device=self.device)
+            clip = torch.empty((b, N_TAGS), dtype=torch.float32, device=self.device)
+        else:
+            frame_embs, clip = out
+        need = self.lib.conette_encode_workspace_bytes(self._ctx, b, l)
+        wsb = self._workspace("enc", need)
+        tap_struct, tap_out = None, None
+        if taps:
+            dims = (96, 192, 384, 768)
+            e = lambda *s: torch.empty(s, dtype=torch.float32, device=self.device)
+            tap_out = {"logmel": e(b, f, N_MELS), "stem": e(b, hs[0], ws_[0], 96)}
+            for i in range(4):
+                tap_out[f"stage{i}_block0"] = e(b, hs[i], ws_[i], dims[i])
+                tap_out[f"stage{i}"] = e(b, hs[i], ws_[i], dims[i])
+                if i > 0:
+                    tap_out[f"down{i}"] = e(b, hs[i], ws_[i], dims[i])
+            tap_struct = EncodeTapsC()
+            tap_struct.logmel = tap_out["logmel"].data_ptr()
+            tap_struct.stem = tap_out["stem"].data_ptr()
+            for i in range(4):
+                tap_struct.stage_block0[i] = tap_out[f"stage{i}_block0"].data_ptr()
+                tap_struct.stage[i] = tap_out[f"stage{i}"].data_ptr()
+                tap_struct.down[i] = tap_out[f"down{i}"].data_ptr() if i > 0 else 0
+        st = self.lib.conette_encode(self._ctx, _ptr(wave), b, l, _ptr(frame_embs), _ptr(clip),
+                                     C.byref(tap_struct) if tap_struct is not None else None, _ptr(wsb),
+                                     wsb.numel(), _stream())
+        _check(st, "conette_encode")
+        if taps:
+            return frame_embs, clip, tap_out
+        return frame_embs, clip
+
+    # ---- a9-a14 ----------------------------------------------------------------------------
+    def decode(self, frame_embs: torch.Tensor, frame_lens: torch.Tensor, bos_ids: torch.Tensor,
+               forbid_mask: Optional[torch.Tensor], beam: int, min_pred: int, max_pred: int,
+               want_step0_logits: bool = False) -> Dict[str, torch.Tensor]:
+        frame_embs = frame_embs.to(self.device, torch.float32).contiguous()
+        b, t, _ = frame_embs.shape
+        frame_lens = frame_lens.to(self.device, torch.int32).contiguous()
+        bos_ids = bos_ids.to(self.device, torch.int32).contiguous()
+        if forbid_mask is not None:
+            forbid_mask = forbid_mask.to(self.device).to(torch.uint8).contiguous()
+            if forbid_mask.numel() != self.vocab_size:
+                raise ValueError("forbid_mask must have vocab_size entries")
+        dev = self.device
+        best_preds = torch.empty((b, max_pred), dtype=torch.int32, device=dev)
+        best_lp = torch.empty((b,), dtype=torch.float32, device=dev)
+        mult_preds = torch.empty((b, beam, max_pred), dtype=torch.int32, device=dev)
+        mult_lp = torch.empty((b, beam), dtype=torch.float32, device=dev)
+        sizes = torch.empty((2,), dtype=torch.int32, device=dev)
+        ldv = (self.vocab_size + 7) // 8 * 8
+        s0 = torch.empty((b * beam, ldv), dtype=torch.float32, device=dev) if want_step0_logits else None
+        need = self.lib.conette_decode_workspace_bytes(self._ctx, b, t, beam, max_pred)
+        wsb = self._workspace("dec", need)
+        st = self.lib.conette_decode(self._ctx, _ptr(frame_embs), _ptr(frame_lens), _ptr(bos_ids), _ptr(forbid_mask),
+                                     b, t, beam, min_pred, max_pred, _ptr(best_preds), _ptr(best_lp), _ptr(mult_preds),
+                                     _ptr(mult_lp), _ptr(sizes), _ptr(s0), _ptr(wsb), wsb.numel(), _stream())
+        _check(st, "conette_decode")
+        out = {"best_preds": best_preds, "best_lprobs": best_lp, "mult_preds": mult_preds, "mult_lprobs": mult_lp,
+               "sizes": sizes}
+        if s0 is not None:
+            out["step0_logits"] = s0[:, : self.vocab_size]
+        return out
+
+    # ---- a1 --------------------------------------------------------------------------------
+    def resample(self, x: torch.Tensor, orig_sr: int, new_sr: int) -> torch.Tensor:
+        """(..., n) fp32 -> (..., ceil(n * new / orig)); torchaudio sinc_interpolation defaults."""
+        if orig_sr == new_sr:
+            return x
+        shape = x.shape
+        x2 = x.to(self.device, torch.float32).reshape(-1, shape[-1]).contiguous()
+        n_out = self.lib.conette_resample_len(shape[-1], int(orig_sr), int(new_sr))
+        out = torch.empty((x2.shape[0], n_out), dtype=torch.float32, device=self.device)
+        _check(self.lib.conette_resample(_ptr(x2), x2.shape[0], shape[-1], int(orig_sr), int(new_sr), _ptr(out),
+                                         _stream()), "conette_resample")
+        return out.reshape(*shape[:-1], n_out)

@@ -1,0 +1,271 @@
+"""CoNeTTEModel -- drop-in for the reference's inference API on MI355X.
+
+Mirrors ``conette.huggingface.model.CoNeTTEModel`` (reference huggingface/model.py:38-289) and
+the inference methods of ``CoNeTTEPLM`` (pl_modules/conette.py:352-525): same constructor
+arguments, ``from_pretrained(name_or_dir, config=...)``, ``model(x, sr, x_shapes, preprocess,
+threshold, task, beam_size, min_pred_size, max_pred_size, forbid_rep_mode)`` and the same
+output dict.  All dense work runs in libconette_hip.so through ``engine.Engine``.
+"""
+from __future__ import annotations
+
+import csv
+import json
+import logging
+import os
+import os.path as osp
+from pathlib import Path
+from typing import Any, Dict, Iterable, List, Optional, Union
+
+import torch
+from torch import Size, Tensor
+
+from .config import CoNeTTEConfig
+from .engine import Engine
+from .preprocessor import CoNeTTEPreprocessor
+from .tokenizer import AACTokenizer, ENGLISH_STOPWORDS, unpickle_extra_state
+
+pylog = logging.getLogger(__name__)
+
+FORBID_MODES = ("none", "all", "content_words")
+
+
+def load_audioset_idx_to_name(offline: bool = False, cache_path: Union[str, Path, None] = None) -> Dict[int, str]:
+    """transforms/audioset_mapping.py:102-107: index -> display_name from class_labels_indices.csv."""
+    cache = Path(cache_path) if cache_path is not None else Path.home().joinpath(".cache", "audioset_mapping")
+    fpath = cache.joinpath("class_labels_indices.csv")
+    if not osp.isfile(fpath):
+        if offline:
+            raise FileNotFoundError(
+                f"Cannot find or download audioset mapping file in '{fpath}' with mode offline={offline}.")
+        from torch.hub import download_url_to_file
+        os.makedirs(cache, exist_ok=True)
+        download_url_to_file("http://storage.googleapis.com/us_audioset/youtube_corpus/v1/csv/class_labels_indices.csv",
+                             str(fpath), progress=False)
+    with open(fpath, "r") as file:
+        data = list(csv.DictReader(file, skipinitialspace=True, strict=True))
+    return {int(d["index"]): d["display_name"] for d in data}
+
+
+def probs_to_names(probs: Tensor, threshold: Union[float, Tensor], idx_to_name: Dict[int, str]) -> List[List[str]]:
+    mask = (probs >= threshold).cpu()
+    return [[idx_to_name[int(j)] for j in torch.where(row)[0].tolist()] for row in mask]
+
+
+def _read_state_dict(path: str) -> Dict[str, Tensor]:
+    st = osp.join(path, "model.safetensors")
+    if osp.isfile(st):
+        from safetensors.torch import load_file
+        return load_file(st)
+    for name in ("pytorch_model.bin", "model.pt", "model.bin"):
+        fp = osp.join(path, name)
+        if osp.isfile(fp):
+            return torch.load(fp, map_location="cpu", weights_only=True)
+    raise FileNotFoundError(f"No weights file (model.safetensors / pytorch_model.bin) in '{path}'.")
+
+
+class CoNeTTEModel:
+    """CoNeTTE for inference; weights live packed on the GPU inside the HIP context."""
+
+    config_class = CoNeTTEConfig
+
+    def __init__(self, config: CoNeTTEConfig, device: Union[str, torch.device, None] = "cuda_if_available",
+                 inference: bool = True, offline: bool = False, model_override: Any = None, *,
+                 state_dict: Optional[Dict[str, Tensor]] = None, precision: str = "bf16",
+                 audioset_idx_to_name: Optional[Dict[int, str]] = None,
+                 stopwords: Optional[Iterable[str]] = None) -> None:
+        if model_override is not None:
+            raise NotImplementedError("model_override (Lightning checkpoints) is not supported by the MI355X path.")
+        if not inference:
+            raise NotImplementedError("The MI355X path is inference-only (reference training stack is out of scope).")
+        if state_dict is None:
+            raise ValueError("CoNeTTEModel needs weights: use CoNeTTEModel.from_pretrained(dir) or pass state_dict=.")
+        if device in ("cuda_if_available", None, "auto"):
+            device = "cuda"
+        self.config = config
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("conette_amd runs on a ROCm GPU only; there is no CPU fallback.")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        state_dict = dict(state_dict)
+        # non-tensor state: pickled dict in `_extra_state_` (model.py:126-139)
+        tok_state = None
+        if "_extra_state_" in state_dict:
+            extra = unpickle_extra_state(state_dict.pop("_extra_state_"))
+            tok_state = extra.get("model.tokenizers.0._extra_state")
+        if tok_state is None:
+            tok_state = config.tokenizer_state
+        if tok_state is None:
+            raise RuntimeError("Cannot build the model from state_dict. (tokenizer is not fit)")
+        self.tokenizer = AACTokenizer.from_txt_state(tok_state)
+        # task tokens (conette.py:103-129); present in a trained tokenizer, appended otherwise
+        self.task_name_to_token_id: Dict[str, int] = {}
+        if config.task_mode in ("ds", "ds_src"):
+            for name in config.task_names:
+                token = f"<bos_{name}>"
+                self.task_name_to_token_id[name] = (self.tokenizer.token_to_id(token) if self.tokenizer.has(token)
+                                                    else self.tokenizer.add_special_token(token))
+        elif config.task_mode != "none":
+            raise ValueError(f"Invalid argument {config.task_mode=}.")
+        vocab = self.tokenizer.get_vocab_size()
+        cls_rows = int(state_dict["model.decoder.classifier.weight"].shape[0])
+        if cls_rows != vocab:
+            raise RuntimeError(f"vocab size mismatch: tokenizer {vocab} vs classifier {cls_rows}")
+        if "model.task_id_to_token_id" in state_dict:
+            self.task_id_to_token_id = state_dict["model.task_id_to_token_id"].to(torch.long).cpu()
+        else:
+            self.task_id_to_token_id = torch.as_tensor([self.task_name_to_token_id[n] for n in config.task_names])
+        frm = state_dict.get("model.forbid_rep_mask")
+        self.forbid_rep_mask: Optional[Tensor] = None if frm is None else frm.to(torch.bool).to(self.device)
+        self._stopwords = list(ENGLISH_STOPWORDS if stopwords is None else stopwords)
+        self.audioset_idx_to_name = (load_audioset_idx_to_name(offline=offline) if audioset_idx_to_name is None
+                                     else dict(audioset_idx_to_name))
+        with torch.cuda.device(self.device):
+            self.engine = Engine(state_dict, precision=precision, d_model=config.d_model, nhead=config.nhead,
+                                 n_layers=config.num_decoder_layers, d_ff=config.dim_feedforward,
+                                 pad_id=self.tokenizer.pad_token_id, bos_id=self.tokenizer.bos_token_id,
+                                 eos_id=self.tokenizer.eos_token_id, device=self.device)
+        self.preprocessor = CoNeTTEPreprocessor(self.engine, verbose=config.verbose)
+        self.training = False
+
+    # ---- construction -----------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, *args, config: Optional[CoNeTTEConfig] = None,
+                        **kwargs) -> "CoNeTTEModel":
+        path = str(pretrained_model_name_or_path)
+        if not osp.isdir(path):
+            from huggingface_hub import snapshot_download  # needs network; raises offline
+            path = snapshot_download(path)
+        if config is None:
+            config = CoNeTTEConfig.from_pretrained(path)
+        return cls(config, *args, state_dict=_read_state_dict(path), **kwargs)
+
+    # ---- reference properties / methods (model.py:109-124) -------------------------------------
+    @property
+    def default_task(self) -> str:
+        return next(iter(self.config.task_names))
+
+    @property
+    def tasks(self) -> List[str]:
+        return list(self.config.task_names)
+
+    def train_and_enable_grad(self, mode: bool = True) -> "CoNeTTEModel":
+        if mode:
+            raise NotImplementedError("The MI355X path is inference-only.")
+        return self
+
+    def eval_and_disable_grad(self, mode: bool = True) -> "CoNeTTEModel":
+        return self.train_and_enable_grad(not mode)
+
+    def eval(self) -> "CoNeTTEModel":
+        return self
+
+    # ---- helpers ---------------------------------------------------------------------------------
+    def get_forbid_rep_mask(self, mode: Optional[str]) -> Optional[Tensor]:
+        """pl_modules/common.py:222-299; None -> the checkpoint's persisted mask (conette.py:427-433)."""
+        if mode is None:
+            return self.forbid_rep_mask
+        vocab = self.tokenizer.get_vocab_size()
+        if mode == "none":
+            return None
+        if mode == "all":
+            return torch.ones((vocab,), dtype=torch.bool, device=self.device)
+        if mode == "content_words":
+            mask = torch.ones((vocab,), dtype=torch.bool)
+            for word in set(self._stopwords):
+                if self.tokenizer.has(word):
+                    mask[self.tokenizer.token_to_id(word)] = False
+            return mask.to(self.device)
+        raise ValueError(f"Invalid argument forbid_rep_mode={mode!r}. (expected one of {FORBID_MODES})")
+
+    def batch_to_task_token_ids(self, datasets: List[str], sources: List[Optional[str]]) -> Tensor:
+        """conette.py:486-525."""
+        bsize = len(datasets)
+        mode = self.config.task_mode
+        if mode == "none":
+            return torch.full((bsize,), self.tokenizer.bos_token_id, dtype=torch.long)
+        task_to_idx = {name: i for i, name in enumerate(self.config.task_names)}
+        if mode == "ds":
+            idx = [task_to_idx[ds] for ds in datasets]
+        elif mode == "ds_src":
+            names = [ds if src is None else f"{ds}_{src}".lower() for ds, src in zip(datasets, sources)]
+            idx = [task_to_idx[n] for n in names]
+        else:
+            raise ValueError(f"Invalid task mode {mode} for batch_to_task_token_ids.")
+        return self.task_id_to_token_id[torch.as_tensor(idx, dtype=torch.long)]
+
+    # ---- forward (model.py:185-261) -----------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, x: Union[Tensor, str, Iterable[str], Iterable[Tensor]],
+                sr: Union[None, int, Iterable[int]] = None, x_shapes: Union[Tensor, None, List[Size]] = None,
+                preprocess: bool = True, threshold: Union[float, Tensor] = 0.3,
+                task: Union[str, List[str], None] = None, beam_size: Optional[int] = None,
+                min_pred_size: Optional[int] = None, max_pred_size: Optional[int] = None,
+                forbid_rep_mode: Optional[str] = None) -> Dict[str, Any]:
+        with torch.cuda.device(self.device):
+            if preprocess:
+                batch = self.preprocessor(x, sr, x_shapes)
+                clip_probs = batch.pop("clip_probs")
+                tags = probs_to_names(clip_probs, threshold, self.audioset_idx_to_name)
+            else:
+                assert isinstance(x, Tensor) and isinstance(x_shapes, Tensor)
+                batch = {"audio": x.to(self.device), "audio_shape": x_shapes.to(self.device)}
+                clip_probs, tags = None, None
+
+            bsize = len(batch["audio"])
+            if task is None:
+                tasks = [self.default_task] * bsize
+            elif isinstance(task, str):
+                tasks = [task] * bsize
+            elif len(task) != bsize:
+                raise ValueError(f"Invalid number of tasks with input. (found {len(task)} tasks but {bsize} elements)")
+            else:
+                tasks = task
+            del task
+            for task in tasks:
+                if task not in self.config.task_names:
+                    raise ValueError(f"Invalid argument {tasks=}. (task {task} is not in {self.config.task_names})")
+            dataset_lst = [self.default_task] * bsize
+            source_lst: List[Optional[str]] = [None] * bsize
+            for i, task in enumerate(tasks):
+                parts = task.split("_")
+                dataset_lst[i] = parts[0]
+                if len(parts) >= 2:
+                    source_lst[i] = "_".join(parts[1:])
+
+            outs = self._generate(batch["audio"], batch["audio_shape"], dataset_lst, source_lst,
+                                  beam_size=beam_size, min_pred_size=min_pred_size, max_pred_size=max_pred_size,
+                                  forbid_rep_mode=forbid_rep_mode)
+            outs["tasks"] = tasks
+            if clip_probs is not None and tags is not None:
+                outs["tags_probs"] = clip_probs
+                outs["tags"] = tags
+            return outs
+
+    def __call__(self, x, sr=None, x_shapes=None, preprocess: bool = True, threshold=0.3, task=None, beam_size=None,
+                 min_pred_size=None, max_pred_size=None, forbid_rep_mode=None) -> Dict[str, Any]:
+        return self.forward(x=x, sr=sr, x_shapes=x_shapes, preprocess=preprocess, threshold=threshold, task=task,
+                            beam_size=beam_size, min_pred_size=min_pred_size, max_pred_size=max_pred_size,
+                            forbid_rep_mode=forbid_rep_mode)
+
+    def _generate(self, audio: Tensor, audio_shape: Tensor, datasets: List[str], sources: List[Optional[str]], *,
+                  beam_size=None, min_pred_size=None, max_pred_size=None, forbid_rep_mode=None) -> Dict[str, Any]:
+        """CoNeTTEPLM.forward("generate") = encode_audio + decode_audio + decode_text (conette.py:352-450)."""
+        if audio.ndim == 4:  # FrameIdentEncoder (nn/encoders/ident.py:19-21)
+            audio = audio.squeeze(dim=1)
+        cfg = self.config
+        beam = cfg.beam_size if beam_size is None else int(beam_size)
+        min_pred = cfg.min_pred_size if min_pred_size is None else int(min_pred_size)
+        max_pred = cfg.max_pred_size if max_pred_size is None else int(max_pred_size)
+        assert beam > 0 and min_pred >= 0
+        lens = audio_shape[:, 1].to(torch.int32)
+        bos = self.batch_to_task_token_ids(datasets, sources)
+        res = self.engine.decode(audio, lens, bos, self.get_forbid_rep_mask(forbid_rep_mode), beam, min_pred, max_pred)
+        pred_size, best_maxlen = (int(v) for v in res["sizes"].tolist())  # the one host sync of the path
+        preds = res["best_preds"][:, :best_maxlen].to(torch.long).contiguous()
+        mult_preds = res["mult_preds"][:, :, :pred_size].to(torch.long).contiguous()
+        return {
+            "cands": self.tokenizer.decode_rec(preds), "preds": preds, "lprobs": res["best_lprobs"],
+            "mult_cands": self.tokenizer.decode_rec(mult_preds), "mult_preds": mult_preds,
+            "mult_lprobs": res["mult_lprobs"],
+        }

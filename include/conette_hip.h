@@ -1,0 +1,118 @@
+/* conette_hip.h -- C ABI of the MI355X (gfx950) CoNeTTE inference library (libconette_hip.so).
+ *
+ * The reference (Labbeti/conette-audio-captioning v0.3.1) is pure Python and has NO FFI layer
+ * (SURVEY.md section 8b): these entry points sit UNDER the Python operator API that the build's
+ * host package (conette_amd) keeps, one per dense stage of the hot path.  Each declaration
+ * names the reference interface it replaces (paths relative to /root/reference/src/conette/).
+ *
+ * Conventions
+ *   - every pointer marked "dev" is a device pointer owned by the caller (PyTorch caching
+ *     allocator); the library allocates only inside conette_create (packed weights + tables);
+ *   - all entry points are asynchronous on `stream` (a hipStream_t passed as void*), never
+ *     call hipDeviceSynchronize, and may be captured into a hipGraph;
+ *   - return value: 0 = ok, non-zero = error code, text via conette_last_error();
+ *     no C++ exception crosses the boundary;
+ *   - one host thread per device/process.
+ */
+#ifndef CONETTE_HIP_H
+#define CONETTE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CONETTE_ABI_VERSION 1
+
+/* precision of GEMM operands / intermediate activations (accumulation is always fp32,
+ * the residual streams are always fp32) */
+#define CONETTE_PREC_F32 0  /* v_mfma_f32_16x16x4_f32: exact-fp32 parity mode          */
+#define CONETTE_PREC_BF16 1 /* v_mfma_f32_16x16x32_bf16: throughput mode (BASELINE cfg) */
+
+typedef struct conette_ctx conette_ctx; /* opaque: packed weights + constant tables */
+
+/* Hyper-parameters; mirrors CoNeTTEConfig (huggingface/config.py:13-88) + tokenizer ids
+ * (tokenization/constants.py:15). */
+typedef struct conette_config {
+  int32_t precision;    /* CONETTE_PREC_* */
+  int32_t vocab_size;   /* rows of model.decoder.classifier.weight */
+  int32_t d_model;      /* 256 */
+  int32_t nhead;        /* 8   */
+  int32_t n_layers;     /* 6   */
+  int32_t d_ff;         /* 2048 */
+  int32_t pad_id;       /* 0 */
+  int32_t bos_id;       /* 1 */
+  int32_t eos_id;       /* 2 */
+  int32_t reserved[7];
+} conette_config;
+
+/* Optional per-stage outputs of conette_encode for parity tests: fp32, channels-last
+ * (B, H, W, C) unless noted; any pointer may be NULL. */
+typedef struct conette_encode_taps {
+  float* logmel;        /* (B, F, 224)  bn0 output (convnext.py:276-292) */
+  float* stem;          /* (B, 252, 56, 96)  downsample_layers[0] output */
+  float* stage_block0[4]; /* output of the first block of stage i */
+  float* stage[4];      /* output of stage i */
+  float* down[4];       /* output of downsample_layers[i], i = 1..3 ([0] unused) */
+} conette_encode_taps;
+
+const char* conette_last_error(void);
+int conette_abi_version(void);
+
+/* Build a context from the reference state dict: `names[i]` is the
+ * reference key (e.g. "preprocessor.encoder.stages.0.0.pwconv1.weight"), `tensors[i]` a dev
+ * pointer to the contiguous fp32 tensor (bool tensors as uint8, int64 as int64), `numel[i]`
+ * its element count.  Replaces module construction + load_state_dict of
+ * huggingface/model.py:41-107,126-163.  Synchronous (runs once). */
+int conette_create(const conette_config* cfg, int32_t n_tensors, const char* const* names,
+                   const void* const* tensors, const int64_t* numel, conette_ctx** out);
+void conette_destroy(conette_ctx* ctx);
+
+/* Geometry helpers: STFT frames F = L/320 + 1; encoder frames T (convnext.py stem + 3 /2). */
+int32_t conette_num_frames(int32_t n_samples);
+int32_t conette_num_audio_frames(int32_t n_samples);
+
+/* Bytes of caller-provided scratch needed by conette_encode / conette_decode. */
+size_t conette_encode_workspace_bytes(const conette_ctx* ctx, int32_t batch, int32_t n_samples);
+size_t conette_decode_workspace_bytes(const conette_ctx* ctx, int32_t batch, int32_t t_audio, int32_t beam,
+                                      int32_t max_pred);
+
+/* a2: log-mel frontend (convnext.py:270-292 + torchlibrosa Spectrogram/LogmelFilterBank + bn0).
+ * wave: dev (B, L) fp32 mono @ 32 kHz, zero-padded to L.  out: dev (B, F, 224) fp32. */
+int conette_frontend_logmel(conette_ctx* ctx, const float* wave, int32_t batch, int32_t n_samples, float* out,
+                            void* stream);
+
+/* a2-a7: ConvNeXt.forward (convnext.py:264-336) + the transpose of preprocessor.py:66.
+ *   frame_embs : dev (B, T, 768) fp32      ("audio" of preprocessor.py:71-75)
+ *   clip_probs : dev (B, 527) fp32         (sigmoid(head_audioset), convnext.py:324-334) */
+int conette_encode(conette_ctx* ctx, const float* wave, int32_t batch, int32_t n_samples, float* frame_embs,
+                   float* clip_probs, const conette_encode_taps* taps, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
+/* a9-a14: CoNeTTEPLM.encode_audio + decode_audio("generate") = nn/decoding/beam.py:22-227 with
+ * the decoder of nn/decoders/aac_tfmer.py:71-118, KV-cached, whole search loop on device.
+ *   frame_embs  : dev (B, T, 768) fp32           frame_lens : dev (B) int32 valid frames
+ *   bos_ids     : dev (B) int32 task tokens      forbid_mask: dev (V) uint8 or NULL
+ * Outputs (all dev, full width; trim on host with out_sizes):
+ *   best_preds  (B, max_pred) int32   best_lprobs (B) fp32
+ *   mult_preds  (B, beam, max_pred) int32   mult_lprobs (B, beam) fp32
+ *   out_sizes   (2) int32: [0] = pred_size (beam.py:192-194,207-211), [1] = best_maxlen (:222-225)
+ *   step_logits : optional dev (B*beam, ld_v) fp32 copy of the step-0 logits (parity), or NULL */
+int conette_decode(conette_ctx* ctx, const float* frame_embs, const int32_t* frame_lens, const int32_t* bos_ids,
+                   const uint8_t* forbid_mask, int32_t batch, int32_t t_audio, int32_t beam,
+                   int32_t min_pred, int32_t max_pred, int32_t* best_preds, float* best_lprobs,
+                   int32_t* mult_preds, float* mult_lprobs, int32_t* out_sizes, float* step0_logits,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* a1: torchaudio.functional.resample (preprocessor.py:134-141), sinc_interpolation width 6,
+ * rolloff 0.99.  in: dev (rows, n_in) fp32; out: dev (rows, n_out), n_out = ceil(n_in*new/orig). */
+int conette_resample(const float* in, int32_t rows, int32_t n_in, int32_t orig_sr, int32_t new_sr, float* out,
+                     void* stream);
+int32_t conette_resample_len(int32_t n_in, int32_t orig_sr, int32_t new_sr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONETTE_HIP_H */
