@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""Benchmark of the CoNeTTE hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic clips already resident in
+HBM: waveform (B, 320000) fp32 -> log-mel -> ConvNeXt -> projection -> KV-cached decoder under
+beam search -> token ids / scores on device (+ the RCCL all-gather of ids for N > 1).
+Workload = BASELINE.json configs[1]/[2] shape: B = 64 clips of 10 s @ 32 kHz per GPU, beam 3,
+bf16 operands, seeded synthetic checkpoint (random-init weights of the reference architecture;
+the published checkpoint is not reachable offline).  N > 1: one process per GPU, every rank
+processes its own 64 clips (weak scaling), no data-path collective except the final all-gather.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import conette_amd  # noqa: E402,F401
+from conette_amd import synth  # noqa: E402
+
+SR = 32000
+CLIP_S = 10
+DIMS = (96, 192, 384, 768)
+DEPTHS = (3, 3, 9, 3)
+POS = (252 * 56, 126 * 28, 63 * 14, 31 * 7)  # positions per 10 s clip and stage
+PEAK_BF16_TFLOPS = 2500.0                    # dense MFMA bf16 (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0                        # HBM3E spec (MI355X_MICROARCH.md)
+
+
+def algorithmic_work(cls: str, batch: int):
+    """(flops, bytes) of ALL launches of a kernel class for one batch."""
+    fl = by = 0.0
+    for c, d, p in zip(DIMS, DEPTHS, POS):
+        n = batch * p
+        if cls == "pw1_gemm":      # (P x C) . (C x 4C) + bias + GELU -> bf16
+            fl += d * 2.0 * n * c * 4 * c
+            by += d * (2.0 * n * c + 2.0 * n * 4 * c + 2.0 * 4 * c * c)
+        elif cls == "pw2_gemm":    # (P x 4C) . (4C x C), x layer-scale + fp32 residual in/out
+            fl += d * 2.0 * n * c * 4 * c
+            by += d * (2.0 * n * 4 * c + 4.0 * n * c + 4.0 * n * c + 2.0 * 4 * c * c)
+        elif cls == "dwconv_ln":   # 49 MAC per element (VALU); fp32 in, bf16 out
+            fl += d * 2.0 * 49 * n * c
+            by += d * (4.0 * n * c + 2.0 * n * c)
+    return fl, by
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--beam", type=int, default=3)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--cpu-clips", type=int, default=32, help="clips in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from conette_amd.dist import gather_captions
+    from conette_amd.engine import Engine
+
+    B, beam, min_pred, max_pred = args.batch, args.beam, 3, 20
+    L = CLIP_S * SR
+    sd_np = synth.synth_state_dict()
+    sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()}
+    eng = Engine(sd, precision=args.precision, device=dev)
+    wave = torch.from_numpy(synth.synth_waveforms(B, L, 1234 + rank * B)).to(dev)
+    t_audio = eng.lib.conette_num_audio_frames(L)
+    lens = torch.full((B,), t_audio, dtype=torch.int32, device=dev)
+    bos = sd["model.task_id_to_token_id"][torch.zeros(B, dtype=torch.long)].to(dev)  # task "clotho"
+    forbid = sd["model.forbid_rep_mask"].to(dev)
+    fe_buf = eng.decode_input_buffer(B, t_audio, beam, max_pred)
+    clip_buf = torch.empty((B, 527), dtype=torch.float32, device=dev)
+
+    def step():
+        eng.encode(wave, out=(fe_buf, clip_buf))
+        out = eng.decode(fe_buf, lens, bos, forbid, beam, min_pred, max_pred, clone=False)
+        if world > 1:
+            return gather_captions(out["best_preds"], out["best_lprobs"], world * B)
+        return out["best_preds"], out["best_lprobs"]
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(max(args.warmup, 3)):  # >= 3: the third identical decode call replays its hipGraph
+        step()
+    fence()
+
+    # ---- pre-pass (untimed): which kernel class dominates, encode / decode split --------------------
+    enc_classes = ("frontend", "stem", "dwconv_ln", "pw1_gemm", "pw2_gemm", "downsample", "heads")
+    eng.profile_enable(enc_classes)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev[0].record()
+    eng.encode(wave, out=(fe_buf, clip_buf))
+    ev[1].record()
+    out = eng.decode(fe_buf, lens, bos, forbid, beam, min_pred, max_pred, clone=False)
+    ev[2].record()
+    torch.cuda.synchronize(dev)
+    pre = eng.profile_read()
+    eng.profile_enable(())
+    encode_ms, decode_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+    stage_ms = {k: round(v[0], 4) for k, v in pre.items()}
+    dominant = max(("pw1_gemm", "pw2_gemm", "dwconv_ln"), key=lambda k: pre.get(k, (0.0, 0))[0])
+    mult = out["mult_preds"]
+    gen_tokens = int((mult != 0).sum().item())  # generated row-steps of this batch (EOS included, pad excluded)
+
+    # ---- timed region: exactly K steps, events only around the dominant class --------------------------
+    eng.profile_enable((dominant,))
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile_enable(())
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    dom_ms, dom_n = prof[dominant]
+    fl, by = algorithmic_work(dominant, B)
+    launches_per_step = dom_n / args.steps
+    avg_launch_s = dom_ms * 1e-3 / dom_n
+    if dominant in ("pw1_gemm", "pw2_gemm"):
+        achieved = fl / launches_per_step / avg_launch_s / 1e12
+        roof = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None}
+    else:
+        achieved = by / launches_per_step / avg_launch_s / 1e9
+        roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
+                "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None}
+    roof["avg_launch_us"] = round(avg_launch_s * 1e6, 2)
+    roof["launches_per_step"] = launches_per_step
+
+    result = None
+    if rank == 0:
+        clips_per_s = world * B * args.steps / dt
+        result = {
+            "metric": "clips_per_sec", "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"B={B}/GPU x 10 s @ 32 kHz clips, ConvNeXt encoder + beam-{beam} KV-cached decode "
+                                   f"(min 3 / max 20 tokens, V=5631), synthetic seeded checkpoint",
+                       "batch_per_gpu": B, "global_batch": world * B, "beam_size": beam, "parallelism": f"dp{world}"},
+            "decode_tokens_per_sec": round(world * gen_tokens / (decode_ms * 1e-3), 1),
+            "encode_ms": round(encode_ms, 3), "decode_ms": round(decode_ms, 3), "stage_ms": stage_ms,
+            "roofline": roof,
+        }
+
+    # ---- CPU baseline (rank 0, N = 1 only): the oracle restatement on host cores ------------------------
+    if rank == 0 and world == 1 and args.cpu_clips > 0:
+        from oracle import cpu_ref as O
+
+        n_thr = max(1, min(args.cpu_threads, len(os.sched_getaffinity(0))))
+        torch.set_num_threads(n_thr)
+        cfg = synth.synth_config_dict()
+        xs = wave[: args.cpu_clips].cpu()[:, None, :]
+        with torch.no_grad():
+            tc = time.perf_counter()
+            O.model_forward(sd, cfg, xs, sr=SR, task="clotho", beam_size=beam)
+            tc = time.perf_counter() - tc
+        result["cpu_baseline"] = {
+            "value": round(args.cpu_clips / tc, 4), "unit": "clips/s", "cores": n_thr, "kind": "port",
+            "sample": f"{args.cpu_clips} of the same synthetic clips, same checkpoint, beam {beam}: oracle/cpu_ref.py "
+                      f"(stock PyTorch fp32, reference algorithm incl. its no-KV-cache decode), {tc:.1f} s"}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,17 +9,17 @@ from .config import CoNeTTEConfig  # noqa: F401
 
 
 def __getattr__(name):  # lazy: importing the package must not need a GPU or the built library
-    if name in ("CoNeTTEModel", "model"):
-        from . import model as _m
-        return _m.CoNeTTEModel if name == "CoNeTTEModel" else _m
+    import importlib
+    if name == "CoNeTTEModel":
+        return importlib.import_module(__name__ + ".model").CoNeTTEModel
     if name == "Engine":
-        from .engine import Engine
-        return Engine
+        return importlib.import_module(__name__ + ".engine").Engine
     raise AttributeError(name)
 
 
 def conette(pretrained_model_name_or_path: str = "Labbeti/conette", **kwargs):
     """Factory mirroring reference src/conette/__init__.py:25-49."""
-    from .model import CoNeTTEModel
+    import importlib
+    CoNeTTEModel = importlib.import_module(__name__ + ".model").CoNeTTEModel
     config = CoNeTTEConfig.from_pretrained(pretrained_model_name_or_path)
     return CoNeTTEModel.from_pretrained(pretrained_model_name_or_path, config=config, **kwargs)

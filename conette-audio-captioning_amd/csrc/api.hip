@@ -19,6 +19,72 @@ void cn_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* conette_last_error(void) { return g_err; }
+
+// ---- runtime state (C++ members kept out of the POD context) -------------------------------------
+struct CnProfRec {
+  int cls;
+  hipEvent_t start, stop;
+};
+struct CnRuntime {
+  std::vector<CnProfRec> recs;       // recorded launches (in order)
+  std::vector<hipEvent_t> free_ev;   // recycled events
+  int open_cls = -1;
+  hipEvent_t open_start = nullptr;
+};
+
+static hipEvent_t rt_event(CnRuntime* rt) {
+  if (!rt->free_ev.empty()) {
+    hipEvent_t e = rt->free_ev.back();
+    rt->free_ev.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void cn_prof_begin(conette_ctx* ctx, int cls, hipStream_t s) {
+  CnRuntime* rt = ctx->rt;
+  rt->open_cls = cls;
+  rt->open_start = rt_event(rt);
+  (void)hipEventRecord(rt->open_start, s);
+}
+void cn_prof_end(conette_ctx* ctx, int cls, hipStream_t s) {
+  CnRuntime* rt = ctx->rt;
+  if (rt->open_cls != cls || !rt->open_start) return;
+  hipEvent_t stop = rt_event(rt);
+  (void)hipEventRecord(stop, s);
+  rt->recs.push_back(CnProfRec{cls, rt->open_start, stop});
+  rt->open_cls = -1;
+  rt->open_start = nullptr;
+}
+
+extern "C" int conette_profile_enable(conette_ctx* ctx, uint32_t class_mask) {
+  if (!ctx) return CN_ERR_ARG;
+  ctx->prof_mask = class_mask;
+  return CN_OK;
+}
+
+extern "C" int conette_profile_read(conette_ctx* ctx, float* ms, int32_t* counts) {
+  if (!ctx || !ms || !counts) {
+    cn_set_error("profile_read: bad argument");
+    return CN_ERR_ARG;
+  }
+  CnRuntime* rt = ctx->rt;
+  for (auto& r : rt->recs) {
+    CN_HIP(hipEventSynchronize(r.stop));
+    float t = 0.f;
+    CN_HIP(hipEventElapsedTime(&t, r.start, r.stop));
+    if (r.cls >= 0 && r.cls < CONETTE_PROF_NCLASS) {
+      ms[r.cls] += t;
+      counts[r.cls] += 1;
+    }
+    rt->free_ev.push_back(r.start);
+    rt->free_ev.push_back(r.stop);
+  }
+  rt->recs.clear();
+  return CN_OK;
+}
 extern "C" int conette_abi_version(void) { return CONETTE_ABI_VERSION; }
 
 // ---- packing kernels --------------------------------------------------------------------------
@@ -132,6 +198,7 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
   conette_ctx* ctx = new conette_ctx();
   memset(ctx, 0, sizeof(*ctx));
   ctx->cfg = *cfg;
+  ctx->rt = new CnRuntime();
   ctx->esize = cfg->precision == CONETTE_PREC_BF16 ? 2 : 4;
   size_t total = 1 << 20;
   for (int i = 0; i < n_tensors; ++i) total += cn_align((size_t)numel[i] * 4) + 256;
@@ -139,6 +206,7 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
   hipError_t e = hipMalloc((void**)&ctx->arena, total);
   if (e != hipSuccess) {
     cn_set_error("create: hipMalloc(%zu) -> %s", total, hipGetErrorString(e));
+    delete ctx->rt;
     delete ctx;
     return CN_ERR_HIP;
   }
@@ -319,7 +387,8 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
     B.err = CN_ERR_HIP;
   }
   if (B.err != CN_OK) {
-    hipFree(ctx->arena);
+    (void)hipFree(ctx->arena);
+    delete ctx->rt;
     delete ctx;
     return B.err;
   }
@@ -327,9 +396,20 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
   return CN_OK;
 }
 
+void cn_decode_graphs_free(conette_ctx* ctx);
+
 extern "C" void conette_destroy(conette_ctx* ctx) {
   if (!ctx) return;
-  if (ctx->arena) hipFree(ctx->arena);
+  cn_decode_graphs_free(ctx);
+  if (ctx->rt) {
+    for (auto& r : ctx->rt->recs) {
+      (void)hipEventDestroy(r.start);
+      (void)hipEventDestroy(r.stop);
+    }
+    for (auto e : ctx->rt->free_ev) (void)hipEventDestroy(e);
+    delete ctx->rt;
+  }
+  if (ctx->arena) (void)hipFree(ctx->arena);
   delete ctx;
 }
 

@@ -50,8 +50,12 @@ struct CnLayerW {
   const float *n1w, *n1b, *n2w, *n2b, *n3w, *n3b;
 };
 
+struct CnRuntime;  // C++ side state: profiling events, decode graphs (api.hip)
+
 struct conette_ctx {
   conette_config cfg;
+  CnRuntime* rt;
+  uint32_t prof_mask;
   int esize;  // operand element size (2 or 4)
   // frontend tables
   const float* window;     // [1024]
@@ -87,6 +91,21 @@ struct conette_ctx {
   char* arena;
   size_t arena_bytes;
   size_t arena_used;
+};
+
+// event pair around the launches of one kernel class when that class is being profiled
+void cn_prof_begin(conette_ctx* ctx, int cls, hipStream_t s);
+void cn_prof_end(conette_ctx* ctx, int cls, hipStream_t s);
+struct CnProfScope {
+  conette_ctx* ctx;
+  int cls;
+  hipStream_t s;
+  CnProfScope(conette_ctx* c, int k, hipStream_t st) : ctx(c), cls(k), s(st) {
+    if (ctx->prof_mask & (1u << cls)) cn_prof_begin(ctx, cls, s);
+  }
+  ~CnProfScope() {
+    if (ctx->prof_mask & (1u << cls)) cn_prof_end(ctx, cls, s);
+  }
 };
 
 // ---- stage entry points implemented in the .hip files ---------------------------------------

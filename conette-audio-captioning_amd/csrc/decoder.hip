@@ -25,7 +25,8 @@ __global__ void cn_cvt_kernel(const float* __restrict__ in, T* __restrict__ out,
 
 __global__ void cn_init_state_kernel(int B, int beam, int maxp, const int* __restrict__ bos, int* n_active, int* slot,
                                      float* sum_lp, int* prefix, int* anc, int* cur_tok, int* out_preds,
-                                     float* out_avg, int* out_len, int* sizes, int pad_id) {
+                                     float* out_avg, int* out_len, int* sizes, int pad_id, int* trace_sel,
+                                     float* trace_val) {
   const int R = B * beam;
   const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
   for (int i = gid; i < B; i += gsz) n_active[i] = beam;
@@ -42,6 +43,10 @@ __global__ void cn_init_state_kernel(int B, int beam, int maxp, const int* __res
     out_preds[i] = pad_id;
   }
   if (gid < 2) sizes[gid] = 0;
+  if (trace_sel)
+    for (int i = gid; i < maxp * R * 2; i += gsz) trace_sel[i] = -1;
+  if (trace_val)
+    for (int i = gid; i < maxp * R; i += gsz) trace_val[i] = 0.f;
 }
 
 // x = E[tok] * sqrt(d) + PE[step]   (aac_tfmer.py:100-106); d == 256, one wave per row
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(256) void cn_search_step_kernel(float* __restrict__
                                                              const uint8_t* __restrict__ forbid, int* n_active,
                                                              int* slot, float* sum_lp, int* prefix, int* anc,
                                                              int* cur_tok, int* out_preds, float* out_avg,
-                                                             int* out_len) {
+                                                             int* out_len, int* trace_sel, float* trace_val) {
   __shared__ float s_red[8];
   __shared__ ValIdx s_vi[4];
   __shared__ float s_mx[CN_MAX_BEAM], s_lg[CN_MAX_BEAM], s_base[CN_MAX_BEAM];
@@ -283,6 +288,14 @@ __global__ __launch_bounds__(256) void cn_search_step_kernel(float* __restrict__
     __syncthreads();
   }
   // bookkeeping (beam.py:164-203)
+  if (tid < k) {
+    const size_t ti = ((size_t)step * gridDim.x + b) * beam + tid;
+    if (trace_sel) {
+      trace_sel[2 * ti] = s_self[tid] / V;
+      trace_sel[2 * ti + 1] = s_self[tid] % V;
+    }
+    if (trace_val) trace_val[ti] = s_selv[tid];
+  }
   if (tid == 0) {
     int cnt = 0;
     for (int c = 0; c < k; ++c) {
@@ -416,7 +429,7 @@ template <typename T>
 static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t* frame_lens, const int32_t* bos_ids,
                        const uint8_t* forbid, int B, int Ta, int beam, int min_pred, int maxp, int32_t* best_preds,
                        float* best_lprobs, int32_t* mult_preds, float* mult_lprobs, int32_t* out_sizes,
-                       float* step0_logits, char* wsp, hipStream_t s) {
+                       float* step0_logits, int32_t* trace_sel, float* trace_val, char* wsp, hipStream_t s) {
   const conette_config& cfg = ctx->cfg;
   const int d = cfg.d_model, NL = cfg.n_layers, R = B * beam, V = cfg.vocab_size, dff = cfg.d_ff;
   DecWs w = dec_ws(ctx, B, Ta, beam, maxp, wsp);
@@ -432,6 +445,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
 
   // ---- once per batch: projection (conette.py:457) and cross K/V of every layer ---------------
   {
+    CnProfScope ps(ctx, CONETTE_PROF_DEC_PREPARE, s);
     const size_t n = (size_t)B * Ta * CN_FEAT;
     hipLaunchKernelGGL((cn_cvt_kernel<T>), dim3((unsigned)((n + 1023) / 1024 < 4096 ? (n + 1023) / 1024 : 4096)), dim3(256), 0, s,
                        frame_embs, fe_t, n);
@@ -442,7 +456,8 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
     CN_TRY((cn_gemm<T>(mem, d, (const T*)ctx->kv_w, d, B * Ta, kv_ld, d, ekv, s)));
   }
   hipLaunchKernelGGL(cn_init_state_kernel, dim3(64), dim3(256), 0, s, B, beam, maxp, bos_ids, w.n_active, w.slot,
-                     w.sum_lp, w.prefix, w.anc, w.cur_tok, mult_preds, mult_lprobs, w.out_len, out_sizes, cfg.pad_id);
+                     w.sum_lp, w.prefix, w.anc, w.cur_tok, mult_preds, mult_lprobs, w.out_len, out_sizes, cfg.pad_id,
+                     trace_sel, trace_val);
   CN_LAUNCH_CHECK();
 
   for (int step = 0; step < maxp; ++step) {
@@ -453,40 +468,75 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
       const CnLayerW& lw = ctx->layers[l];
       T* kc = (T*)w.kc + (size_t)l * maxp * R * d;
       T* vc = (T*)w.vc + (size_t)l * maxp * R * d;
-      EpiBiasAct<float> eq{lw.sa_in_b, w.qkv, 3 * d, ACT_NONE};
-      CN_TRY((cn_gemm<T>(xt, d, (const T*)lw.sa_in_w, d, R, 3 * d, d, eq, s)));
-      hipLaunchKernelGGL((cn_self_attn_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.qkv, kc, vc, w.anc, step, R, beam,
-                         maxp, scale, attn_t);
-      CN_LAUNCH_CHECK();
-      EpiResid eo{lw.sa_out_b, nullptr, w.x, w.tmp, d};
-      CN_TRY((cn_gemm<T>(attn_t, d, (const T*)lw.sa_out_w, d, R, d, d, eo, s)));
-      hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, lw.n1w, lw.n1b, R, w.x, xt);
-      CN_LAUNCH_CHECK();
-
-      EpiBiasAct<float> ecq{lw.ca_q_b, w.q, d, ACT_NONE};
-      CN_TRY((cn_gemm<T>(xt, d, (const T*)lw.ca_q_w, d, R, d, d, ecq, s)));
-      hipLaunchKernelGGL((cn_cross_attn_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.q, kvc, kv_ld, l * 2 * d,
-                         frame_lens, R, beam, Ta, scale, attn_t);
-      CN_LAUNCH_CHECK();
-      EpiResid eco{lw.ca_out_b, nullptr, w.x, w.tmp, d};
-      CN_TRY((cn_gemm<T>(attn_t, d, (const T*)lw.ca_out_w, d, R, d, d, eco, s)));
-      hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, lw.n2w, lw.n2b, R, w.x, xt);
-      CN_LAUNCH_CHECK();
-
-      EpiBiasAct<T> e1{lw.ff1_b, ffh, dff, ACT_GELU};
-      CN_TRY((cn_gemm<T>(xt, d, (const T*)lw.ff1_w, d, R, dff, d, e1, s)));
-      EpiResid e2{lw.ff2_b, nullptr, w.x, w.tmp, d};
-      CN_TRY((cn_gemm<T>(ffh, dff, (const T*)lw.ff2_w, dff, R, d, dff, e2, s)));
-      hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, lw.n3w, lw.n3b, R, w.x, xt);
-      CN_LAUNCH_CHECK();
+      {
+        CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+        EpiBiasAct<float> eq{lw.sa_in_b, w.qkv, 3 * d, ACT_NONE};
+        CN_TRY((cn_gemm<T>(xt, d, (const T*)lw.sa_in_w, d, R, 3 * d, d, eq, s)));
+      }
+      {
+        CnProfScope ps(ctx, CONETTE_PROF_DEC_ATTN, s);
+        hipLaunchKernelGGL((cn_self_attn_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.qkv, kc, vc, w.anc, step, R,
+                           beam, maxp, scale, attn_t);
+        CN_LAUNCH_CHECK();
+      }
+      {
+        CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+        EpiResid eo{lw.sa_out_b, nullptr, w.x, w.tmp, d};
+        CN_TRY((cn_gemm<T>(attn_t, d, (const T*)lw.sa_out_w, d, R, d, d, eo, s)));
+      }
+      {
+        CnProfScope ps(ctx, CONETTE_PROF_DEC_MISC, s);
+        hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, lw.n1w, lw.n1b, R, w.x, xt);
+        CN_LAUNCH_CHECK();
+      }
+      {
+        CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+        EpiBiasAct<float> ecq{lw.ca_q_b, w.q, d, ACT_NONE};
+        CN_TRY((cn_gemm<T>(xt, d, (const T*)lw.ca_q_w, d, R, d, d, ecq, s)));
+      }
+      {
+        CnProfScope ps(ctx, CONETTE_PROF_DEC_ATTN, s);
+        hipLaunchKernelGGL((cn_cross_attn_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.q, kvc, kv_ld, l * 2 * d,
+                           frame_lens, R, beam, Ta, scale, attn_t);
+        CN_LAUNCH_CHECK();
+      }
+      {
+        CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+        EpiResid eco{lw.ca_out_b, nullptr, w.x, w.tmp, d};
+        CN_TRY((cn_gemm<T>(attn_t, d, (const T*)lw.ca_out_w, d, R, d, d, eco, s)));
+      }
+      {
+        CnProfScope ps(ctx, CONETTE_PROF_DEC_MISC, s);
+        hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, lw.n2w, lw.n2b, R, w.x, xt);
+        CN_LAUNCH_CHECK();
+      }
+      {
+        CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+        EpiBiasAct<T> e1{lw.ff1_b, ffh, dff, ACT_GELU};
+        CN_TRY((cn_gemm<T>(xt, d, (const T*)lw.ff1_w, d, R, dff, d, e1, s)));
+      }
+      {
+        CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+        EpiResid e2{lw.ff2_b, nullptr, w.x, w.tmp, d};
+        CN_TRY((cn_gemm<T>(ffh, dff, (const T*)lw.ff2_w, dff, R, d, dff, e2, s)));
+      }
+      {
+        CnProfScope ps(ctx, CONETTE_PROF_DEC_MISC, s);
+        hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, lw.n3w, lw.n3b, R, w.x, xt);
+        CN_LAUNCH_CHECK();
+      }
     }
-    EpiBiasAct<float> ec{ctx->cls_b, w.logits, w.ldv, ACT_NONE};
-    CN_TRY((cn_gemm<T>(xt, d, (const T*)ctx->cls_w, d, R, V, d, ec, s)));
+    {
+      CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+      EpiBiasAct<float> ec{ctx->cls_b, w.logits, w.ldv, ACT_NONE};
+      CN_TRY((cn_gemm<T>(xt, d, (const T*)ctx->cls_w, d, R, V, d, ec, s)));
+    }
     if (step == 0 && step0_logits)
       CN_HIP(hipMemcpyAsync(step0_logits, w.logits, (size_t)R * w.ldv * 4, hipMemcpyDeviceToDevice, s));
+    CnProfScope ps_search(ctx, CONETTE_PROF_SEARCH, s);
     hipLaunchKernelGGL(cn_search_step_kernel, dim3(B), dim3(256), 0, s, w.logits, w.ldv, V, beam, maxp, step, min_pred,
                        cfg.eos_id, forbid, w.n_active, w.slot, w.sum_lp, w.prefix, w.anc, w.cur_tok, mult_preds,
-                       mult_lprobs, w.out_len);
+                       mult_lprobs, w.out_len, trace_sel, trace_val);
     CN_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(cn_finalize_kernel, dim3(cn_cdiv(B, 64)), dim3(64), 0, s, B, beam, maxp, cfg.eos_id, mult_preds,
@@ -497,11 +547,69 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
   return CN_OK;
 }
 
+// ---- hipGraph replay of the (static) decode launch sequence ---------------------------------------
+struct DecKey {
+  const void *fe, *lens, *bos, *forbid, *bp, *bl, *mp, *ml, *sz, *s0, *ts, *tv, *ws;
+  int B, Ta, beam, min_pred, maxp;
+  bool operator==(const DecKey& o) const { return memcmp(this, &o, sizeof(DecKey)) == 0; }
+};
+struct DecGraph {
+  DecKey key;
+  hipGraphExec_t exec;
+  hipGraph_t graph;
+  int seen;
+};
+#define CN_MAX_DEC_GRAPHS 8
+struct DecGraphCache {
+  DecGraph g[CN_MAX_DEC_GRAPHS];
+  int n;
+  int enabled;
+};
+static DecGraphCache* graph_cache(conette_ctx* ctx, bool create) {
+  // one cache per context, keyed by the context pointer (contexts are few and long-lived)
+  static conette_ctx* owners[16];
+  static DecGraphCache* caches[16];
+  for (int i = 0; i < 16; ++i)
+    if (owners[i] == ctx) return caches[i];
+  if (!create) return nullptr;
+  for (int i = 0; i < 16; ++i)
+    if (owners[i] == nullptr) {
+      owners[i] = ctx;
+      caches[i] = new DecGraphCache();
+      memset(caches[i], 0, sizeof(DecGraphCache));
+      caches[i]->enabled = 1;
+      return caches[i];
+    }
+  return nullptr;
+}
+void cn_decode_graphs_free(conette_ctx* ctx) {
+  static_assert(sizeof(DecGraphCache) > 0, "");
+  DecGraphCache* c = graph_cache(ctx, false);
+  if (!c) return;
+  for (int i = 0; i < c->n; ++i)
+    if (c->g[i].exec) {
+      (void)hipGraphExecDestroy(c->g[i].exec);
+      (void)hipGraphDestroy(c->g[i].graph);
+    }
+  c->n = 0;
+}
+extern "C" int conette_set_option(conette_ctx* ctx, int32_t option, int32_t value) {
+  if (!ctx) return CN_ERR_ARG;
+  if (option == CONETTE_OPT_DECODE_GRAPH) {
+    DecGraphCache* c = graph_cache(ctx, true);
+    if (c) c->enabled = value ? 1 : 0;
+    return CN_OK;
+  }
+  cn_set_error("set_option: unknown option %d", option);
+  return CN_ERR_ARG;
+}
+
 extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const int32_t* frame_lens,
                               const int32_t* bos_ids, const uint8_t* forbid_mask, int32_t batch, int32_t t_audio,
                               int32_t beam, int32_t min_pred, int32_t max_pred, int32_t* best_preds,
                               float* best_lprobs, int32_t* mult_preds, float* mult_lprobs, int32_t* out_sizes,
-                              float* step0_logits, void* workspace, size_t workspace_bytes, void* stream) {
+                              float* step0_logits, int32_t* trace_sel, float* trace_val, void* workspace,
+                              size_t workspace_bytes, void* stream) {
   if (!ctx || !frame_embs || !frame_lens || !bos_ids || !best_preds || !best_lprobs || !mult_preds || !mult_lprobs ||
       !out_sizes || !workspace || batch <= 0 || t_audio <= 0) {
     cn_set_error("decode: bad argument");
@@ -525,11 +633,76 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
     cn_set_error("decode: workspace %zu < %zu", workspace_bytes, need);
     return CN_ERR_WORKSPACE;
   }
-  if (ctx->cfg.precision == CONETTE_PREC_BF16)
-    return decode_impl<bf16_t>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, beam, min_pred,
-                               max_pred, best_preds, best_lprobs, mult_preds, mult_lprobs, out_sizes, step0_logits,
-                               (char*)workspace, (hipStream_t)stream);
-  return decode_impl<float>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, beam, min_pred,
-                            max_pred, best_preds, best_lprobs, mult_preds, mult_lprobs, out_sizes, step0_logits,
-                            (char*)workspace, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  auto run = [&]() -> int {
+    if (ctx->cfg.precision == CONETTE_PREC_BF16)
+      return decode_impl<bf16_t>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, beam, min_pred,
+                                 max_pred, best_preds, best_lprobs, mult_preds, mult_lprobs, out_sizes, step0_logits,
+                                 trace_sel, trace_val, (char*)workspace, s);
+    return decode_impl<float>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, beam, min_pred,
+                              max_pred, best_preds, best_lprobs, mult_preds, mult_lprobs, out_sizes, step0_logits,
+                              trace_sel, trace_val, (char*)workspace, s);
+  };
+  DecGraphCache* cache = graph_cache(ctx, true);
+  const uint32_t dec_classes = (1u << CONETTE_PROF_DEC_PREPARE) | (1u << CONETTE_PROF_DEC_GEMM) |
+                               (1u << CONETTE_PROF_DEC_ATTN) | (1u << CONETTE_PROF_DEC_MISC) |
+                               (1u << CONETTE_PROF_SEARCH);
+  if (!cache || !cache->enabled || (ctx->prof_mask & dec_classes) != 0) return run();
+
+  DecKey key;
+  memset(&key, 0, sizeof(key));
+  key.fe = frame_embs, key.lens = frame_lens, key.bos = bos_ids, key.forbid = forbid_mask, key.bp = best_preds;
+  key.bl = best_lprobs, key.mp = mult_preds, key.ml = mult_lprobs, key.sz = out_sizes, key.s0 = step0_logits;
+  key.ts = trace_sel, key.tv = trace_val, key.ws = workspace;
+  key.B = batch, key.Ta = t_audio, key.beam = beam, key.min_pred = min_pred, key.maxp = max_pred;
+  DecGraph* e = nullptr;
+  for (int i = 0; i < cache->n; ++i)
+    if (cache->g[i].key == key) e = &cache->g[i];
+  if (e && e->exec) {
+    CN_HIP(hipGraphLaunch(e->exec, s));
+    return CN_OK;
+  }
+  if (!e) {  // first sighting: run eagerly (also performs the one-time kernel attribute setup)
+    if (cache->n == CN_MAX_DEC_GRAPHS) {  // evict the oldest
+      if (cache->g[0].exec) {
+        (void)hipGraphExecDestroy(cache->g[0].exec);
+        (void)hipGraphDestroy(cache->g[0].graph);
+      }
+      memmove(&cache->g[0], &cache->g[1], sizeof(DecGraph) * (CN_MAX_DEC_GRAPHS - 1));
+      cache->n--;
+    }
+    e = &cache->g[cache->n++];
+    memset(e, 0, sizeof(*e));
+    e->key = key;
+    e->seen = 1;
+    return run();
+  }
+  // second sighting: capture, instantiate, launch
+  hipError_t ce = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+  if (ce != hipSuccess) {
+    (void)hipGetLastError();
+    cache->enabled = 0;
+    return run();
+  }
+  const int rc = run();
+  hipGraph_t graph = nullptr;
+  ce = hipStreamEndCapture(s, &graph);
+  if (rc != CN_OK || ce != hipSuccess || graph == nullptr) {
+    (void)hipGetLastError();
+    if (graph) (void)hipGraphDestroy(graph);
+    cache->enabled = 0;
+    return run();
+  }
+  hipGraphExec_t exec = nullptr;
+  ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (ce != hipSuccess || exec == nullptr) {
+    (void)hipGetLastError();
+    (void)hipGraphDestroy(graph);
+    cache->enabled = 0;
+    return run();
+  }
+  e->exec = exec;
+  e->graph = graph;
+  CN_HIP(hipGraphLaunch(exec, s));
+  return CN_OK;
 }

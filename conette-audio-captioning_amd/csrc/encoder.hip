@@ -362,10 +362,14 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
   EncWs ws = enc_ws(ctx, B, L, wsp);
   T* y = (T*)ws.y;
   T* hbuf = (T*)ws.h;
-  CN_TRY(cn_frontend(ctx, wave, B, L, ws.logmel, s));
+  {
+    CnProfScope ps(ctx, CONETTE_PROF_FRONTEND, s);
+    CN_TRY(cn_frontend(ctx, wave, B, L, ws.logmel, s));
+  }
   if (taps) CN_TRY(tap_copy(taps->logmel, ws.logmel, (size_t)B * g.F * CN_N_MELS, s));
   {
     const long n_pos = (long)B * g.H[0] * g.W[0];
+    CnProfScope ps(ctx, CONETTE_PROF_STEM, s);
     hipLaunchKernelGGL(cn_stem_kernel, dim3((unsigned)((n_pos + 63) / 64)), dim3(256), 0, s, ws.logmel, g.F, g.H[0],
                        n_pos, ctx->stem_w, ctx->stem_b, ctx->stem_ln_w, ctx->stem_ln_b, ws.x);
     CN_LAUNCH_CHECK();
@@ -379,6 +383,7 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
       const int Cp = CN_DIMS[st - 1], Hp = g.H[st - 1], Wp = g.W[st - 1];
       const long n_in = (long)B * Hp * Wp;
       const CnDownW& dw = ctx->down[st - 1];
+      CnProfScope ps(ctx, CONETTE_PROF_DOWNSAMPLE, s);
       hipLaunchKernelGGL((cn_ln_patchify_kernel<T>), dim3((unsigned)((n_in + 3) / 4)), dim3(256), 0, s, ws.x, Hp, Wp,
                          Cp, n_in, dw.ln_w, dw.ln_b, y);
       CN_LAUNCH_CHECK();
@@ -388,16 +393,26 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
     }
     for (int b = 0; b < CN_DEPTHS[st]; ++b, ++blk) {
       const CnBlockW& bw = ctx->blocks[blk];
-      CN_TRY(dwconv_dispatch<T>(C, ws.x, B, H, W, bw, y, s));
-      EpiBiasAct<T> e1{bw.b1, hbuf, 4 * C, ACT_GELU};
-      CN_TRY((cn_gemm<T>(y, C, (const T*)bw.w1, C, (int)P, 4 * C, C, e1, s)));
-      EpiResid e2{bw.b2, bw.scale, ws.x, ws.x, C};
-      CN_TRY((cn_gemm<T>(hbuf, 4 * C, (const T*)bw.w2, 4 * C, (int)P, C, 4 * C, e2, s)));
+      {
+        CnProfScope ps(ctx, CONETTE_PROF_DWCONV_LN, s);
+        CN_TRY(dwconv_dispatch<T>(C, ws.x, B, H, W, bw, y, s));
+      }
+      {
+        CnProfScope ps(ctx, CONETTE_PROF_PW1_GEMM, s);
+        EpiBiasAct<T> e1{bw.b1, hbuf, 4 * C, ACT_GELU};
+        CN_TRY((cn_gemm<T>(y, C, (const T*)bw.w1, C, (int)P, 4 * C, C, e1, s)));
+      }
+      {
+        CnProfScope ps(ctx, CONETTE_PROF_PW2_GEMM, s);
+        EpiResid e2{bw.b2, bw.scale, ws.x, ws.x, C};
+        CN_TRY((cn_gemm<T>(hbuf, 4 * C, (const T*)bw.w2, 4 * C, (int)P, C, 4 * C, e2, s)));
+      }
       if (taps && b == 0) CN_TRY(tap_copy(taps->stage_block0[st], ws.x, (size_t)P * C, s));
     }
     if (taps) CN_TRY(tap_copy(taps->stage[st], ws.x, (size_t)P * C, s));
   }
   const int Tn = g.H[3];
+  CnProfScope ps_heads(ctx, CONETTE_PROF_HEADS, s);
   hipLaunchKernelGGL((cn_frame_mean_kernel<T>), dim3((unsigned)(B * Tn)), dim3(256), 0, s, ws.x, g.W[3], CN_FEAT,
                      frame_embs, (T*)nullptr);
   CN_LAUNCH_CHECK();

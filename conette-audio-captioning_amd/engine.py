@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Dict, Optional, Tuple
+from typing import Any, Dict, Optional, Tuple
 
 import torch
 
@@ -25,7 +25,11 @@ EXPORTS = (
     "conette_last_error", "conette_abi_version", "conette_create", "conette_destroy", "conette_num_frames",
     "conette_num_audio_frames", "conette_encode_workspace_bytes", "conette_decode_workspace_bytes",
     "conette_frontend_logmel", "conette_encode", "conette_decode", "conette_resample", "conette_resample_len",
+    "conette_set_option", "conette_profile_enable", "conette_profile_read",
 )
+OPT_DECODE_GRAPH = 1
+PROF_CLASSES = ("frontend", "stem", "dwconv_ln", "pw1_gemm", "pw2_gemm", "downsample", "heads", "dec_prepare",
+                "dec_gemm", "dec_attn", "dec_misc", "search")
 
 
 class ConetteConfigC(C.Structure):
@@ -74,7 +78,13 @@ def load_library() -> C.CDLL:
     lib.conette_decode.restype = C.c_int
     lib.conette_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.conette_set_option.restype = C.c_int
+    lib.conette_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.conette_profile_enable.restype = C.c_int
+    lib.conette_profile_enable.argtypes = [C.c_void_p, C.c_uint32]
+    lib.conette_profile_read.restype = C.c_int
+    lib.conette_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     lib.conette_resample.restype = C.c_int
     lib.conette_resample.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.conette_resample_len.restype = C.c_int32
@@ -148,6 +158,7 @@ class Engine:
             torch.cuda.synchronize(self.device)
         self._ctx = handle
         self._ws: Dict[str, torch.Tensor] = {}
+        self._dec_bufs: Dict[Any, Dict[str, Any]] = {}
         del keep
 
     def __del__(self) -> None:
@@ -214,36 +225,83 @@ class Engine:
         return frame_embs, clip
 
     # ---- a9-a14 ----------------------------------------------------------------------------
+    def _decode_buffers(self, b: int, t: int, beam: int, max_pred: int, s0: bool, trace: bool) -> Dict[str, Any]:
+        """Persistent I/O buffers per shape: identical pointers let the library replay its hipGraph."""
+        key = (b, t, beam, max_pred, s0, trace)
+        buf = self._dec_bufs.get(key)
+        if buf is None:
+            dev = self.device
+            ldv = (self.vocab_size + 7) // 8 * 8
+            e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+            buf = {
+                "fe": e((b, t, FEAT), torch.float32), "lens": e((b,), torch.int32), "bos": e((b,), torch.int32),
+                "forbid": e((self.vocab_size,), torch.uint8),
+                "best_preds": e((b, max_pred), torch.int32), "best_lprobs": e((b,), torch.float32),
+                "mult_preds": e((b, beam, max_pred), torch.int32), "mult_lprobs": e((b, beam), torch.float32),
+                "sizes": e((2,), torch.int32),
+                "step0": e((b * beam, ldv), torch.float32) if s0 else None,
+                "trace_sel": e((max_pred, b, beam, 2), torch.int32) if trace else None,
+                "trace_val": e((max_pred, b, beam), torch.float32) if trace else None,
+            }
+            if len(self._dec_bufs) >= 8:
+                self._dec_bufs.pop(next(iter(self._dec_bufs)))
+            self._dec_bufs[key] = buf
+        return buf
+
     def decode(self, frame_embs: torch.Tensor, frame_lens: torch.Tensor, bos_ids: torch.Tensor,
                forbid_mask: Optional[torch.Tensor], beam: int, min_pred: int, max_pred: int,
-               want_step0_logits: bool = False) -> Dict[str, torch.Tensor]:
-        frame_embs = frame_embs.to(self.device, torch.float32).contiguous()
+               want_step0_logits: bool = False, want_trace: bool = False, clone: bool = True) -> Dict[str, torch.Tensor]:
+        """Beam search over pre-computed frame embeddings.  Outputs are full width; trim with
+        ``sizes`` = [pred_size, best_maxlen].  ``clone=False`` returns the persistent buffers."""
         b, t, _ = frame_embs.shape
-        frame_lens = frame_lens.to(self.device, torch.int32).contiguous()
-        bos_ids = bos_ids.to(self.device, torch.int32).contiguous()
+        buf = self._decode_buffers(b, t, int(beam), int(max_pred), want_step0_logits, want_trace)
+        if frame_embs.data_ptr() != buf["fe"].data_ptr():
+            buf["fe"].copy_(frame_embs, non_blocking=True)
+        buf["lens"].copy_(frame_lens.to(torch.int32), non_blocking=True)
+        buf["bos"].copy_(bos_ids.to(torch.int32), non_blocking=True)
+        forbid_ptr = None
         if forbid_mask is not None:
-            forbid_mask = forbid_mask.to(self.device).to(torch.uint8).contiguous()
             if forbid_mask.numel() != self.vocab_size:
                 raise ValueError("forbid_mask must have vocab_size entries")
-        dev = self.device
-        best_preds = torch.empty((b, max_pred), dtype=torch.int32, device=dev)
-        best_lp = torch.empty((b,), dtype=torch.float32, device=dev)
-        mult_preds = torch.empty((b, beam, max_pred), dtype=torch.int32, device=dev)
-        mult_lp = torch.empty((b, beam), dtype=torch.float32, device=dev)
-        sizes = torch.empty((2,), dtype=torch.int32, device=dev)
-        ldv = (self.vocab_size + 7) // 8 * 8
-        s0 = torch.empty((b * beam, ldv), dtype=torch.float32, device=dev) if want_step0_logits else None
+            buf["forbid"].copy_(forbid_mask.to(torch.uint8), non_blocking=True)
+            forbid_ptr = buf["forbid"]
         need = self.lib.conette_decode_workspace_bytes(self._ctx, b, t, beam, max_pred)
         wsb = self._workspace("dec", need)
-        st = self.lib.conette_decode(self._ctx, _ptr(frame_embs), _ptr(frame_lens), _ptr(bos_ids), _ptr(forbid_mask),
-                                     b, t, beam, min_pred, max_pred, _ptr(best_preds), _ptr(best_lp), _ptr(mult_preds),
-                                     _ptr(mult_lp), _ptr(sizes), _ptr(s0), _ptr(wsb), wsb.numel(), _stream())
+        st = self.lib.conette_decode(self._ctx, _ptr(buf["fe"]), _ptr(buf["lens"]), _ptr(buf["bos"]), _ptr(forbid_ptr),
+                                     b, t, beam, min_pred, max_pred, _ptr(buf["best_preds"]), _ptr(buf["best_lprobs"]),
+                                     _ptr(buf["mult_preds"]), _ptr(buf["mult_lprobs"]), _ptr(buf["sizes"]),
+                                     _ptr(buf["step0"]), _ptr(buf["trace_sel"]), _ptr(buf["trace_val"]), _ptr(wsb),
+                                     wsb.numel(), _stream())
         _check(st, "conette_decode")
-        out = {"best_preds": best_preds, "best_lprobs": best_lp, "mult_preds": mult_preds, "mult_lprobs": mult_lp,
-               "sizes": sizes}
-        if s0 is not None:
-            out["step0_logits"] = s0[:, : self.vocab_size]
+        cp = (lambda x: x.clone()) if clone else (lambda x: x)
+        out = {k: cp(buf[k]) for k in ("best_preds", "best_lprobs", "mult_preds", "mult_lprobs", "sizes")}
+        if want_step0_logits:
+            out["step0_logits"] = cp(buf["step0"])[:, : self.vocab_size]
+        if want_trace:
+            out["trace_sel"] = cp(buf["trace_sel"])
+            out["trace_val"] = cp(buf["trace_val"])
         return out
+
+    def decode_input_buffer(self, b: int, t: int, beam: int, max_pred: int) -> torch.Tensor:
+        """The persistent (B, T, 768) input of decode(): encode straight into it to skip a copy."""
+        return self._decode_buffers(b, t, int(beam), int(max_pred), False, False)["fe"]
+
+    # ---- options / profiling ------------------------------------------------------------------
+    def set_decode_graph(self, enabled: bool) -> None:
+        _check(self.lib.conette_set_option(self._ctx, OPT_DECODE_GRAPH, int(bool(enabled))), "set_option")
+
+    def profile_enable(self, classes=()) -> None:
+        mask = 0
+        for c in classes:
+            mask |= 1 << PROF_CLASSES.index(c)
+        _check(self.lib.conette_profile_enable(self._ctx, mask), "profile_enable")
+
+    def profile_read(self) -> Dict[str, Any]:
+        n = len(PROF_CLASSES)
+        ms = (C.c_float * n)()
+        cnt = (C.c_int32 * n)()
+        _check(self.lib.conette_profile_read(self._ctx, ms, cnt), "profile_read")
+        return {PROF_CLASSES[i]: (float(ms[i]), int(cnt[i])) for i in range(n) if cnt[i] > 0}
 
     # ---- a1 --------------------------------------------------------------------------------
     def resample(self, x: torch.Tensor, orig_sr: int, new_sr: int) -> torch.Tensor:

@@ -99,18 +99,48 @@ int conette_encode(conette_ctx* ctx, const float* wave, int32_t batch, int32_t n
  *   best_preds  (B, max_pred) int32   best_lprobs (B) fp32
  *   mult_preds  (B, beam, max_pred) int32   mult_lprobs (B, beam) fp32
  *   out_sizes   (2) int32: [0] = pred_size (beam.py:192-194,207-211), [1] = best_maxlen (:222-225)
- *   step_logits : optional dev (B*beam, ld_v) fp32 copy of the step-0 logits (parity), or NULL */
+ *   step0_logits: optional dev (B*beam, ld_v) fp32 copy of the step-0 logits (parity), or NULL
+ *   trace_sel   : optional dev (max_pred, B, beam, 2) int32 = (parent row, token) picked by the
+ *                 per-clip top-k of each step in descending order, -1 where unused; or NULL
+ *   trace_val   : optional dev (max_pred, B, beam) fp32 running log-prob sums of those picks
+ * With identical arguments (pointers included) the launch sequence is replayed from a cached
+ * hipGraph from the third call on (see conette_set_option). */
 int conette_decode(conette_ctx* ctx, const float* frame_embs, const int32_t* frame_lens, const int32_t* bos_ids,
                    const uint8_t* forbid_mask, int32_t batch, int32_t t_audio, int32_t beam,
                    int32_t min_pred, int32_t max_pred, int32_t* best_preds, float* best_lprobs,
                    int32_t* mult_preds, float* mult_lprobs, int32_t* out_sizes, float* step0_logits,
-                   void* workspace, size_t workspace_bytes, void* stream);
+                   int32_t* trace_sel, float* trace_val, void* workspace, size_t workspace_bytes, void* stream);
 
 /* a1: torchaudio.functional.resample (preprocessor.py:134-141), sinc_interpolation width 6,
  * rolloff 0.99.  in: dev (rows, n_in) fp32; out: dev (rows, n_out), n_out = ceil(n_in*new/orig). */
 int conette_resample(const float* in, int32_t rows, int32_t n_in, int32_t orig_sr, int32_t new_sr, float* out,
                      void* stream);
 int32_t conette_resample_len(int32_t n_in, int32_t orig_sr, int32_t new_sr);
+
+/* Runtime options. */
+#define CONETTE_OPT_DECODE_GRAPH 1 /* 1 (default): replay conette_decode from a cached hipGraph */
+int conette_set_option(conette_ctx* ctx, int32_t option, int32_t value);
+
+/* Per-kernel-class timing with HIP events recorded on the caller's stream around each launch
+ * of the selected classes (bench.py's roofline leg).  While a decoder class is selected, decode
+ * graphs are bypassed.  conette_profile_read synchronises the recorded events, ADDS the elapsed
+ * milliseconds / launch counts per class into ms[CONETTE_PROF_NCLASS] / counts[...] and
+ * clears the recording. */
+#define CONETTE_PROF_FRONTEND 0
+#define CONETTE_PROF_STEM 1
+#define CONETTE_PROF_DWCONV_LN 2
+#define CONETTE_PROF_PW1_GEMM 3
+#define CONETTE_PROF_PW2_GEMM 4
+#define CONETTE_PROF_DOWNSAMPLE 5
+#define CONETTE_PROF_HEADS 6
+#define CONETTE_PROF_DEC_PREPARE 7
+#define CONETTE_PROF_DEC_GEMM 8
+#define CONETTE_PROF_DEC_ATTN 9
+#define CONETTE_PROF_DEC_MISC 10
+#define CONETTE_PROF_SEARCH 11
+#define CONETTE_PROF_NCLASS 12
+int conette_profile_enable(conette_ctx* ctx, uint32_t class_mask);
+int conette_profile_read(conette_ctx* ctx, float* ms, int32_t* counts);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,100 @@
+"""CPU: the C-ABI library loads and exports every symbol include/conette_hip.h declares; host
+logic (config / tokenizer / input normalisation helpers / synthetic checkpoint recipe)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    from conette_amd import engine
+    return engine.load_library()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "conette_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(conette_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 16
+    from conette_amd import engine
+    assert declared == set(engine.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.conette_abi_version() == 1
+
+
+def test_geometry_helpers(lib):
+    # 10 s -> 1001 STFT frames -> 31 encoder frames; 30 s -> 94; 5 s -> 15; 1 s -> 3
+    assert lib.conette_num_frames(320000) == 1001
+    assert [lib.conette_num_audio_frames(int(s * 32000)) for s in (10, 30, 5, 1)] == [31, 94, 15, 3]
+    assert lib.conette_resample_len(44100, 44100, 32000) == 32000
+    assert lib.conette_resample_len(1000, 16000, 32000) == 2000
+
+
+def test_engine_refuses_to_run_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from conette_amd.engine import Engine
+    with pytest.raises(RuntimeError):
+        Engine({"model.decoder.classifier.weight": torch.zeros(8, 256)})
+
+
+def test_config_roundtrip(tmp_path):
+    from conette_amd import CoNeTTEConfig, synth
+    cfg = CoNeTTEConfig(**synth.synth_config_dict(n_words=50))
+    cfg.save_pretrained(str(tmp_path))
+    cfg2 = CoNeTTEConfig.from_pretrained(str(tmp_path))
+    assert cfg2.beam_size == 3 and cfg2.min_pred_size == 3 and cfg2.max_pred_size == 20
+    assert list(cfg2.task_names) == list(synth.TASK_NAMES)
+    assert cfg2.tokenizer_state["tokenizer"]["itos"]["4"] == "w4"  # JSON turns int keys into str
+
+
+def test_tokenizer_decode_and_normalisers():
+    from conette_amd import synth
+    from conette_amd.tokenizer import AACTokenizer, unpickle_extra_state
+    st = synth.synth_tokenizer_state(n_words=20)
+    st["tokenizer"]["itos"][10] = ","
+    st["tokenizer"]["itos"][11] = "-"
+    st["tokenizer"]["itos"][12] = "Rain"
+    tok = AACTokenizer.from_txt_state(json.loads(json.dumps(st)))  # through JSON: str keys
+    assert tok.is_fit() and tok.get_vocab_size() == 4 + 20 + 7
+    assert tok.decode_rec(torch.tensor([[1, 4, 10, 5, 2, 0, 0]])) == ["w4, w5"]
+    assert tok.decode_rec(torch.tensor([12, 11, 5, 2])) == "rain-w5"
+    assert tok.decode_rec(torch.tensor([[[4, 2], [5, 2]]])) == [["w4", "w5"]]
+    assert tok.token_to_id("<bos_clotho>") == 24
+    extra = unpickle_extra_state(torch.from_numpy(synth.extra_state_tensor(20)))
+    assert extra["model.tokenizers.0._extra_state"]["tokenizer"]["itos"][4] == "w4"
+
+
+def test_extra_state_unpickler_refuses_code():
+    import pickle
+    from conette_amd.tokenizer import unpickle_extra_state
+    evil = torch.frombuffer(bytearray(pickle.dumps(os.system)), dtype=torch.uint8)
+    with pytest.raises(pickle.UnpicklingError):
+        unpickle_extra_state(evil)
+
+
+def test_frame_embs_lens_matches_reference_rule():
+    from conette_amd.preprocessor import frame_embs_lens
+    # 5 s in a 10 s batch -> 16; torch round-half-even on fp32
+    lens = frame_embs_lens(torch.tensor([320000, 160000, 64000]), 320000, 31)
+    assert lens.tolist() == [31, 16, 6] and lens.dtype == torch.int32
+
+
+def test_synth_recipe_is_deterministic():
+    from conette_amd import synth
+    a = synth.synth_state_dict(n_words=30)
+    b = synth.synth_state_dict(n_words=30)
+    assert len(a) == 306 and all(np.array_equal(a[k], b[k]) for k in a)
+    w1 = synth.synth_waveforms(2, 4000, 5, lengths=[4000, 1000])
+    assert np.array_equal(w1, synth.synth_waveforms(2, 4000, 5, lengths=[4000, 1000]))
+    assert (w1[1, 1000:] == 0).all() and w1.dtype == np.float32

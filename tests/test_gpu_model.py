@@ -1,0 +1,147 @@
+"""GPU: the drop-in Python API (CoNeTTEModel) end to end on the golden scenarios + API cases,
+and size-independent properties at the benchmark batch (B=64)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+TAGS = {i: f"tag{i}" for i in range(527)}
+
+
+@pytest.fixture(scope="module")
+def model_dir(tmp_path_factory):
+    from conette_amd import synth
+    return synth.write_pretrained_dir(str(tmp_path_factory.mktemp("conette_synth")))
+
+
+@pytest.fixture(scope="module")
+def model_fp32(model_dir):
+    from conette_amd import CoNeTTEConfig, CoNeTTEModel
+    config = CoNeTTEConfig.from_pretrained(model_dir)
+    return CoNeTTEModel.from_pretrained(model_dir, config=config, precision="fp32", offline=True,
+                                        audioset_idx_to_name=TAGS)
+
+
+@pytest.fixture(scope="module")
+def model_bf16(model_dir):
+    from conette_amd import CoNeTTEModel
+    return CoNeTTEModel.from_pretrained(model_dir, precision="bf16", offline=True, audioset_idx_to_name=TAGS)
+
+
+@pytest.mark.parametrize("name", G.SCENARIOS)
+def test_model_forward_matches_reference_fixture(name, model_fp32):
+    g = G.load(name)
+    x, kw = G.inputs(g)
+    out = model_fp32(x, sr=32000, **kw)
+    assert out["preds"].dtype == torch.long and out["mult_preds"].dtype == torch.long
+    assert out["preds"].cpu().tolist() == g["preds"].tolist()
+    assert out["mult_preds"].cpu().tolist() == g["mult_preds"].tolist()
+    np.testing.assert_allclose(out["lprobs"].cpu().numpy(), g["lprobs"], atol=2e-4)
+    np.testing.assert_allclose(out["mult_lprobs"].cpu().numpy(), g["mult_lprobs"], atol=2e-4)
+    assert out["cands"] == json.loads(str(g["cands"]))
+    assert out["mult_cands"] == json.loads(str(g["mult_cands"]))
+    assert out["tasks"] == json.loads(str(g["tasks"]))
+    np.testing.assert_allclose(out["tags_probs"].cpu().numpy(), g["tags_probs"], rtol=1e-3, atol=1e-4)
+    # tags: identical wherever the probability is not within 1e-3 of the 0.3 threshold
+    ref_tags = json.loads(str(g["tags"]))
+    for b, row in enumerate(g["tags_probs"]):
+        safe = {f"tag{i}" for i, p in enumerate(row) if abs(p - 0.3) > 1e-3}
+        assert set(out["tags"][b]) & safe == set(ref_tags[b]) & safe
+
+
+def test_api_cases(model_fp32):
+    from conette_amd import synth
+    with open(os.path.join(G.GOLDEN, "api_cases.json")) as f:
+        api = json.load(f)
+    m = model_fp32
+    wav = torch.from_numpy(synth.synth_waveforms(2, 64000, 7000))
+    assert m.default_task == api["default_task"] and m.tasks == api["tasks"]
+    assert m(wav[0], sr=32000)["preds"].cpu().tolist() == api["rank1_preds"]
+    assert m(wav[0][None], sr=32000)["preds"].cpu().tolist() == api["rank2_preds"]
+    assert m(wav[0:1, None], sr=32000)["preds"].cpu().tolist() == api["rank3_preds"]
+    o4 = m(torch.stack([wav[0], wav[1]], 0), sr=32000)
+    assert o4["preds"].cpu().tolist() == api["stereo_preds"]
+    o5 = m([wav[0][None], wav[1][None]], sr=[32000, 32000], task=["clotho", "audiocaps"])
+    assert o5["preds"].cpu().tolist() == api["list_preds"]
+    assert o5["tasks"] == api["list_tasks"] and o5["cands"] == api["list_cands"]
+    pre = m.preprocessor(wav[:, None], 32000, None)
+    o6 = m(pre["audio"], x_shapes=pre["audio_shape"], preprocess=False, task="clotho")
+    assert o6["preds"].cpu().tolist() == api["nopre_preds"] and sorted(o6.keys()) == api["nopre_keys"]
+    o7 = m(wav[:, None], sr=32000, task="clotho")
+    assert o7["preds"].cpu().tolist() == api["pre_preds"] and sorted(o7.keys()) == api["full_keys"]
+    with pytest.raises(ValueError) as e:
+        m(wav[0], sr=32000, task="not_a_task")
+    assert str(e.value) == api["bad_task_error"]
+    with pytest.raises(ValueError) as e:
+        m(wav[:, None], sr=32000, task=["clotho"])
+    assert str(e.value) == api["bad_ntasks_error"]
+    with pytest.raises(ValueError):
+        m(wav[0], sr=16000, x_shapes=torch.tensor([[64000]]))
+    # 16 kHz input through the HIP resampler
+    assert m(wav[0][::2].contiguous(), sr=16000)["preds"].cpu().tolist() == api["sr16k_preds"]
+    # test_inference.py semantics: str / list types, two tasks, forbid_rep_mode="none", beam 1 + tags
+    out = m(wav[0], sr=32000, task="clotho", forbid_rep_mode="none", beam_size=1)
+    assert isinstance(out["cands"][0], str) and isinstance(out["tags"], list)
+
+
+def test_wav_file_input(model_fp32, tmp_path):
+    """A path input goes through the PCM reader; 16-bit quantisation only perturbs the input."""
+    import wave
+    from conette_amd import synth
+    wav = synth.synth_waveforms(1, 48000, 31)[0]
+    pcm = np.clip(np.round(wav * 32768.0), -32768, 32767).astype("<i2")
+    p = str(tmp_path / "a.wav")
+    with wave.open(p, "wb") as w:
+        w.setnchannels(1), w.setsampwidth(2), w.setframerate(32000)
+        w.writeframes(pcm.tobytes())
+    out_path = model_fp32(p)
+    out_tensor = model_fp32(torch.from_numpy(pcm.astype(np.float32) / 32768.0), sr=32000)
+    assert out_path["preds"].cpu().tolist() == out_tensor["preds"].cpu().tolist()
+    assert isinstance(out_path["cands"][0], str)
+
+
+def test_properties_at_benchmark_batch(model_bf16):
+    """BASELINE configs[1]/[2] sizes (B=64, 10 s): size-independent properties of the path."""
+    from conette_amd import synth
+    eng = model_bf16.engine
+    B = 64
+    wave = torch.from_numpy(synth.synth_waveforms(B, 320000, 1234)).cuda()
+    fe, clip = eng.encode(wave)
+    fe2, clip2 = eng.encode(wave)
+    assert torch.equal(fe, fe2) and torch.equal(clip, clip2)                  # deterministic
+    assert torch.isfinite(fe).all() and ((clip >= 0) & (clip <= 1)).all()
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(0)).cuda()
+    fe_p, _ = eng.encode(wave[perm].contiguous())
+    assert torch.equal(fe_p, fe[perm])                                         # clips are independent
+    fe_s, _ = eng.encode(wave[:7].contiguous())
+    assert torch.equal(fe_s, fe[:7])                                           # and batch-size invariant
+    lens = torch.full((B,), fe.shape[1], dtype=torch.int32)
+    bos = model_bf16.task_id_to_token_id[torch.zeros(B, dtype=torch.long)]
+    o3 = eng.decode(fe, lens, bos, model_bf16.forbid_rep_mask, 3, 3, 20)
+    o3b = eng.decode(fe, lens, bos, model_bf16.forbid_rep_mask, 3, 3, 20)     # 2nd/3rd call: graph replay
+    o3c = eng.decode(fe, lens, bos, model_bf16.forbid_rep_mask, 3, 3, 20)
+    for k in ("best_preds", "best_lprobs", "mult_preds", "mult_lprobs", "sizes"):
+        assert torch.equal(o3[k], o3b[k]) and torch.equal(o3[k], o3c[k]), k
+    ps, bm = (int(v) for v in o3["sizes"].tolist())
+    mp, ml = o3["mult_preds"].cpu(), o3["mult_lprobs"].cpu()
+    bp, bl = o3["best_preds"].cpu(), o3["best_lprobs"].cpu()
+    assert torch.equal(bl, ml.max(dim=1).values)                               # best = max averaged log-prob
+    assert torch.equal(bp, mp[torch.arange(B), ml.argmax(dim=1)])
+    assert (mp[:, :, ps:] == 0).all() and 1 <= bm <= ps <= 20
+    for row in mp.reshape(-1, 20).tolist():                                    # EOS floor, pad after EOS
+        if 2 in row:
+            e = row.index(2)
+            assert e >= 3 and all(t == 0 for t in row[e + 1:])
+        assert all(t not in (1, 3) and t < 5624 for t in row)                 # never <bos>/<unk>/task tokens
+    forbid = model_bf16.forbid_rep_mask.cpu()
+    for row in mp.reshape(-1, 20).tolist():                                    # content words never repeat
+        seen = [t for t in row if t > 2 and forbid[t]]
+        assert len(seen) == len(set(seen))
+    o1 = eng.decode(fe, lens, bos, model_bf16.forbid_rep_mask, 1, 3, 20)
+    assert torch.equal(o1["best_preds"], o1["mult_preds"][:, 0])               # beam 1 == greedy chain
+    assert torch.equal(o1["best_lprobs"], o1["mult_lprobs"][:, 0])

@@ -1,0 +1,159 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI
+(conette_amd.engine -> libconette_hip.so); the checker is the committed golden fixtures
+(outputs of the imported reference) plus the CPU oracle on small cases.
+
+Tolerances:
+  fp32 mode : intermediates rtol 1e-3 / atol 2e-4 of an O(1) activation; token ids bit-exact
+              (every golden candidate gap is > 6e-4); averaged log-probs abs 1e-4.
+  bf16 mode : intermediates abs 0.1 (observed max 0.035 at rms ~1.1); every beam decision whose
+              reference top-(k+1) candidates are separated by > 0.25 must match for as long as the
+              search state is still the reference's; best averaged log-prob abs 0.15.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+NCHW_TAPS = ["stem", "stage0_block0", "stage0", "down1", "stage1", "down2", "stage2", "down3", "stage3"]
+
+
+@pytest.fixture(scope="module")
+def engines(synth_weights):
+    from conette_amd.engine import Engine
+    return {"fp32": Engine(synth_weights, precision="fp32"), "bf16": Engine(synth_weights, precision="bf16")}
+
+
+def _padded_wave(g):
+    from conette_amd import synth
+    n = [int(v) for v in g["lengths"]]
+    return torch.from_numpy(synth.synth_waveforms(len(n), max(n), int(g["seed0"]), lengths=n)), n
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", G.SCENARIOS)
+def test_encode_matches_reference_fixture(name, prec, engines):
+    g = G.load(name)
+    wave, n = _padded_wave(g)
+    fe, clip, taps = engines[prec].encode(wave.cuda(), taps=True)
+    torch.cuda.synchronize()
+    rtol, atol = (1e-3, 2e-4) if prec == "fp32" else (0.0, 0.1)
+    np.testing.assert_allclose(G.sub(taps["logmel"]), g["sub_logmel"], rtol=1e-3, atol=2e-3, err_msg="logmel")
+    for k in NCHW_TAPS:
+        got = G.sub(taps[k].permute(0, 3, 1, 2).contiguous())
+        np.testing.assert_allclose(got, g["sub_" + k], rtol=rtol, atol=atol, err_msg=f"{name}/{prec}/{k}")
+        if prec == "bf16":  # the bulk must be much closer than the worst element
+            assert float(np.abs(got - g["sub_" + k]).mean()) < 0.02, k
+    np.testing.assert_allclose(fe.cpu().numpy(), g["frame_embs"], rtol=rtol, atol=atol if prec == "fp32" else 0.06)
+    np.testing.assert_allclose(clip.cpu().numpy(), g["tags_probs"], rtol=rtol, atol=1e-4 if prec == "fp32" else 0.03)
+
+
+def _ref_calls(g, beam):
+    """Golden per-call trace -> list of (step, clip, parents, tokens, sums, margin)."""
+    par, tok, sums, margin = G.trace_of(g)
+    kw = json.loads(str(g["kw"]))
+    bsz = len(g["lengths"])
+    max_pred = kw.get("max_pred_size", 20)
+    k = [beam] * bsz
+    calls, ci = [], 0
+    for step in range(max_pred):
+        for clip in range(bsz):
+            if k[clip] == 0:
+                continue
+            assert len(par[ci]) == k[clip]
+            calls.append((step, clip, par[ci], tok[ci], sums[ci], float(margin[ci])))
+            n_fin = k[clip] if step == max_pred - 1 else sum(1 for t in tok[ci] if t == 2)
+            k[clip] -= n_fin
+            ci += 1
+        if ci == len(par):
+            break
+    assert ci == len(par)
+    return calls
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", G.SCENARIOS)
+def test_decode_matches_reference_fixture(name, prec, engines, synth_weights, synth_cfg):
+    """Beam search from the reference's own frame embeddings: per-step decisions and outputs."""
+    g = G.load(name)
+    kw = json.loads(str(g["kw"]))
+    eng = engines[prec]
+    bsz = len(g["lengths"])
+    beam = kw.get("beam_size", synth_cfg["beam_size"])
+    min_pred = kw.get("min_pred_size", synth_cfg["min_pred_size"])
+    max_pred = kw.get("max_pred_size", synth_cfg["max_pred_size"])
+    tasks = json.loads(str(g["tasks"]))
+    task_names = list(synth_cfg["task_names"])
+    bos = synth_weights["model.task_id_to_token_id"][torch.as_tensor([task_names.index(t) for t in tasks])]
+    mode = kw.get("forbid_rep_mode")
+    v = eng.vocab_size
+    forbid = {None: synth_weights["model.forbid_rep_mask"], "none": None, "all": torch.ones(v, dtype=torch.bool)}[mode]
+    fe = torch.from_numpy(g["frame_embs"]).cuda()
+    lens = torch.from_numpy(g["audio_shape"][:, 1].astype(np.int32))
+    out = eng.decode(fe, lens, bos, forbid, beam, min_pred, max_pred, want_trace=True)
+    torch.cuda.synchronize()
+    sel = out["trace_sel"].cpu().numpy()
+    val = out["trace_val"].cpu().numpy()
+    # Effective margin of a call = smallest gap among its top-(k+1) candidates: the gap to the first
+    # rejected candidate (recorded) and the gaps between consecutive picks (order decides row slots).
+    tol = 5e-4 if prec == "fp32" else 0.25
+    diverged = set()
+    n_checked = 0
+    for step, clip, par, tok, sums, margin in _ref_calls(g, beam):
+        if clip in diverged:
+            continue
+        k = len(par)
+        eff = min([margin] + [sums[i] - sums[i + 1] for i in range(k - 1)])
+        same = sel[step, clip, :k, 0].tolist() == par and sel[step, clip, :k, 1].tolist() == tok
+        if eff <= tol:
+            # a near-tie at this precision: either outcome is acceptable, but once the GPU path takes
+            # the other branch its later decisions are no longer comparable for this clip
+            if not same:
+                diverged.add(clip)
+            continue
+        assert same, (name, prec, step, clip, sel[step, clip, :k].tolist(), par, tok)
+        np.testing.assert_allclose(val[step, clip, :k], sums, atol=2e-4 * (step + 1) if prec == "fp32" else 0.12 * (step + 1))
+        n_checked += 1
+    assert n_checked > 0 or prec == "bf16"  # a single bf16 clip may hit a near-tie at step 0
+    ps, bm = (int(x) for x in out["sizes"].tolist())
+    if not diverged:
+        assert out["mult_preds"][:, :, :ps].cpu().tolist() == g["mult_preds"].tolist()
+        assert out["best_preds"][:, :bm].cpu().tolist() == g["preds"].tolist()
+        np.testing.assert_allclose(out["mult_lprobs"].cpu().numpy(), g["mult_lprobs"], atol=1e-4 if prec == "fp32" else 0.05)
+    # beam log-prob tolerance (north_star): clips whose search never left the reference's state must
+    # agree to 1e-4 (fp32) / 0.05 (bf16); a clip that took the other side of a near-tie decodes a
+    # different caption, whose length-normalised score is only sanity-bounded
+    keep = [b for b in range(bsz) if b not in diverged]
+    got_lp = out["best_lprobs"].cpu().numpy()
+    np.testing.assert_allclose(got_lp[keep], g["lprobs"][keep], atol=1e-4 if prec == "fp32" else 0.05)
+    assert np.all(np.abs(got_lp - g["lprobs"]) < 0.5) and np.all(got_lp < 0)
+    if prec == "fp32":
+        assert not diverged  # every golden candidate gap exceeds the fp32 tolerance
+
+
+def test_frontend_against_oracle_small(engines, synth_weights):
+    """Direct oracle check (DFT-as-conv restatement) on odd lengths incl. the reflect-padded edges."""
+    from conette_amd import synth
+    from oracle import cpu_ref as O
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    for L in (32000, 48001, 16383):
+        wave = torch.from_numpy(synth.synth_waveforms(2, L, 99, lengths=[L, L // 3]))
+        got = engines["fp32"].frontend_logmel(wave.cuda()).cpu()
+        with torch.no_grad():
+            ref = O.logmel_bn0(synth_weights, wave)[:, 0]
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-3, atol=2e-3)
+
+
+def test_resample_against_oracle(engines):
+    from oracle import thirdparty as tp
+    x = torch.randn(3, 44100, generator=torch.Generator().manual_seed(0))
+    for o, n in ((44100, 32000), (16000, 32000), (48000, 32000)):
+        got = engines["fp32"].resample(x.cuda(), o, n).cpu()
+        ref = tp.resample(x, o, n)
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
