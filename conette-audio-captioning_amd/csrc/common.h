@@ -56,6 +56,19 @@ __device__ __forceinline__ float cn_to_f32(bf16_t x) { return (float)x; }
 // exact-erf GELU (torch F.gelu default; reference convnext.py:47, aac_tfmer.py:36)
 __device__ __forceinline__ float cn_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7): 1 rcp + 1 exp + 6 fma instead of the
+// ~40-instruction libm erff; used by the bf16 path where the result is rounded to 8 bits anyway
+__device__ __forceinline__ float cn_gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = 1.0f - p * t * __expf(-z * z);  // erf(|x|/sqrt2)
+  return 0.5f * x + 0.5f * fabsf(x) * e;            // 0.5 x (1 + sign(x) erf(|x|/sqrt2))
+}
+
 // 64-lane butterfly reductions
 __device__ __forceinline__ float cn_wave_sum(float v) {
 #pragma unroll

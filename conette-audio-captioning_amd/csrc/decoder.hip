@@ -11,10 +11,13 @@
 //   * EOS floor, forbid-repeat mask, log-softmax, running sums, per-clip top-k and the
 //     finished / shrinking-k bookkeeping run in one kernel per step with no host sync.
 #include "ctx.h"
-#include "gemm.h"
+#include <type_traits>
+
+#include "gemm2.h"
 
 #define CN_MAX_BEAM 8
 #define CN_MAX_PRED 64
+#define FF2_SPLITS 8
 
 // ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -65,14 +68,32 @@ __global__ __launch_bounds__(256) void cn_embed_kernel(const int* __restrict__ t
   cn_store4(xt + (size_t)r * 256 + 4 * lane, o[0], o[1], o[2], o[3]);
 }
 
-// x = LayerNorm(tmp) (eps 1e-5, d == 256); one wave per row
+// x = LayerNorm(sum of nslab partial slabs [+ bias + residual]) (eps 1e-5, d == 256); one wave per row.
+// With nslab == 1 and no bias / residual this is the plain LayerNorm of a finished GEMM output.
 template <typename T>
-__global__ __launch_bounds__(256) void cn_ln256_kernel(const float* __restrict__ in, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void cn_ln256_kernel(const float* __restrict__ in, int nslab, size_t slab_stride,
+                                                       const float* __restrict__ bias,
+                                                       const float* __restrict__ resid, const float* __restrict__ w,
                                                        const float* __restrict__ b, int R, float* __restrict__ x,
                                                        T* __restrict__ xt) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= R) return;
-  const f32x4 v = *(const f32x4*)(in + (size_t)r * 256 + 4 * lane);
+  f32x4 v = *(const f32x4*)(in + (size_t)r * 256 + 4 * lane);
+  for (int sl = 1; sl < nslab; ++sl) {
+    const f32x4 u = *(const f32x4*)(in + sl * slab_stride + (size_t)r * 256 + 4 * lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += u[i];
+  }
+  if (bias) {
+    const f32x4 u = *(const f32x4*)(bias + 4 * lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += u[i];
+  }
+  if (resid) {
+    const f32x4 u = *(const f32x4*)(resid + (size_t)r * 256 + 4 * lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += u[i];
+  }
   const float mean = cn_wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
   float s2 = 0.f;
 #pragma unroll
@@ -377,7 +398,7 @@ __global__ void cn_finalize2_kernel(int B, const int* __restrict__ eos_idx, int*
 // ---------------------------------------------------------------------------------------------
 struct DecWs {
   void *fe_t, *mem, *kvc, *xt, *attn_t, *ffh, *kc, *vc;
-  float *x, *qkv, *q, *tmp, *logits;
+  float *x, *qkv, *q, *tmp, *logits, *slabs;
   int *n_active, *slot, *prefix, *anc, *cur_tok, *out_len, *eos_idx;
   float* sum_lp;
   int ldv;
@@ -404,6 +425,7 @@ static DecWs dec_ws(const conette_ctx* ctx, int B, int Ta, int beam, int maxp, c
   w.q = (float*)take((size_t)R * d * 4);
   w.attn_t = take((size_t)R * d * es);
   w.tmp = (float*)take((size_t)R * d * 4);
+  w.slabs = (float*)take((size_t)FF2_SPLITS * R * d * 4);
   w.ffh = take((size_t)R * ctx->cfg.d_ff * es);
   w.logits = (float*)take((size_t)R * w.ldv * 4);
   w.kc = take((size_t)NL * maxp * R * d * es);
@@ -451,9 +473,9 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
                        frame_embs, fe_t, n);
     CN_LAUNCH_CHECK();
     EpiBiasAct<T> ep{ctx->proj_b, mem, d, ACT_RELU};
-    CN_TRY((cn_gemm<T>(fe_t, CN_FEAT, (const T*)ctx->proj_w, CN_FEAT, B * Ta, d, CN_FEAT, ep, s)));
+    CN_TRY(cn_mm(fe_t, CN_FEAT, (const T*)ctx->proj_w, CN_FEAT, B * Ta, d, CN_FEAT, ep, s));
     EpiBiasAct<T> ekv{ctx->kv_b, kvc, kv_ld, ACT_NONE};
-    CN_TRY((cn_gemm<T>(mem, d, (const T*)ctx->kv_w, d, B * Ta, kv_ld, d, ekv, s)));
+    CN_TRY(cn_mm(mem, d, (const T*)ctx->kv_w, d, B * Ta, kv_ld, d, ekv, s));
   }
   hipLaunchKernelGGL(cn_init_state_kernel, dim3(64), dim3(256), 0, s, B, beam, maxp, bos_ids, w.n_active, w.slot,
                      w.sum_lp, w.prefix, w.anc, w.cur_tok, mult_preds, mult_lprobs, w.out_len, out_sizes, cfg.pad_id,
@@ -471,7 +493,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
       {
         CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
         EpiBiasAct<float> eq{lw.sa_in_b, w.qkv, 3 * d, ACT_NONE};
-        CN_TRY((cn_gemm<T>(xt, d, (const T*)lw.sa_in_w, d, R, 3 * d, d, eq, s)));
+        CN_TRY(cn_mm(xt, d, (const T*)lw.sa_in_w, d, R, 3 * d, d, eq, s));
       }
       {
         CnProfScope ps(ctx, CONETTE_PROF_DEC_ATTN, s);
@@ -482,17 +504,18 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
       {
         CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
         EpiResid eo{lw.sa_out_b, nullptr, w.x, w.tmp, d};
-        CN_TRY((cn_gemm<T>(attn_t, d, (const T*)lw.sa_out_w, d, R, d, d, eo, s)));
+        CN_TRY(cn_mm(attn_t, d, (const T*)lw.sa_out_w, d, R, d, d, eo, s));
       }
       {
         CnProfScope ps(ctx, CONETTE_PROF_DEC_MISC, s);
-        hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, lw.n1w, lw.n1b, R, w.x, xt);
+        hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, 1, (size_t)0, (const float*)nullptr,
+                           (const float*)nullptr, lw.n1w, lw.n1b, R, w.x, xt);
         CN_LAUNCH_CHECK();
       }
       {
         CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
         EpiBiasAct<float> ecq{lw.ca_q_b, w.q, d, ACT_NONE};
-        CN_TRY((cn_gemm<T>(xt, d, (const T*)lw.ca_q_w, d, R, d, d, ecq, s)));
+        CN_TRY(cn_mm(xt, d, (const T*)lw.ca_q_w, d, R, d, d, ecq, s));
       }
       {
         CnProfScope ps(ctx, CONETTE_PROF_DEC_ATTN, s);
@@ -503,33 +526,48 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
       {
         CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
         EpiResid eco{lw.ca_out_b, nullptr, w.x, w.tmp, d};
-        CN_TRY((cn_gemm<T>(attn_t, d, (const T*)lw.ca_out_w, d, R, d, d, eco, s)));
+        CN_TRY(cn_mm(attn_t, d, (const T*)lw.ca_out_w, d, R, d, d, eco, s));
       }
       {
         CnProfScope ps(ctx, CONETTE_PROF_DEC_MISC, s);
-        hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, lw.n2w, lw.n2b, R, w.x, xt);
+        hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, 1, (size_t)0, (const float*)nullptr,
+                           (const float*)nullptr, lw.n2w, lw.n2b, R, w.x, xt);
         CN_LAUNCH_CHECK();
       }
       {
         CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-        EpiBiasAct<T> e1{lw.ff1_b, ffh, dff, ACT_GELU};
-        CN_TRY((cn_gemm<T>(xt, d, (const T*)lw.ff1_w, d, R, dff, d, e1, s)));
+        EpiBiasAct<T> e1{lw.ff1_b, ffh, dff, std::is_same<T, bf16_t>::value ? ACT_GELU_FAST : ACT_GELU};
+        CN_TRY(cn_mm(xt, d, (const T*)lw.ff1_w, d, R, dff, d, e1, s));
       }
-      {
-        CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-        EpiResid e2{lw.ff2_b, nullptr, w.x, w.tmp, d};
-        CN_TRY((cn_gemm<T>(ffh, dff, (const T*)lw.ff2_w, dff, R, d, dff, e2, s)));
-      }
-      {
+      if constexpr (std::is_same<T, bf16_t>::value) {
+        // K = d_ff is long and M = R is small: split K over blockIdx.y into partial slabs, summed
+        // (fixed order, with bias + residual) by the LayerNorm kernel that follows
+        const int splits = (dff % (FF2_SPLITS * 64) == 0) ? FF2_SPLITS : 1;
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+          EpiSlab e2{w.slabs, d, (size_t)R * d};
+          CN_TRY(cn_gemm2(ffh, dff, (const bf16_t*)lw.ff2_w, dff, R, d, dff, e2, s, splits));
+        }
         CnProfScope ps(ctx, CONETTE_PROF_DEC_MISC, s);
-        hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, lw.n3w, lw.n3b, R, w.x, xt);
+        hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.slabs, splits, (size_t)R * d,
+                           lw.ff2_b, w.x, lw.n3w, lw.n3b, R, w.x, xt);
+        CN_LAUNCH_CHECK();
+      } else {
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+          EpiResid e2{lw.ff2_b, nullptr, w.x, w.tmp, d};
+          CN_TRY(cn_mm(ffh, dff, (const T*)lw.ff2_w, dff, R, d, dff, e2, s));
+        }
+        CnProfScope ps(ctx, CONETTE_PROF_DEC_MISC, s);
+        hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, 1, (size_t)0,
+                           (const float*)nullptr, (const float*)nullptr, lw.n3w, lw.n3b, R, w.x, xt);
         CN_LAUNCH_CHECK();
       }
     }
     {
       CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
       EpiBiasAct<float> ec{ctx->cls_b, w.logits, w.ldv, ACT_NONE};
-      CN_TRY((cn_gemm<T>(xt, d, (const T*)ctx->cls_w, d, R, V, d, ec, s)));
+      CN_TRY(cn_mm(xt, d, (const T*)ctx->cls_w, d, R, V, d, ec, s));
     }
     if (step == 0 && step0_logits)
       CN_HIP(hipMemcpyAsync(step0_logits, w.logits, (size_t)R * w.ldv * 4, hipMemcpyDeviceToDevice, s));

@@ -6,7 +6,9 @@
 // operand type (bf16 or fp32).  Depthwise 7x7 + LayerNorm run on the VALU, the pointwise and
 // downsample contractions on MFMA through cn_gemm (north_star).
 #include "ctx.h"
-#include "gemm.h"
+#include <type_traits>
+
+#include "gemm2.h"
 
 // ---------------------------------------------------------------------------------------------
 // stem: Conv2d(1 -> 96, k 4x4, s 4x4, pad (4, 0)) + LayerNorm(channels_first, eps 1e-6)
@@ -388,7 +390,7 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
                          Cp, n_in, dw.ln_w, dw.ln_b, y);
       CN_LAUNCH_CHECK();
       EpiBiasAct<float> epi{dw.bias, ws.x, C, ACT_NONE};
-      CN_TRY((cn_gemm<T>(y, 4 * Cp, (const T*)dw.w, 4 * Cp, (int)P, C, 4 * Cp, epi, s)));
+      CN_TRY(cn_mm(y, 4 * Cp, (const T*)dw.w, 4 * Cp, (int)P, C, 4 * Cp, epi, s));
       if (taps) CN_TRY(tap_copy(taps->down[st], ws.x, (size_t)P * C, s));
     }
     for (int b = 0; b < CN_DEPTHS[st]; ++b, ++blk) {
@@ -399,13 +401,13 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
       }
       {
         CnProfScope ps(ctx, CONETTE_PROF_PW1_GEMM, s);
-        EpiBiasAct<T> e1{bw.b1, hbuf, 4 * C, ACT_GELU};
-        CN_TRY((cn_gemm<T>(y, C, (const T*)bw.w1, C, (int)P, 4 * C, C, e1, s)));
+        EpiBiasAct<T> e1{bw.b1, hbuf, 4 * C, std::is_same<T, bf16_t>::value ? ACT_GELU_FAST : ACT_GELU};
+        CN_TRY(cn_mm(y, C, (const T*)bw.w1, C, (int)P, 4 * C, C, e1, s));
       }
       {
         CnProfScope ps(ctx, CONETTE_PROF_PW2_GEMM, s);
         EpiResid e2{bw.b2, bw.scale, ws.x, ws.x, C};
-        CN_TRY((cn_gemm<T>(hbuf, 4 * C, (const T*)bw.w2, 4 * C, (int)P, C, 4 * C, e2, s)));
+        CN_TRY(cn_mm(hbuf, 4 * C, (const T*)bw.w2, 4 * C, (int)P, C, 4 * C, e2, s));
       }
       if (taps && b == 0) CN_TRY(tap_copy(taps->stage_block0[st], ws.x, (size_t)P * C, s));
     }
@@ -421,7 +423,7 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
                        ctx->norm_b, (T*)ws.clip_t);
     CN_LAUNCH_CHECK();
     EpiBiasAct<float> eh{ctx->head_b, clip_probs, CN_N_TAGS, ACT_SIGMOID};
-    CN_TRY((cn_gemm<T>((const T*)ws.clip_t, CN_FEAT, (const T*)ctx->head_w, CN_FEAT, B, CN_N_TAGS, CN_FEAT, eh, s)));
+    CN_TRY(cn_mm((const T*)ws.clip_t, CN_FEAT, (const T*)ctx->head_w, CN_FEAT, B, CN_N_TAGS, CN_FEAT, eh, s));
   }
   return CN_OK;
 }

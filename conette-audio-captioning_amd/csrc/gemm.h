@@ -24,7 +24,7 @@ template <> struct GemmTraits<float> {
   static constexpr int CPR = 8;
 };
 
-enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3, ACT_GELU_FAST = 4 };
 
 // out[m][n] = act(acc + bias[n])
 template <typename TOut> struct EpiBiasAct {
@@ -32,13 +32,14 @@ template <typename TOut> struct EpiBiasAct {
   TOut* out;
   int ldo;
   int act;
-  __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int N) const {
+  __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int N, int /*ks*/ = 0) const {
     float r[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float x = v[i];
       if (bias != nullptr && n + i < N) x += bias[n + i];
       if (act == ACT_GELU) x = cn_gelu(x);
+      else if (act == ACT_GELU_FAST) x = cn_gelu_fast(x);
       else if (act == ACT_RELU) x = fmaxf(x, 0.0f);
       else if (act == ACT_SIGMOID) x = 1.0f / (1.0f + __expf(-x));
       r[i] = x;
@@ -61,7 +62,7 @@ struct EpiResid {
   const float* resid;
   float* out;
   int ld;
-  __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int N) const {
+  __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int N, int /*ks*/ = 0) const {
     const size_t o = (size_t)m * ld + n;
     if (n + 3 < N && (ld & 3) == 0) {
       f32x4 rs = *(const f32x4*)(resid + o);

@@ -225,9 +225,11 @@ class Engine:
         return frame_embs, clip
 
     # ---- a9-a14 ----------------------------------------------------------------------------
-    def _decode_buffers(self, b: int, t: int, beam: int, max_pred: int, s0: bool, trace: bool) -> Dict[str, Any]:
-        """Persistent I/O buffers per shape: identical pointers let the library replay its hipGraph."""
-        key = (b, t, beam, max_pred, s0, trace)
+    def _decode_buffers(self, b: int, t: int, beam: int, max_pred: int, s0: bool, trace: bool,
+                        slot: int = 0) -> Dict[str, Any]:
+        """Persistent I/O buffers per shape (and pipeline slot): identical pointers let the library
+        replay its hipGraph."""
+        key = (b, t, beam, max_pred, s0, trace, slot)
         buf = self._dec_bufs.get(key)
         if buf is None:
             dev = self.device
@@ -250,11 +252,13 @@ class Engine:
 
     def decode(self, frame_embs: torch.Tensor, frame_lens: torch.Tensor, bos_ids: torch.Tensor,
                forbid_mask: Optional[torch.Tensor], beam: int, min_pred: int, max_pred: int,
-               want_step0_logits: bool = False, want_trace: bool = False, clone: bool = True) -> Dict[str, torch.Tensor]:
+               want_step0_logits: bool = False, want_trace: bool = False, clone: bool = True,
+               slot: int = 0) -> Dict[str, torch.Tensor]:
         """Beam search over pre-computed frame embeddings.  Outputs are full width; trim with
-        ``sizes`` = [pred_size, best_maxlen].  ``clone=False`` returns the persistent buffers."""
+        ``sizes`` = [pred_size, best_maxlen].  ``clone=False`` returns the persistent buffers of
+        pipeline ``slot`` (two slots let the decode of batch i overlap the encode of batch i+1)."""
         b, t, _ = frame_embs.shape
-        buf = self._decode_buffers(b, t, int(beam), int(max_pred), want_step0_logits, want_trace)
+        buf = self._decode_buffers(b, t, int(beam), int(max_pred), want_step0_logits, want_trace, slot)
         if frame_embs.data_ptr() != buf["fe"].data_ptr():
             buf["fe"].copy_(frame_embs, non_blocking=True)
         buf["lens"].copy_(frame_lens.to(torch.int32), non_blocking=True)
@@ -266,7 +270,7 @@ class Engine:
             buf["forbid"].copy_(forbid_mask.to(torch.uint8), non_blocking=True)
             forbid_ptr = buf["forbid"]
         need = self.lib.conette_decode_workspace_bytes(self._ctx, b, t, beam, max_pred)
-        wsb = self._workspace("dec", need)
+        wsb = self._workspace("dec", need)  # one workspace: decodes of all slots serialise on their stream
         st = self.lib.conette_decode(self._ctx, _ptr(buf["fe"]), _ptr(buf["lens"]), _ptr(buf["bos"]), _ptr(forbid_ptr),
                                      b, t, beam, min_pred, max_pred, _ptr(buf["best_preds"]), _ptr(buf["best_lprobs"]),
                                      _ptr(buf["mult_preds"]), _ptr(buf["mult_lprobs"]), _ptr(buf["sizes"]),
@@ -282,9 +286,9 @@ class Engine:
             out["trace_val"] = cp(buf["trace_val"])
         return out
 
-    def decode_input_buffer(self, b: int, t: int, beam: int, max_pred: int) -> torch.Tensor:
+    def decode_input_buffer(self, b: int, t: int, beam: int, max_pred: int, slot: int = 0) -> torch.Tensor:
         """The persistent (B, T, 768) input of decode(): encode straight into it to skip a copy."""
-        return self._decode_buffers(b, t, int(beam), int(max_pred), False, False)["fe"]
+        return self._decode_buffers(b, t, int(beam), int(max_pred), False, False, slot)["fe"]
 
     # ---- options / profiling ------------------------------------------------------------------
     def set_decode_graph(self, enabled: bool) -> None:
