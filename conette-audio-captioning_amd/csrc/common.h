@@ -69,6 +69,16 @@ __device__ __forceinline__ float cn_gelu_fast(float x) {
   return 0.5f * x + 0.5f * fabsf(x) * e;            // 0.5 x (1 + sign(x) erf(|x|/sqrt2))
 }
 
+// XCD-aware block remap (cdna guide T1, bijective form): workgroups are dealt round-robin over the
+// 8 XCDs, each with a private L2, so blocks b and b+8 share an L2.  Give every XCD one CONTIGUOUS
+// chunk of the logical grid so that neighbouring tiles (shared halos / shared A panels) hit in L2
+// instead of being re-fetched over the fabric once per XCD.  Affects speed only.
+__device__ __forceinline__ int cn_xcd_remap(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7;
+  const int xcd = bid & 7, i = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
 // 64-lane butterfly reductions
 __device__ __forceinline__ float cn_wave_sum(float v) {
 #pragma unroll

@@ -76,71 +76,89 @@ __global__ __launch_bounds__(256) void cn_stem_kernel(const float* __restrict__ 
 
 // ---------------------------------------------------------------------------------------------
 // depthwise 7x7 (pad 3) + LayerNorm over C (eps 1e-6): x fp32 (B,H,W,C) -> y T (B,H,W,C)
-// One thread = one channel x a 4(h) x 4(w) output patch: 100 loads feed 784 FMAs; the block is
-// C x S threads covering a 4 x (4S) tile for all channels, so the LayerNorm over C is local to
-// the block: conv results go through an LDS tile [pos][C] and one wave normalises a position.
+// One thread = one channel x a TH(h) x 4(w) output patch: (TH+6) x 10 loads feed TH*4*49 FMAs.
+// Loads are branch-free (clamped address, zero-masked value) and issued a whole input row at a
+// time so that many are in flight; lanes run over channels, so every load instruction is one
+// coalesced 256-byte line.  The block is C x S threads covering a TH x (4S) tile for all
+// channels, so the LayerNorm over C is local to the block: conv results go through an LDS tile
+// [pos][C] and one wave normalises a position (two-pass mean / variance, wave-shuffle sums).
 // ---------------------------------------------------------------------------------------------
-template <typename T, int C, int S>
-__global__ __launch_bounds__(C* S) void cn_dwconv_ln_kernel(const float* __restrict__ x, int H, int W, int tiles_h,
+template <typename T, int C, int S, int TH>
+__global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(const float* __restrict__ x, int H, int W, int tiles_h,
                                                             int tiles_w, const float* __restrict__ dw_w /*[49][C]*/,
                                                             const float* __restrict__ dw_b,
                                                             const float* __restrict__ ln_w,
                                                             const float* __restrict__ ln_b, T* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* s_v = (float*)smem_raw;  // [16*S][C]
+  float* s_v = (float*)smem_raw;  // [TH*4*S][C]
+  constexpr int NP = TH * 4;      // positions per thread
+  constexpr int CT = C > 384 ? 384 : C;  // threads along the channel axis (C = 768: two passes)
   const int tid = threadIdx.x;
-  const int c = tid % C, sidx = tid / C;
-  int bid = blockIdx.x;
+  const int c0 = tid % CT, sidx = tid / CT;
+  int bid = cn_xcd_remap(blockIdx.x, gridDim.x);
   const int tw = bid % tiles_w;
   bid /= tiles_w;
   const int th = bid % tiles_h;
   const int b = bid / tiles_h;
-  const int h0 = th * 4, w0 = tw * (4 * S) + sidx * 4;
+  const int h0 = th * TH, w0 = tw * (4 * S) + sidx * 4;
 
+  int wcl[10];
+  bool wok[10];
+#pragma unroll
+  for (int q = 0; q < 10; ++q) {
+    const int ww = w0 - 3 + q;
+    wok[q] = (ww >= 0) && (ww < W);
+    wcl[q] = min(max(ww, 0), W - 1) * C;
+  }
+#pragma unroll 1
+  for (int c = c0; c < C; c += CT) {
   float k[49];
 #pragma unroll
   for (int i = 0; i < 49; ++i) k[i] = dw_w[i * C + c];
-  float acc[4][4];
+  float acc[TH][4];
   const float bias = dw_b[c];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < TH; ++a)
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[a][e] = bias;
 
   const float* xb = x + (size_t)b * H * W * C + c;
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < TH + 6; ++r) {
     const int hh = h0 - 3 + r;
-    if (hh < 0 || hh >= H) continue;
+    const bool hok = (hh >= 0) && (hh < H);
+    const float* xr = xb + (size_t)min(max(hh, 0), H - 1) * W * C;
+    float v[10];
 #pragma unroll
-    for (int q = 0; q < 10; ++q) {
-      const int ww = w0 - 3 + q;
-      float v = 0.f;
-      if (ww >= 0 && ww < W) v = xb[((size_t)hh * W + ww) * C];
+    for (int q = 0; q < 10; ++q) v[q] = xr[wcl[q]];
 #pragma unroll
-      for (int oh = 0; oh < 4; ++oh) {
-        const int i = r - oh;
-        if (i < 0 || i > 6) continue;
+    for (int q = 0; q < 10; ++q) v[q] = (hok && wok[q]) ? v[q] : 0.f;
+#pragma unroll
+    for (int oh = 0; oh < TH; ++oh) {
+      const int i = r - oh;
+      if (i < 0 || i > 6) continue;
+#pragma unroll
+      for (int q = 0; q < 10; ++q)
 #pragma unroll
         for (int ow = 0; ow < 4; ++ow) {
           const int j = q - ow;
           if (j < 0 || j > 6) continue;
-          acc[oh][ow] = fmaf(v, k[i * 7 + j], acc[oh][ow]);
+          acc[oh][ow] = fmaf(v[q], k[i * 7 + j], acc[oh][ow]);
         }
-      }
     }
   }
 #pragma unroll
-  for (int oh = 0; oh < 4; ++oh)
+  for (int oh = 0; oh < TH; ++oh)
 #pragma unroll
-    for (int ow = 0; ow < 4; ++ow) s_v[((sidx * 16) + oh * 4 + ow) * C + c] = acc[oh][ow];
+    for (int ow = 0; ow < 4; ++ow) s_v[((sidx * NP) + oh * 4 + ow) * C + c] = acc[oh][ow];
+  }
   __syncthreads();
 
-  constexpr int NW = C * S / 64;
+  constexpr int NW = CT * S / 64;
   constexpr int PER = (C + 63) / 64;
   const int lane = tid & 63, wv = tid >> 6;
-  for (int p = wv; p < 16 * S; p += NW) {
-    const int ps = p >> 4, oh = (p >> 2) & 3, ow = p & 3;
+  for (int p = wv; p < NP * S; p += NW) {
+    const int ps = p / NP, oh = (p % NP) >> 2, ow = p & 3;
     const int h = h0 + oh, w = tw * (4 * S) + ps * 4 + ow;
     if (h >= H || w >= W) continue;  // wave-uniform
     float v[PER];
@@ -169,18 +187,18 @@ __global__ __launch_bounds__(C* S) void cn_dwconv_ln_kernel(const float* __restr
   }
 }
 
-template <typename T, int C, int S>
+template <typename T, int C, int S, int TH>
 static int launch_dwconv(const float* x, int B, int H, int W, const CnBlockW& bw, T* y, hipStream_t s) {
-  const int tiles_h = cn_cdiv(H, 4), tiles_w = cn_cdiv(W, 4 * S);
-  const size_t smem = (size_t)16 * S * C * sizeof(float);
+  const int tiles_h = cn_cdiv(H, TH), tiles_w = cn_cdiv(W, 4 * S);
+  const size_t smem = (size_t)TH * 4 * S * C * sizeof(float);
   static bool configured = false;
   if (!configured) {
-    CN_HIP(hipFuncSetAttribute((const void*)cn_dwconv_ln_kernel<T, C, S>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)smem));
+    CN_HIP(hipFuncSetAttribute((const void*)cn_dwconv_ln_kernel<T, C, S, TH>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     configured = true;
   }
-  hipLaunchKernelGGL((cn_dwconv_ln_kernel<T, C, S>), dim3((unsigned)(B * tiles_h * tiles_w)), dim3(C * S), smem, s, x,
-                     H, W, tiles_h, tiles_w, bw.dw_w, bw.dw_b, bw.ln_w, bw.ln_b, y);
+  hipLaunchKernelGGL((cn_dwconv_ln_kernel<T, C, S, TH>), dim3((unsigned)(B * tiles_h * tiles_w)),
+                     dim3((C > 384 ? 384 : C) * S), smem, s, x, H, W, tiles_h, tiles_w, bw.dw_w, bw.dw_b, bw.ln_w, bw.ln_b, y);
   CN_LAUNCH_CHECK();
   return CN_OK;
 }
@@ -343,10 +361,10 @@ extern "C" size_t conette_encode_workspace_bytes(const conette_ctx* ctx, int32_t
 template <typename T>
 static int dwconv_dispatch(int C, const float* x, int B, int H, int W, const CnBlockW& bw, T* y, hipStream_t s) {
   switch (C) {
-    case 96: return launch_dwconv<T, 96, 2>(x, B, H, W, bw, y, s);
-    case 192: return launch_dwconv<T, 192, 1>(x, B, H, W, bw, y, s);
-    case 384: return launch_dwconv<T, 384, 1>(x, B, H, W, bw, y, s);
-    case 768: return launch_dwconv<T, 768, 1>(x, B, H, W, bw, y, s);
+    case 96: return launch_dwconv<T, 96, 2, 8>(x, B, H, W, bw, y, s);
+    case 192: return launch_dwconv<T, 192, 1, 8>(x, B, H, W, bw, y, s);
+    case 384: return launch_dwconv<T, 384, 1, 4>(x, B, H, W, bw, y, s);
+    case 768: return launch_dwconv<T, 768, 1, 4>(x, B, H, W, bw, y, s);
   }
   cn_set_error("dwconv: unsupported C=%d", C);
   return CN_ERR_ARG;

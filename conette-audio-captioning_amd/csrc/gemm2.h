@@ -49,8 +49,9 @@ __global__ __launch_bounds__(256) void cn_gemm2_kernel(const bf16_t* __restrict_
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int n_tiles = (N + BN - 1) / BN;
-  const int m0 = (blockIdx.x / n_tiles) * BM;
-  const int n0 = (blockIdx.x % n_tiles) * BN;
+  const int bid = cn_xcd_remap(blockIdx.x, gridDim.x);  // the n-tiles of one A panel share an XCD / L2
+  const int m0 = (bid / n_tiles) * BM;
+  const int n0 = (bid % n_tiles) * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
