@@ -32,6 +32,27 @@ template <typename TOut> struct EpiBiasAct {
   TOut* out;
   int ldo;
   int act;
+  // --- staged interface (gemm2.h): registers -> pre() -> LDS tile -> commit() of 16-byte row chunks
+  typedef TOut stage_t;
+  __device__ __forceinline__ float pre(int n, float x, int N) const {
+    if (bias != nullptr && n < N) x += bias[n];
+    if (act == ACT_GELU) x = cn_gelu(x);
+    else if (act == ACT_GELU_FAST) x = cn_gelu_fast(x);
+    else if (act == ACT_RELU) x = fmaxf(x, 0.0f);
+    else if (act == ACT_SIGMOID) x = 1.0f / (1.0f + __expf(-x));
+    return x;
+  }
+  __device__ __forceinline__ void commit(int m, int n, const TOut* chunk, int N, int /*ks*/) const {
+    constexpr int E = 16 / (int)sizeof(TOut);
+    TOut* p = out + (size_t)m * ldo + n;
+    if (n + E - 1 < N && (ldo % E) == 0) {
+      *(uint4*)p = *(const uint4*)chunk;
+    } else {
+#pragma unroll
+      for (int i = 0; i < E; ++i)
+        if (n + i < N) p[i] = chunk[i];
+    }
+  }
   __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int N, int /*ks*/ = 0) const {
     float r[4];
 #pragma unroll
@@ -62,6 +83,24 @@ struct EpiResid {
   const float* resid;
   float* out;
   int ld;
+  typedef float stage_t;
+  __device__ __forceinline__ float pre(int n, float x, int N) const {
+    if (n >= N) return 0.f;
+    x += bias[n];
+    return scale ? scale[n] * x : x;
+  }
+  __device__ __forceinline__ void commit(int m, int n, const float* chunk, int N, int /*ks*/) const {
+    const size_t o = (size_t)m * ld + n;
+    if (n + 3 < N && (ld & 3) == 0) {
+      const f32x4 rs = *(const f32x4*)(resid + o);
+      const f32x4 c = *(const f32x4*)chunk;
+      *(f32x4*)(out + o) = f32x4{rs[0] + c[0], rs[1] + c[1], rs[2] + c[2], rs[3] + c[3]};
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (n + i < N) out[o + i] = resid[o + i] + chunk[i];
+    }
+  }
   __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int N, int /*ks*/ = 0) const {
     const size_t o = (size_t)m * ld + n;
     if (n + 3 < N && (ld & 3) == 0) {

@@ -20,6 +20,18 @@ struct EpiSlab {
   float* out;
   int ld;
   size_t slab_stride;
+  typedef float stage_t;
+  __device__ __forceinline__ float pre(int, float x, int) const { return x; }
+  __device__ __forceinline__ void commit(int m, int n, const float* chunk, int N, int ks) const {
+    float* p = out + (size_t)ks * slab_stride + (size_t)m * ld + n;
+    if (n + 3 < N && (ld & 3) == 0) {
+      *(f32x4*)p = *(const f32x4*)chunk;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (n + i < N) p[i] = chunk[i];
+    }
+  }
   __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int N, int ks) const {
     float* p = out + (size_t)ks * slab_stride + (size_t)m * ld + n;
     if (n + 3 < N && (ld & 3) == 0) {
@@ -126,20 +138,52 @@ __global__ __launch_bounds__(256) void cn_gemm2_kernel(const bf16_t* __restrict_
     buf ^= 1;
   }
 
+  // ---- staged epilogue: registers -> LDS tile [BM][BN] (output type) -> whole-row 16-byte stores.
+  // Direct stores from the MFMA layout are 8/16 bytes per lane scattered over 16 rows, which cost
+  // up to 2.2x write amplification at HBM (rocprof WRITE_SIZE); through LDS every wave-instruction
+  // stores contiguous 16-byte chunks of a few rows.  (The loop above ended on a barrier.)
+  typedef typename Epi::stage_t ST;
+  if constexpr (sizeof(ST) == 4) {
+    // fp32 outputs already store 16 bytes per lane (64 contiguous bytes per row and instruction):
+    // staging a 64 KB fp32 tile only costs occupancy (measured: pw2 +35 %), so store directly
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const int m = m0 + wm * (BM / 2) + b * 16 + (lane & 15);
+        const int n = n0 + wn * (BN / 2) + a * 16 + 4 * (lane >> 4);
+        if (m < M && n < N) epi(m, n, acc[a][b], N, (int)blockIdx.y);
+      }
+    return;
+  }
+  constexpr int EPC = 16 / (int)sizeof(ST);          // elements per 16-byte chunk
+  constexpr int PITCH = BN + EPC;                     // padded row pitch (elements)
+  constexpr int CH = BN / EPC;                        // chunks per row
+  ST* tile = (ST*)smem;
 #pragma unroll
   for (int a = 0; a < TN; ++a)
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
-      const int m = m0 + wm * (BM / 2) + b * 16 + (lane & 15);
-      const int n = n0 + wn * (BN / 2) + a * 16 + 4 * (lane >> 4);
-      if (m < M && n < N) epi(m, n, acc[a][b], N, (int)blockIdx.y);
+      const int ml = wm * (BM / 2) + b * 16 + (lane & 15);
+      const int nl = wn * (BN / 2) + a * 16 + 4 * (lane >> 4);
+      const f32x4 v = acc[a][b];
+      cn_store4(tile + ml * PITCH + nl, epi.pre(n0 + nl, v[0], N), epi.pre(n0 + nl + 1, v[1], N),
+                epi.pre(n0 + nl + 2, v[2], N), epi.pre(n0 + nl + 3, v[3], N));
     }
+  __syncthreads();
+  for (int idx = tid; idx < BM * CH; idx += 256) {
+    const int r = idx / CH, c = idx % CH;
+    const int m = m0 + r, n = n0 + c * EPC;
+    if (m < M && n < N) epi.commit(m, n, tile + r * PITCH + c * EPC, N, (int)blockIdx.y);
+  }
 }
 
 template <int BM, int BN, int BK, class Epi>
 static int cn_launch_gemm2_t(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, int splits,
                              const Epi& epi, hipStream_t stream) {
-  constexpr int SMEM = 2 * (BM + BN) * BK * 2;
+  constexpr int EPI_BYTES = sizeof(typename Epi::stage_t) == 4 ? 0 : BM * (BN * 2 + 16);
+  constexpr int PIPE_BYTES = 2 * (BM + BN) * BK * 2;
+  constexpr int SMEM = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
   static bool configured = false;
   if (!configured) {
     CN_HIP(hipFuncSetAttribute((const void*)cn_gemm2_kernel<BM, BN, BK, Epi>,
