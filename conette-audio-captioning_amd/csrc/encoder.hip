@@ -9,6 +9,7 @@
 #include <type_traits>
 
 #include "gemm2.h"
+#include "mlp_fused.h"
 
 // ---------------------------------------------------------------------------------------------
 // stem: Conv2d(1 -> 96, k 4x4, s 4x4, pad (4, 0)) + LayerNorm(channels_first, eps 1e-6)
@@ -417,15 +418,31 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
         CnProfScope ps(ctx, CONETTE_PROF_DWCONV_LN, s);
         CN_TRY(dwconv_dispatch<T>(C, ws.x, B, H, W, bw, y, s));
       }
-      {
-        CnProfScope ps(ctx, CONETTE_PROF_PW1_GEMM, s);
-        EpiBiasAct<T> e1{bw.b1, hbuf, 4 * C, std::is_same<T, bf16_t>::value ? ACT_GELU_FAST : ACT_GELU};
-        CN_TRY(cn_mm(y, C, (const T*)bw.w1, C, (int)P, 4 * C, C, e1, s));
+      bool fused = false;
+      if constexpr (std::is_same<T, bf16_t>::value) {
+        // narrow stages: fused MLP keeps the 4C hidden in LDS (mlp_fused.h); timed under PW1
+        if (C == 96 || C == 192) {
+          CnProfScope ps(ctx, CONETTE_PROF_PW1_GEMM, s);
+          if (C == 96)
+            CN_TRY((cn_launch_mlp_fused<96, 4>(y, (const bf16_t*)bw.w1, bw.b1, (const bf16_t*)bw.w2, bw.b2, bw.scale,
+                                               ws.x, (int)P, s)));
+          else
+            CN_TRY((cn_launch_mlp_fused<192, 2>(y, (const bf16_t*)bw.w1, bw.b1, (const bf16_t*)bw.w2, bw.b2, bw.scale,
+                                                ws.x, (int)P, s)));
+          fused = true;
+        }
       }
-      {
-        CnProfScope ps(ctx, CONETTE_PROF_PW2_GEMM, s);
-        EpiResid e2{bw.b2, bw.scale, ws.x, ws.x, C};
-        CN_TRY(cn_mm(hbuf, 4 * C, (const T*)bw.w2, 4 * C, (int)P, C, 4 * C, e2, s));
+      if (!fused) {
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_PW1_GEMM, s);
+          EpiBiasAct<T> e1{bw.b1, hbuf, 4 * C, std::is_same<T, bf16_t>::value ? ACT_GELU_FAST : ACT_GELU};
+          CN_TRY(cn_mm(y, C, (const T*)bw.w1, C, (int)P, 4 * C, C, e1, s));
+        }
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_PW2_GEMM, s);
+          EpiResid e2{bw.b2, bw.scale, ws.x, ws.x, C};
+          CN_TRY(cn_mm(hbuf, 4 * C, (const T*)bw.w2, 4 * C, (int)P, C, 4 * C, e2, s));
+        }
       }
       if (taps && b == 0) CN_TRY(tap_copy(taps->stage_block0[st], ws.x, (size_t)P * C, s));
     }

@@ -1,0 +1,170 @@
+// Fused ConvNeXt MLP for the narrow stages (C = 96, 192), bf16:
+//
+//     x[m][:] += scale * ( W2 . gelu( W1 . y[m][:] + b1 ) + b2 )          (convnext.py:66-74)
+//
+// The reference (and the unfused path) materialises the (P x 4C) hidden in memory: at C = 96 that
+// is 8x the bytes of the block's input and makes pw1 / pw2 HBM-bound.  Here
+// a block owns BM = 32*TM positions and walks the hidden dimension in chunks of 32 units:
+//
+//   GEMM1  Hc[BM][32]  = y[BM][C] . W1c[32][C]^T      A operand of y kept in REGISTERS for all chunks
+//   epi1   Hc = gelu(Hc + b1c) -> bf16 -> LDS (swizzled [BM][32] tile, 64-byte rows)
+//   GEMM2  O[BM][C]   += Hc[BM][32] . W2c[C][32]^T    fp32 accumulators live across all chunks
+//
+// so the hidden never leaves the CU.  W1c / W2c chunks (C*128 bytes) stream L2 -> LDS with
+// global_load_lds_dwordx4 into a double buffer (chunk j+1 in flight during chunk j); the same
+// source-side XOR swizzle as gemm2.h keeps the ds_read_b128 fragment reads conflict-free.
+// 4 waves as 2 (rows) x 2 (hidden / channel halves); two barriers per chunk.
+#pragma once
+#include "gemm.h"
+
+template <int C, int TM>
+__global__ __launch_bounds__(256) void cn_mlp_fused_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ W1,
+                                                           const float* __restrict__ b1,
+                                                           const bf16_t* __restrict__ W2,
+                                                           const float* __restrict__ b2,
+                                                           const float* __restrict__ scale, float* __restrict__ X,
+                                                           int M) {
+  constexpr int BM = 32 * TM;           // rows per block (TM 16-row tiles per wave-row-half)
+  constexpr int KS1 = C / 32;           // k-steps of GEMM1
+  constexpr int TN2 = C / 32;           // 16-channel tiles per wave in GEMM2 (wave owns C/2 channels)
+  constexpr int NCH = 4 * C / 32;       // hidden chunks
+  constexpr int W1C_BYTES = 32 * C * 2; // [KS1][32 rows][64 B]
+  constexpr int W2C_BYTES = C * 64;     // [C rows][64 B]
+  constexpr int BUF = W1C_BYTES + W2C_BYTES;
+  constexpr int N_DMA = BUF / 1024;     // per chunk
+  constexpr int DPW = N_DMA / 4;
+  static_assert(N_DMA % 4 == 0, "DMA pieces must split evenly over 4 waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sH = smem + 2 * BUF;            // [BM][64 B]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = cn_xcd_remap(blockIdx.x, gridDim.x) * BM;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int sw = (lr >> 2) & 3;         // swizzle term of a 64-byte-row tile for row (16k + lr)
+
+  // ---- A operand (y rows) straight to registers: frag[b][ks] = y[m][32ks + 8lq .. +8] ----------
+  bf16x8 fa[TM][KS1];
+#pragma unroll
+  for (int b = 0; b < TM; ++b) {
+    const int m = min(m0 + wm * (BM / 2) + b * 16 + lr, M - 1);
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) fa[b][ks] = *(const bf16x8*)(Y + (size_t)m * C + ks * 32 + lq * 8);
+  }
+
+  // ---- per-lane DMA sources for chunk 0 ----------------------------------------------------------
+  const char* src[DPW];
+  int adv[DPW];
+#pragma unroll
+  for (int i = 0; i < DPW; ++i) {
+    const int inst = wave * DPW + i;
+    const int slot = lane & 3;
+    if (inst < W1C_BYTES / 1024) {            // W1 chunk: sub-tile ks = inst / 2, 16 rows per piece
+      const int ks = inst >> 1;
+      const int r = (inst & 1) * 16 + (lane >> 2);
+      const int chunk = slot ^ ((r >> 2) & 3);
+      src[i] = (const char*)(W1 + (size_t)r * C + ks * 32) + chunk * 16;
+      adv[i] = 32 * C * 2;                    // next 32 hidden rows
+    } else {                                  // W2 chunk: rows = output channels, 64 bytes of K each
+      const int r = (inst - W1C_BYTES / 1024) * 16 + (lane >> 2);
+      const int chunk = slot ^ ((r >> 2) & 3);
+      src[i] = (const char*)(W2 + (size_t)r * (4 * C)) + chunk * 16;
+      adv[i] = 64;                            // next 32 hidden columns
+    }
+  }
+  auto stage = [&](int buf, int j) {
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+      const int inst = wave * DPW + i;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)j * adv[i]),
+                                       (__attribute__((address_space(3))) void*)(smem + buf * BUF + inst * 1024), 16, 0,
+                                       0);
+    }
+  };
+
+  f32x4 acc2[TN2][TM];
+#pragma unroll
+  for (int a = 0; a < TN2; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  for (int j = 0; j < NCH; ++j) {
+    const int buf = j & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                     // chunk j landed; everyone is done with chunk j-1 (buffers + H)
+    if (j + 1 < NCH) stage(buf ^ 1, j + 1);
+    const char* sW1 = smem + buf * BUF;
+    const char* sW2 = sW1 + W1C_BYTES;
+
+    // GEMM1: this wave -> rows wm*(BM/2).. (TM tiles) x hidden wn*16..+16 of the chunk
+    f32x4 acc1[TM];
+#pragma unroll
+    for (int b = 0; b < TM; ++b) acc1[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+      const bf16x8 fw = *(const bf16x8*)(sW1 + ks * 2048 + (wn * 16 + lr) * 64 + ((lq ^ sw) * 16));
+#pragma unroll
+      for (int b = 0; b < TM; ++b) acc1[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, fa[b][ks], acc1[b], 0, 0, 0);
+    }
+    // epilogue 1: + b1, GELU, -> bf16 -> H tile; lane holds hidden 4lq..4lq+3 (of this wave's 16) of row lr
+    {
+      const f32x4 bb = *(const f32x4*)(b1 + j * 32 + wn * 16 + 4 * lq);
+      const int chunk = wn * 2 + (lq >> 1);
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const int ml = wm * (BM / 2) + b * 16 + lr;
+        bf16_t* dst = (bf16_t*)(sH + ml * 64 + ((chunk ^ sw) * 16) + (lq & 1) * 8);
+        cn_store4(dst, cn_gelu_fast(acc1[b][0] + bb[0]), cn_gelu_fast(acc1[b][1] + bb[1]),
+                  cn_gelu_fast(acc1[b][2] + bb[2]), cn_gelu_fast(acc1[b][3] + bb[3]));
+      }
+    }
+    __syncthreads();                     // H chunk complete
+    // GEMM2: rows wm*(BM/2).. (TM tiles) x channels wn*(C/2).. (TN2 tiles), K = 32
+    bf16x8 fh[TM];
+#pragma unroll
+    for (int b = 0; b < TM; ++b) fh[b] = *(const bf16x8*)(sH + (wm * (BM / 2) + b * 16 + lr) * 64 + ((lq ^ sw) * 16));
+#pragma unroll
+    for (int a = 0; a < TN2; ++a) {
+      const bf16x8 fw2 = *(const bf16x8*)(sW2 + (wn * (C / 2) + a * 16 + lr) * 64 + ((lq ^ sw) * 16));
+#pragma unroll
+      for (int b = 0; b < TM; ++b) acc2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2, fh[b], acc2[a][b], 0, 0, 0);
+    }
+  }
+
+  // ---- final epilogue: x += scale * (acc + b2), 16 bytes per lane (4 consecutive channels) ---------
+#pragma unroll
+  for (int a = 0; a < TN2; ++a) {
+    const int n = wn * (C / 2) + a * 16 + 4 * lq;
+    const f32x4 bb = *(const f32x4*)(b2 + n);
+    const f32x4 sc = *(const f32x4*)(scale + n);
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      const int m = m0 + wm * (BM / 2) + b * 16 + lr;
+      if (m < M) {
+        float* p = X + (size_t)m * C + n;
+        const f32x4 r = *(const f32x4*)p;
+        const f32x4 v = acc2[a][b];
+        *(f32x4*)p = f32x4{r[0] + sc[0] * (v[0] + bb[0]), r[1] + sc[1] * (v[1] + bb[1]), r[2] + sc[2] * (v[2] + bb[2]),
+                           r[3] + sc[3] * (v[3] + bb[3])};
+      }
+    }
+  }
+}
+
+template <int C, int TM>
+static int cn_launch_mlp_fused(const bf16_t* Y, const bf16_t* W1, const float* b1, const bf16_t* W2, const float* b2,
+                               const float* scale, float* X, int M, hipStream_t s) {
+  constexpr int SMEM = 2 * (32 * C * 2 + C * 64) + 32 * TM * 64;
+  static bool configured = false;
+  if (!configured) {
+    CN_HIP(hipFuncSetAttribute((const void*)cn_mlp_fused_kernel<C, TM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               SMEM));
+    configured = true;
+  }
+  hipLaunchKernelGGL((cn_mlp_fused_kernel<C, TM>), dim3((unsigned)cn_cdiv(M, 32 * TM)), dim3(256), SMEM, s, Y, W1, b1,
+                     W2, b2, scale, X, M);
+  CN_LAUNCH_CHECK();
+  return CN_OK;
+}
