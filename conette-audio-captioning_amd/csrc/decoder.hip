@@ -122,6 +122,29 @@ __device__ __forceinline__ float cn_dot8(f32x4 a, f32x4 b) {  // 32-dim head dot
   return d;
 }
 
+// Online-softmax update with a batch of NB scores / values (all loads were issued before the math,
+// so a row pays one memory latency per batch instead of one per key).
+template <int NB>
+__device__ __forceinline__ void cn_attn_update(const float (&sc)[NB], const f32x4 (&vv)[NB], float& m, float& l,
+                                               f32x4& acc) {
+  float mb = sc[0];
+#pragma unroll
+  for (int u = 1; u < NB; ++u) mb = fmaxf(mb, sc[u]);
+  const float mn = fmaxf(m, mb);
+  const float corr = __expf(m - mn);
+  l *= corr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] *= corr;
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    const float p = __expf(sc[u] - mn);  // masked entries carry -inf -> p = 0
+    l += p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = fmaf(p, vv[u][i], acc[i]);
+  }
+  m = mn;
+}
+
 // Causal self-attention of ONE new position per row over the cached prefix (8 heads x 32).
 // lane l owns dims 4l..4l+3 (head l>>3).  Writes this step's K/V into the cache.
 template <typename T>
@@ -129,6 +152,7 @@ __global__ __launch_bounds__(256) void cn_self_attn_kernel(const float* __restri
                                                            T* __restrict__ vc, const int* __restrict__ anc, int step,
                                                            int R, int beam, int maxp, float scale,
                                                            T* __restrict__ out) {
+  constexpr int NB = 8;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= R) return;
   const float* row = qkv + (size_t)r * 768 + 4 * lane;
@@ -143,25 +167,27 @@ __global__ __launch_bounds__(256) void cn_self_attn_kernel(const float* __restri
   const int rb = (r / beam) * beam;
   float m = -INFINITY, l = 0.f;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s <= step; ++s) {
-    f32x4 kk, vv;
-    if (s < step) {
-      const int src = rb + anc[(size_t)r * maxp + s];
-      kk = cn_load4<T>(kc + ((size_t)s * R + src) * 256 + 4 * lane);
-      vv = cn_load4<T>(vc + ((size_t)s * R + src) * 256 + 4 * lane);
-    } else {  // own entry, at cache precision
-      kk = f32x4{cn_to_f32(cn_from_f32<T>(kn[0])), cn_to_f32(cn_from_f32<T>(kn[1])), cn_to_f32(cn_from_f32<T>(kn[2])),
-                 cn_to_f32(cn_from_f32<T>(kn[3]))};
-      vv = f32x4{cn_to_f32(cn_from_f32<T>(vn[0])), cn_to_f32(cn_from_f32<T>(vn[1])), cn_to_f32(cn_from_f32<T>(vn[2])),
-                 cn_to_f32(cn_from_f32<T>(vn[3]))};
-    }
-    const float sc = cn_dot8(q, kk);
-    const float mn = fmaxf(m, sc);
-    const float corr = __expf(m - mn), p = __expf(sc - mn);
-    l = l * corr + p;
+  for (int s0 = 0; s0 < step; s0 += NB) {
+    f32x4 kk[NB], vv[NB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = acc[i] * corr + p * vv[i];
-    m = mn;
+    for (int u = 0; u < NB; ++u) {
+      const int s = min(s0 + u, step - 1);
+      const int src = rb + anc[(size_t)r * maxp + s];
+      kk[u] = cn_load4<T>(kc + ((size_t)s * R + src) * 256 + 4 * lane);
+      vv[u] = cn_load4<T>(vc + ((size_t)s * R + src) * 256 + 4 * lane);
+    }
+    float sc[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) sc[u] = (s0 + u < step) ? cn_dot8(q, kk[u]) : -INFINITY;
+    cn_attn_update<NB>(sc, vv, m, l, acc);
+  }
+  {  // own entry, at cache precision
+    const f32x4 kk = f32x4{cn_to_f32(cn_from_f32<T>(kn[0])), cn_to_f32(cn_from_f32<T>(kn[1])),
+                           cn_to_f32(cn_from_f32<T>(kn[2])), cn_to_f32(cn_from_f32<T>(kn[3]))};
+    const f32x4 v1[1] = {f32x4{cn_to_f32(cn_from_f32<T>(vn[0])), cn_to_f32(cn_from_f32<T>(vn[1])),
+                               cn_to_f32(cn_from_f32<T>(vn[2])), cn_to_f32(cn_from_f32<T>(vn[3]))}};
+    const float s1[1] = {cn_dot8(q, kk)};
+    cn_attn_update<1>(s1, v1, m, l, acc);
   }
   const float inv = 1.0f / l;
   cn_store4(out + (size_t)r * 256 + 4 * lane, acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
@@ -174,6 +200,7 @@ __global__ __launch_bounds__(256) void cn_cross_attn_kernel(const float* __restr
                                                             int kv_ld, int kv_off, const int* __restrict__ lens,
                                                             int R, int beam, int Ta, float scale,
                                                             T* __restrict__ out) {
+  constexpr int NB = 8;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= R) return;
   const int b = r / beam;
@@ -185,16 +212,18 @@ __global__ __launch_bounds__(256) void cn_cross_attn_kernel(const float* __restr
   const T* base = kv + (size_t)b * Ta * kv_ld + kv_off + 4 * lane;
   float m = -INFINITY, l = 0.f;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int t = 0; t < n; ++t) {
-    const f32x4 kk = cn_load4<T>(base + (size_t)t * kv_ld);
-    const f32x4 vv = cn_load4<T>(base + (size_t)t * kv_ld + 256);
-    const float sc = cn_dot8(qq, kk);
-    const float mn = fmaxf(m, sc);
-    const float corr = __expf(m - mn), p = __expf(sc - mn);
-    l = l * corr + p;
+  for (int t0 = 0; t0 < n; t0 += NB) {
+    f32x4 kk[NB], vv[NB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = acc[i] * corr + p * vv[i];
-    m = mn;
+    for (int u = 0; u < NB; ++u) {
+      const int t = min(t0 + u, n - 1);
+      kk[u] = cn_load4<T>(base + (size_t)t * kv_ld);
+      vv[u] = cn_load4<T>(base + (size_t)t * kv_ld + 256);
+    }
+    float sc[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) sc[u] = (t0 + u < n) ? cn_dot8(qq, kk[u]) : -INFINITY;
+    cn_attn_update<NB>(sc, vv, m, l, acc);
   }
   const float inv = 1.0f / l;
   cn_store4(out + (size_t)r * 256 + 4 * lane, acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);

@@ -209,10 +209,11 @@ static int launch_dwconv(const float* x, int B, int H, int W, const CnBlockW& bw
 // x fp32 (B,H,W,C) -> p T (B, H/2, W/2, (kh, kw, C)); rows/cols beyond 2*floor() are dropped.
 // One wave per input position.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void cn_ln_patchify_kernel(const float* __restrict__ x, int H, int W, int C,
-                                                             long n_pos, const float* __restrict__ ln_w,
+template <typename T, int C>
+__global__ __launch_bounds__(256) void cn_ln_patchify_kernel(const float* __restrict__ x, int H, int W, long n_pos,
+                                                             const float* __restrict__ ln_w,
                                                              const float* __restrict__ ln_b, T* __restrict__ p) {
+  constexpr int PER = (C + 63) / 64;
   const int lane = threadIdx.x & 63;
   const long pos = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pos >= n_pos) return;
@@ -223,28 +224,28 @@ __global__ __launch_bounds__(256) void cn_ln_patchify_kernel(const float* __rest
   const int b = (int)(t / H);
   if (h >= 2 * H2 || w >= 2 * W2) return;
   const float* xi = x + (size_t)pos * C;
-  float v[12];
+  float v[PER];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < 12; ++i) {
+  for (int i = 0; i < PER; ++i) {
     const int cc = lane + 64 * i;
-    v[i] = cc < C ? xi[cc] : 0.f;
+    v[i] = (C % 64 == 0 || cc < C) ? xi[cc] : 0.f;
     s += v[i];
   }
-  const float mean = cn_wave_sum(s) / (float)C;
+  const float mean = cn_wave_sum(s) * (1.0f / C);
   float s2 = 0.f;
 #pragma unroll
-  for (int i = 0; i < 12; ++i) {
+  for (int i = 0; i < PER; ++i) {
     const int cc = lane + 64 * i;
-    const float d = cc < C ? v[i] - mean : 0.f;
+    const float d = (C % 64 == 0 || cc < C) ? v[i] - mean : 0.f;
     s2 = fmaf(d, d, s2);
   }
-  const float rstd = 1.0f / sqrtf(cn_wave_sum(s2) / (float)C + 1e-6f);
+  const float rstd = 1.0f / sqrtf(cn_wave_sum(s2) * (1.0f / C) + 1e-6f);
   T* o = p + ((((size_t)b * H2 + (h >> 1)) * W2 + (w >> 1)) * 4 + ((h & 1) * 2 + (w & 1))) * C;
 #pragma unroll
-  for (int i = 0; i < 12; ++i) {
+  for (int i = 0; i < PER; ++i) {
     const int cc = lane + 64 * i;
-    if (cc < C) o[cc] = cn_from_f32<T>((v[i] - mean) * rstd * ln_w[cc] + ln_b[cc]);
+    if (C % 64 == 0 || cc < C) o[cc] = cn_from_f32<T>((v[i] - mean) * rstd * ln_w[cc] + ln_b[cc]);
   }
 }
 
@@ -405,8 +406,13 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
       const long n_in = (long)B * Hp * Wp;
       const CnDownW& dw = ctx->down[st - 1];
       CnProfScope ps(ctx, CONETTE_PROF_DOWNSAMPLE, s);
-      hipLaunchKernelGGL((cn_ln_patchify_kernel<T>), dim3((unsigned)((n_in + 3) / 4)), dim3(256), 0, s, ws.x, Hp, Wp,
-                         Cp, n_in, dw.ln_w, dw.ln_b, y);
+      const dim3 pg((unsigned)((n_in + 3) / 4));
+      if (Cp == 96)
+        hipLaunchKernelGGL((cn_ln_patchify_kernel<T, 96>), pg, dim3(256), 0, s, ws.x, Hp, Wp, n_in, dw.ln_w, dw.ln_b, y);
+      else if (Cp == 192)
+        hipLaunchKernelGGL((cn_ln_patchify_kernel<T, 192>), pg, dim3(256), 0, s, ws.x, Hp, Wp, n_in, dw.ln_w, dw.ln_b, y);
+      else
+        hipLaunchKernelGGL((cn_ln_patchify_kernel<T, 384>), pg, dim3(256), 0, s, ws.x, Hp, Wp, n_in, dw.ln_w, dw.ln_b, y);
       CN_LAUNCH_CHECK();
       EpiBiasAct<float> epi{dw.bias, ws.x, C, ACT_NONE};
       CN_TRY(cn_mm(y, 4 * Cp, (const T*)dw.w, 4 * Cp, (int)P, C, 4 * Cp, epi, s));

@@ -7,12 +7,16 @@
 //    a wave-instruction writes 1 KiB linearly, so the bank-conflict swizzle is applied to the
 //    per-lane SOURCE address and mirrored on the ds_read_b128 address (cdna guide rule 21):
 //        16-byte chunk c of row r lives at slot  c ^ ((r / rows_per_256B) & (chunks_per_row-1))
-//  * BK = 64 (32 only when K % 64 != 0, i.e. the K = 96 pointwise conv of stage 0);
+//  * BK = 64 (32 only when K % 64 != 0, i.e. the K = 96 pointwise conv of stage 0); the skinny
+//    decoder GEMMs (M = B*beam rows, K = 256 per slice) use BK = 256: the whole K extent is one
+//    stage, so a block pays ONE memory latency instead of one per k-tile;
 //  * the DMA of k-tile t+1 is issued before the fragments of tile t are read, one
 //    vmcnt(0) + barrier per k-tile;
 //  * optional split-K over blockIdx.y: the epilogue receives the slice index (partial slabs,
 //    summed in a fixed order by the consumer -> deterministic, no atomics).
 #pragma once
+#include <stdlib.h>
+
 #include "gemm.h"
 
 // out[ks][m][n] = acc  (partial sums of one K slice; bias / residual are added by the consumer)
@@ -50,8 +54,9 @@ __global__ __launch_bounds__(256) void cn_gemm2_kernel(const bf16_t* __restrict_
                                                        int k_slice, Epi epi) {
   constexpr int RBY = BK * 2;          // bytes per tile row
   constexpr int CPR = RBY / 16;        // 16-byte chunks per row (4 or 8)
-  constexpr int RPB = 256 / RBY;       // tile rows per 256-byte LDS bank row (4 or 2)
-  constexpr int RPI = 1024 / RBY;      // tile rows written by one DMA wave-instruction (16 or 8)
+  constexpr int RPB = RBY >= 256 ? 1 : 256 / RBY;  // tile rows per 256-byte LDS bank row (4, 2 or 1)
+  constexpr int SWM = CPR > 16 ? 15 : CPR - 1;       // swizzle mask: XOR the chunk index with (row / RPB) & SWM
+  constexpr int RPI = 1024 / RBY;      // tile rows written by one DMA wave-instruction (16, 8 or 2)
   constexpr int A_BYTES = BM * RBY, W_BYTES = BN * RBY, BUF = A_BYTES + W_BYTES;
   constexpr int N_DMA = BUF / 1024;
   static_assert(BUF % 1024 == 0 && A_BYTES % 1024 == 0, "tile must be a whole number of 1 KiB DMA pieces");
@@ -80,11 +85,11 @@ __global__ __launch_bounds__(256) void cn_gemm2_kernel(const bf16_t* __restrict_
     const int slot = lane % CPR;
     if (inst < N_DMA) {
       if (row < BM) {
-        const int chunk = slot ^ ((row / RPB) & (CPR - 1));
+        const int chunk = slot ^ ((row / RPB) & SWM);
         src[i] = (const char*)(A + (size_t)min(m0 + row, M - 1) * lda + k_begin) + chunk * 16;
       } else {
         const int r = row - BM;
-        const int chunk = slot ^ ((r / RPB) & (CPR - 1));
+        const int chunk = slot ^ ((r / RPB) & SWM);
         src[i] = (const char*)(W + (size_t)min(n0 + r, N - 1) * ldw + k_begin) + chunk * 16;
       }
     } else {
@@ -109,15 +114,16 @@ __global__ __launch_bounds__(256) void cn_gemm2_kernel(const bf16_t* __restrict_
     for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int lr = lane & 15;
-  const int sw = (lr / RPB) & (CPR - 1);
+  const int sw = (lr / RPB) & SWM;
   const int row_off = lr * RBY;
 
+  constexpr int NBUF = BK >= 256 ? 1 : 2;
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int buf = 0;
   for (int kt = 0; kt < KT; ++kt) {
-    if (kt + 1 < KT) stage(buf ^ 1, kt + 1);
+    if (NBUF == 2 && kt + 1 < KT) stage(buf ^ 1, kt + 1);
     const char* sA = smem + buf * BUF;
     const char* sW = sA + A_BYTES;
 #pragma unroll
@@ -133,9 +139,13 @@ __global__ __launch_bounds__(256) void cn_gemm2_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[a], fa[b], acc[a][b], 0, 0, 0);
     }
+    if (NBUF == 1 && kt + 1 < KT) {  // single stage: refill only after every wave has read it
+      __syncthreads();
+      stage(0, kt + 1);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    buf ^= 1;
+    if (NBUF == 2) buf ^= 1;
   }
 
   // ---- staged epilogue: registers -> LDS tile [BM][BN] (output type) -> whole-row 16-byte stores.
@@ -182,7 +192,7 @@ template <int BM, int BN, int BK, class Epi>
 static int cn_launch_gemm2_t(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, int splits,
                              const Epi& epi, hipStream_t stream) {
   constexpr int EPI_BYTES = sizeof(typename Epi::stage_t) == 4 ? 0 : BM * (BN * 2 + 16);
-  constexpr int PIPE_BYTES = 2 * (BM + BN) * BK * 2;
+  constexpr int PIPE_BYTES = (BK >= 256 ? 1 : 2) * (BM + BN) * BK * 2;  // BK = 256: single stage per slice
   constexpr int SMEM = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
   static bool configured = false;
   if (!configured) {
@@ -209,11 +219,12 @@ static int cn_gemm2(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, i
   const bool k64 = (K % 64 == 0);
   if (M >= 4096) {
     const bool n96 = (N % 96 == 0) && (N % 128 != 0);
-    if (!k64) return cn_launch_gemm2_t<128, 128, 32, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+    if (!k64 || getenv("CN_GEMM_BK32")) return cn_launch_gemm2_t<128, 128, 32, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
     if (n96) return cn_launch_gemm2_t<128, 96, 64, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
     return cn_launch_gemm2_t<128, 128, 64, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
   }
   if (!k64) return cn_launch_gemm2_t<64, 64, 32, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+  if ((K / splits) % 256 == 0) return cn_launch_gemm2_t<64, 64, 256, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
   return cn_launch_gemm2_t<64, 64, 64, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
 }
 
