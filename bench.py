@@ -88,6 +88,8 @@ def main() -> None:
     sd_np = synth.synth_state_dict()
     sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()}
     eng = Engine(sd, precision=args.precision, device=dev)
+    if os.environ.get("CN_NO_GRAPH"):
+        eng.set_decode_graph(False)
     wave = torch.from_numpy(synth.synth_waveforms(B, L, 1234 + rank * B)).to(dev)
     t_audio = eng.lib.conette_num_audio_frames(L)
     lens = torch.full((B,), t_audio, dtype=torch.int32, device=dev)
@@ -95,7 +97,12 @@ def main() -> None:
     forbid = sd["model.forbid_rep_mask"].to(dev)
     # Two pipeline slots and two HIP streams: the decode of batch i (small latency-bound launches,
     # replayed from a hipGraph) overlaps the encode of batch i+1 (big MFMA / VALU kernels).
-    s_enc, s_dec = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    share = int(os.environ.get("CN_DEC_SHARE", "8"))
+    if share > 0:   # CU-partitioned streams: decode owns 1/share of the CUs, encode the rest
+        from conette_amd.engine import make_partitioned_streams
+        s_enc, s_dec = make_partitioned_streams(dev, decode_share=share)
+    else:
+        s_enc, s_dec = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     fe_buf = [eng.decode_input_buffer(B, t_audio, beam, max_pred, slot=i) for i in range(2)]
     clip_buf = [torch.empty((B, 527), dtype=torch.float32, device=dev) for _ in range(2)]
     enc_done = [torch.cuda.Event() for _ in range(2)]

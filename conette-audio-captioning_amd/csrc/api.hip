@@ -413,6 +413,22 @@ extern "C" void conette_destroy(conette_ctx* ctx) {
   delete ctx;
 }
 
+// ---- CU-partitioned streams ------------------------------------------------------------------------
+extern "C" int conette_stream_create_masked(const uint32_t* mask_words, int32_t n_words, void** out_stream) {
+  if (!mask_words || n_words <= 0 || !out_stream) {
+    cn_set_error("stream_create_masked: bad argument");
+    return CN_ERR_ARG;
+  }
+  hipStream_t st = nullptr;
+  CN_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, mask_words));
+  *out_stream = (void*)st;
+  return CN_OK;
+}
+extern "C" int conette_stream_destroy(void* stream) {
+  if (stream) CN_HIP(hipStreamDestroy((hipStream_t)stream));
+  return CN_OK;
+}
+
 // ---- resampler (row a1): torchaudio.functional.resample, sinc_interpolation, width 6, rolloff 0.99
 static int gcd_i(int a, int b) { return b == 0 ? a : gcd_i(b, a % b); }
 

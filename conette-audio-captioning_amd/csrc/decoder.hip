@@ -11,6 +11,8 @@
 //   * EOS floor, forbid-repeat mask, log-softmax, running sums, per-clip top-k and the
 //     finished / shrinking-k bookkeeping run in one kernel per step with no host sync.
 #include "ctx.h"
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "gemm2.h"
@@ -18,6 +20,10 @@
 #define CN_MAX_BEAM 8
 #define CN_MAX_PRED 64
 #define FF2_SPLITS 8
+static int ff2_splits_env() {
+  const char* e = getenv("CN_FF2_SPLITS");
+  return e ? atoi(e) : 4;
+}
 
 // ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -380,6 +386,164 @@ __global__ __launch_bounds__(256) void cn_search_step_kernel(float* __restrict__
   }
 }
 
+// Same step, fast path: the clip's (masked) logit rows live in LDS for all passes, every thread keeps
+// a sorted top-k of its strided candidates in registers (one scan), and k rounds of block arg-max over
+// the thread heads merge them.  Ties resolve to the lowest flat index exactly like the kernel above.
+__global__ __launch_bounds__(256) void cn_search_step2_kernel(const float* __restrict__ logits, int ldv, int V,
+                                                              int beam, int maxp, int step, int min_pred, int eos_id,
+                                                              const uint8_t* __restrict__ forbid, int* n_active,
+                                                              int* slot, float* sum_lp, int* prefix, int* anc,
+                                                              int* cur_tok, int* out_preds, float* out_avg,
+                                                              int* out_len, int* trace_sel, float* trace_val) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  float* s_lgt = (float*)smem_dyn;  // [nrows][V]
+  __shared__ float s_red[8];
+  __shared__ ValIdx s_vi[4];
+  __shared__ float s_mx[CN_MAX_BEAM], s_lg[CN_MAX_BEAM], s_base[CN_MAX_BEAM];
+  __shared__ float s_selv[CN_MAX_BEAM];
+  __shared__ int s_self[CN_MAX_BEAM];
+  __shared__ int s_prefix[CN_MAX_BEAM][CN_MAX_PRED + 1];
+  __shared__ int s_anc[CN_MAX_BEAM][CN_MAX_PRED];
+  __shared__ int s_slot[CN_MAX_BEAM];
+  __shared__ int s_newpos[CN_MAX_BEAM];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int k = n_active[b];
+  if (k == 0) return;
+  const int rb = b * beam;
+  const int nrows = step == 0 ? 1 : k;
+
+  for (int i = tid; i < k * (maxp + 1); i += 256) s_prefix[i / (maxp + 1)][i % (maxp + 1)] = prefix[(size_t)rb * (maxp + 1) + i];
+  for (int i = tid; i < k * maxp; i += 256) s_anc[i / maxp][i % maxp] = anc[(size_t)rb * maxp + i];
+  if (tid < k) {
+    s_slot[tid] = slot[rb + tid];
+    s_base[tid] = step == 0 ? 0.f : sum_lp[rb + tid];
+  }
+  for (int p = 0; p < nrows; ++p) {
+    const float* lg = logits + (size_t)(rb + p) * ldv;
+    for (int v = tid; v < V; v += 256) s_lgt[p * V + v] = lg[v];
+  }
+  __syncthreads();
+  // EOS floor (beam.py:129-130) + forbid-repeat (beam.py:146-156) on the LDS copy
+  for (int i = tid; i < nrows * (step + 2); i += 256) {
+    const int p = i / (step + 2), j = i % (step + 2);
+    if (j == step + 1) {
+      if (step < min_pred) s_lgt[p * V + eos_id] = -INFINITY;
+    } else if (forbid != nullptr) {
+      const int tok = s_prefix[p][j];
+      if (forbid[tok]) s_lgt[p * V + tok] = -INFINITY;
+    }
+  }
+  __syncthreads();
+  for (int p = 0; p < nrows; ++p) {
+    const float* lg = s_lgt + p * V;
+    float mx = -INFINITY;
+    for (int v = tid; v < V; v += 256) mx = fmaxf(mx, lg[v]);
+    mx = cn_wave_max(mx);
+    if (lane == 0) s_red[wv] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    float sm = 0.f;
+    for (int v = tid; v < V; v += 256) sm += expf(lg[v] - mx);
+    sm = cn_wave_sum(sm);
+    if (lane == 0) s_red[4 + wv] = sm;
+    __syncthreads();
+    if (tid == 0) {
+      s_mx[p] = mx;
+      s_lg[p] = logf(s_red[4] + s_red[5] + s_red[6] + s_red[7]);
+    }
+    __syncthreads();
+  }
+  // per-thread sorted top-k (strict > keeps the earlier = lower flat index first on ties)
+  float bv[CN_MAX_BEAM];
+  int bi[CN_MAX_BEAM];
+#pragma unroll
+  for (int j = 0; j < CN_MAX_BEAM; ++j) {
+    bv[j] = -INFINITY;
+    bi[j] = 0x7fffffff;
+  }
+  for (int p = 0; p < nrows; ++p) {
+    const float* lg = s_lgt + p * V;
+    const float mx = s_mx[p], lgs = s_lg[p], base = s_base[p];
+    for (int v = tid; v < V; v += 256) {
+      float cand = (lg[v] - mx) - lgs;
+      if (step != 0) cand = base + cand;
+      if (cand > bv[CN_MAX_BEAM - 1]) {
+        bv[CN_MAX_BEAM - 1] = cand;
+        bi[CN_MAX_BEAM - 1] = p * V + v;
+#pragma unroll
+        for (int j = CN_MAX_BEAM - 1; j > 0; --j) {
+          if (bv[j] > bv[j - 1]) {
+            const float tv = bv[j];
+            bv[j] = bv[j - 1];
+            bv[j - 1] = tv;
+            const int ti = bi[j];
+            bi[j] = bi[j - 1];
+            bi[j - 1] = ti;
+          }
+        }
+      }
+    }
+  }
+  int head = 0;
+  for (int c = 0; c < k; ++c) {
+    ValIdx mine{-INFINITY, 0x7fffffff};
+#pragma unroll
+    for (int j = 0; j < CN_MAX_BEAM; ++j)
+      if (head == j) mine = ValIdx{bv[j], bi[j]};
+    ValIdx best = vi_wave(mine);
+    if (lane == 0) s_vi[wv] = best;
+    __syncthreads();
+    const ValIdx win = vi_better(vi_better(s_vi[0], s_vi[1]), vi_better(s_vi[2], s_vi[3]));
+    if (mine.i == win.i && mine.i != 0x7fffffff) ++head;
+    if (tid == 0) {
+      s_selv[c] = win.v;
+      s_self[c] = win.i;
+    }
+    __syncthreads();
+  }
+  // bookkeeping (beam.py:164-203)
+  if (tid < k) {
+    const size_t ti = ((size_t)step * gridDim.x + b) * beam + tid;
+    if (trace_sel) {
+      trace_sel[2 * ti] = s_self[tid] / V;
+      trace_sel[2 * ti + 1] = s_self[tid] % V;
+    }
+    if (trace_val) trace_val[ti] = s_selv[tid];
+  }
+  if (tid == 0) {
+    int cnt = 0;
+    for (int c = 0; c < k; ++c) {
+      const int token = s_self[c] % V;
+      const bool fin = (token == eos_id) || (step == maxp - 1);
+      s_newpos[c] = fin ? -1 : cnt++;
+    }
+    n_active[b] = cnt;
+  }
+  __syncthreads();
+  for (int c = 0; c < k; ++c) {
+    const int flat = s_self[c];
+    const int parent = flat / V, token = flat % V;
+    const int np = s_newpos[c];
+    if (np < 0) {
+      const int sl = rb + s_slot[c];
+      for (int j = tid; j <= step; j += 256) out_preds[(size_t)sl * maxp + j] = (j == step) ? token : s_prefix[parent][j + 1];
+      if (tid == 0) {
+        out_avg[sl] = s_selv[c] / (float)(step + 1);
+        out_len[sl] = step + 1;
+      }
+    } else {
+      const int dst = rb + np;
+      for (int j = tid; j <= step + 1; j += 256) prefix[(size_t)dst * (maxp + 1) + j] = (j == step + 1) ? token : s_prefix[parent][j];
+      for (int j = tid; j <= step; j += 256) anc[(size_t)dst * maxp + j] = (j == step) ? parent : s_anc[parent][j];
+      if (tid == 0) {
+        sum_lp[dst] = s_selv[c];
+        slot[dst] = s_slot[c];
+        cur_tok[dst] = token;
+      }
+    }
+  }
+}
+
 // best beam per clip (beam.py:205-220): first max of the averaged log-prob; pred_size via atomicMax
 __global__ void cn_finalize_kernel(int B, int beam, int maxp, int eos_id, const int* __restrict__ out_preds,
                                    const float* __restrict__ out_avg, const int* __restrict__ out_len,
@@ -427,7 +591,7 @@ __global__ void cn_finalize2_kernel(int B, const int* __restrict__ eos_idx, int*
 // ---------------------------------------------------------------------------------------------
 struct DecWs {
   void *fe_t, *mem, *kvc, *xt, *attn_t, *ffh, *kc, *vc;
-  float *x, *qkv, *q, *tmp, *logits, *slabs;
+  float *x, *x2, *qkv, *q, *tmp, *logits, *slabs;
   int *n_active, *slot, *prefix, *anc, *cur_tok, *out_len, *eos_idx;
   float* sum_lp;
   int ldv;
@@ -449,6 +613,7 @@ static DecWs dec_ws(const conette_ctx* ctx, int B, int Ta, int beam, int maxp, c
   w.mem = take((size_t)B * Ta * d * es);
   w.kvc = take((size_t)B * Ta * NL * 2 * d * es);
   w.x = (float*)take((size_t)R * d * 4);
+  w.x2 = (float*)take((size_t)R * d * 4);
   w.xt = take((size_t)R * d * es);
   w.qkv = (float*)take((size_t)R * 3 * d * 4);
   w.q = (float*)take((size_t)R * d * 4);
@@ -515,95 +680,190 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
     hipLaunchKernelGGL((cn_embed_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.cur_tok, ctx->emb, ctx->pe, step, R,
                        sqrtf((float)d), w.x, xt);
     CN_LAUNCH_CHECK();
-    for (int l = 0; l < NL; ++l) {
-      const CnLayerW& lw = ctx->layers[l];
-      T* kc = (T*)w.kc + (size_t)l * maxp * R * d;
-      T* vc = (T*)w.vc + (size_t)l * maxp * R * d;
-      {
-        CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-        EpiBiasAct<float> eq{lw.sa_in_b, w.qkv, 3 * d, ACT_NONE};
-        CN_TRY(cn_mm(xt, d, (const T*)lw.sa_in_w, d, R, 3 * d, d, eq, s));
-      }
-      {
-        CnProfScope ps(ctx, CONETTE_PROF_DEC_ATTN, s);
-        hipLaunchKernelGGL((cn_self_attn_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.qkv, kc, vc, w.anc, step, R,
-                           beam, maxp, scale, attn_t);
-        CN_LAUNCH_CHECK();
-      }
-      {
-        CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-        EpiResid eo{lw.sa_out_b, nullptr, w.x, w.tmp, d};
-        CN_TRY(cn_mm(attn_t, d, (const T*)lw.sa_out_w, d, R, d, d, eo, s));
-      }
-      {
-        CnProfScope ps(ctx, CONETTE_PROF_DEC_MISC, s);
-        hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, 1, (size_t)0, (const float*)nullptr,
-                           (const float*)nullptr, lw.n1w, lw.n1b, R, w.x, xt);
-        CN_LAUNCH_CHECK();
-      }
-      {
-        CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-        EpiBiasAct<float> ecq{lw.ca_q_b, w.q, d, ACT_NONE};
-        CN_TRY(cn_mm(xt, d, (const T*)lw.ca_q_w, d, R, d, d, ecq, s));
-      }
-      {
-        CnProfScope ps(ctx, CONETTE_PROF_DEC_ATTN, s);
-        hipLaunchKernelGGL((cn_cross_attn_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.q, kvc, kv_ld, l * 2 * d,
-                           frame_lens, R, beam, Ta, scale, attn_t);
-        CN_LAUNCH_CHECK();
-      }
-      {
-        CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-        EpiResid eco{lw.ca_out_b, nullptr, w.x, w.tmp, d};
-        CN_TRY(cn_mm(attn_t, d, (const T*)lw.ca_out_w, d, R, d, d, eco, s));
-      }
-      {
-        CnProfScope ps(ctx, CONETTE_PROF_DEC_MISC, s);
-        hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, 1, (size_t)0, (const float*)nullptr,
-                           (const float*)nullptr, lw.n2w, lw.n2b, R, w.x, xt);
-        CN_LAUNCH_CHECK();
-      }
-      {
-        CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-        EpiBiasAct<T> e1{lw.ff1_b, ffh, dff, std::is_same<T, bf16_t>::value ? ACT_GELU_FAST : ACT_GELU};
-        CN_TRY(cn_mm(xt, d, (const T*)lw.ff1_w, d, R, dff, d, e1, s));
-      }
-      if constexpr (std::is_same<T, bf16_t>::value) {
-        // K = d_ff is long and M = R is small: split K over blockIdx.y into partial slabs, summed
-        // (fixed order, with bias + residual) by the LayerNorm kernel that follows
-        const int splits = (dff % (FF2_SPLITS * 64) == 0) ? FF2_SPLITS : 1;
+    // LN-prologue GEMMs (cn_gemm2_ln256) measured SLOWER than LN kernel + plain GEMM (decode 9.1 vs 8.2 ms at
+    // R = 192: the prologue serialises load -> reduce -> LDS write in front of the MFMAs); kept as an option.
+    static const int dec_fused = getenv("CN_DEC_FUSED") ? atoi(getenv("CN_DEC_FUSED")) : 0;
+    bool fused_done = false;
+    if constexpr (std::is_same<T, bf16_t>::value) if (dec_fused) {
+      fused_done = true;
+      // bf16 path: every LayerNorm is the prologue of the GEMM that consumes it (cn_gemm2_ln256), the
+      // fp32 stream ping-pongs between two buffers (the prologue reads the old one as residual while
+      // the n-tile-0 blocks write the new one), FFN2 is split-K into slabs summed by the next prologue.
+      float* xc = w.x;   // current residual stream
+      float* xn = w.x2;  // next
+      int splits = ff2_splits_env();
+      if (splits < 1 || splits > FF2_SPLITS || dff % (splits * 256) != 0) splits = 1;
+      const size_t slab = (size_t)R * d;
+      for (int l = 0; l < NL; ++l) {
+        const CnLayerW& lw = ctx->layers[l];
+        bf16_t* kc = (bf16_t*)w.kc + (size_t)l * maxp * R * d;
+        bf16_t* vc = (bf16_t*)w.vc + (size_t)l * maxp * R * d;
         {
           CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-          EpiSlab e2{w.slabs, d, (size_t)R * d};
+          EpiBiasAct<float> eq{lw.sa_in_b, w.qkv, 3 * d, ACT_NONE};
+          if (l == 0) {
+            CN_TRY(cn_gemm2(xt, d, (const bf16_t*)lw.sa_in_w, d, R, 3 * d, d, eq, s));
+          } else {  // x = LN3_{l-1}(x + FFN2 slabs + b2) fused in
+            const CnLayerW& pw = ctx->layers[l - 1];
+            CN_TRY(cn_gemm2_ln256(w.slabs, splits, slab, pw.ff2_b, xc, pw.n3w, pw.n3b, xn,
+                                  (const bf16_t*)lw.sa_in_w, d, R, 3 * d, eq, s));
+            float* t = xc; xc = xn; xn = t;
+          }
+        }
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_ATTN, s);
+          hipLaunchKernelGGL((cn_self_attn_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.qkv, kc, vc, w.anc, step, R,
+                             beam, maxp, scale, attn_t);
+          CN_LAUNCH_CHECK();
+        }
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+          EpiResid eo{lw.sa_out_b, nullptr, xc, w.tmp, d};
+          CN_TRY(cn_gemm2(attn_t, d, (const bf16_t*)lw.sa_out_w, d, R, d, d, eo, s));
+        }
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);  // x = LN1(tmp); q = x Wq + b
+          EpiBiasAct<float> ecq{lw.ca_q_b, w.q, d, ACT_NONE};
+          CN_TRY(cn_gemm2_ln256(w.tmp, 1, 0, nullptr, nullptr, lw.n1w, lw.n1b, xn, (const bf16_t*)lw.ca_q_w, d, R, d,
+                                ecq, s));
+          float* t = xc; xc = xn; xn = t;
+        }
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_ATTN, s);
+          hipLaunchKernelGGL((cn_cross_attn_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.q, kvc, kv_ld, l * 2 * d,
+                             frame_lens, R, beam, Ta, scale, attn_t);
+          CN_LAUNCH_CHECK();
+        }
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+          EpiResid eco{lw.ca_out_b, nullptr, xc, w.tmp, d};
+          CN_TRY(cn_gemm2(attn_t, d, (const bf16_t*)lw.ca_out_w, d, R, d, d, eco, s));
+        }
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);  // x = LN2(tmp); h = gelu(x W1 + b1)
+          EpiBiasAct<bf16_t> e1{lw.ff1_b, ffh, dff, ACT_GELU_FAST};
+          CN_TRY(cn_gemm2_ln256(w.tmp, 1, 0, nullptr, nullptr, lw.n2w, lw.n2b, xn, (const bf16_t*)lw.ff1_w, d, R, dff,
+                                e1, s));
+          float* t = xc; xc = xn; xn = t;
+        }
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);  // FFN2 partial slabs (bias / residual / LN3 in the consumer)
+          EpiSlab e2{w.slabs, d, slab};
           CN_TRY(cn_gemm2(ffh, dff, (const bf16_t*)lw.ff2_w, dff, R, d, dff, e2, s, splits));
         }
-        CnProfScope ps(ctx, CONETTE_PROF_DEC_MISC, s);
-        hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.slabs, splits, (size_t)R * d,
-                           lw.ff2_b, w.x, lw.n3w, lw.n3b, R, w.x, xt);
-        CN_LAUNCH_CHECK();
-      } else {
-        {
-          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-          EpiResid e2{lw.ff2_b, nullptr, w.x, w.tmp, d};
-          CN_TRY(cn_mm(ffh, dff, (const T*)lw.ff2_w, dff, R, d, dff, e2, s));
-        }
-        CnProfScope ps(ctx, CONETTE_PROF_DEC_MISC, s);
-        hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, 1, (size_t)0,
-                           (const float*)nullptr, (const float*)nullptr, lw.n3w, lw.n3b, R, w.x, xt);
-        CN_LAUNCH_CHECK();
+      }
+      {
+        CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);  // x = LN3_last(...); logits = x Wc + bc
+        const CnLayerW& pw = ctx->layers[NL - 1];
+        EpiBiasAct<float> ec{ctx->cls_b, w.logits, w.ldv, ACT_NONE};
+        CN_TRY(cn_gemm2_ln256(w.slabs, splits, slab, pw.ff2_b, xc, pw.n3w, pw.n3b, xn, (const bf16_t*)ctx->cls_w, d, R,
+                              V, ec, s));
       }
     }
-    {
-      CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-      EpiBiasAct<float> ec{ctx->cls_b, w.logits, w.ldv, ACT_NONE};
-      CN_TRY(cn_mm(xt, d, (const T*)ctx->cls_w, d, R, V, d, ec, s));
+    if (!fused_done) {
+      for (int l = 0; l < NL; ++l) {
+        const CnLayerW& lw = ctx->layers[l];
+        T* kc = (T*)w.kc + (size_t)l * maxp * R * d;
+        T* vc = (T*)w.vc + (size_t)l * maxp * R * d;
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+          EpiBiasAct<float> eq{lw.sa_in_b, w.qkv, 3 * d, ACT_NONE};
+          CN_TRY(cn_mm(xt, d, (const T*)lw.sa_in_w, d, R, 3 * d, d, eq, s));
+        }
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_ATTN, s);
+          hipLaunchKernelGGL((cn_self_attn_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.qkv, kc, vc, w.anc, step, R,
+                             beam, maxp, scale, attn_t);
+          CN_LAUNCH_CHECK();
+        }
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+          EpiResid eo{lw.sa_out_b, nullptr, w.x, w.tmp, d};
+          CN_TRY(cn_mm(attn_t, d, (const T*)lw.sa_out_w, d, R, d, d, eo, s));
+        }
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_MISC, s);
+          hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, 1, (size_t)0, (const float*)nullptr,
+                             (const float*)nullptr, lw.n1w, lw.n1b, R, w.x, xt);
+          CN_LAUNCH_CHECK();
+        }
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+          EpiBiasAct<float> ecq{lw.ca_q_b, w.q, d, ACT_NONE};
+          CN_TRY(cn_mm(xt, d, (const T*)lw.ca_q_w, d, R, d, d, ecq, s));
+        }
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_ATTN, s);
+          hipLaunchKernelGGL((cn_cross_attn_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.q, kvc, kv_ld, l * 2 * d,
+                             frame_lens, R, beam, Ta, scale, attn_t);
+          CN_LAUNCH_CHECK();
+        }
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+          EpiResid eco{lw.ca_out_b, nullptr, w.x, w.tmp, d};
+          CN_TRY(cn_mm(attn_t, d, (const T*)lw.ca_out_w, d, R, d, d, eco, s));
+        }
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_MISC, s);
+          hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, 1, (size_t)0, (const float*)nullptr,
+                             (const float*)nullptr, lw.n2w, lw.n2b, R, w.x, xt);
+          CN_LAUNCH_CHECK();
+        }
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+          EpiBiasAct<T> e1{lw.ff1_b, ffh, dff, std::is_same<T, bf16_t>::value ? ACT_GELU_FAST : ACT_GELU};
+          CN_TRY(cn_mm(xt, d, (const T*)lw.ff1_w, d, R, dff, d, e1, s));
+        }
+        if constexpr (std::is_same<T, bf16_t>::value) {
+          // K = d_ff is long and M = R is small: split K over blockIdx.y into partial slabs, summed
+          // (fixed order, with bias + residual) by the LayerNorm kernel that follows
+          const int splits = (dff % (FF2_SPLITS * 64) == 0) ? FF2_SPLITS : 1;
+          {
+            CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+            EpiSlab e2{w.slabs, d, (size_t)R * d};
+            CN_TRY(cn_gemm2(ffh, dff, (const bf16_t*)lw.ff2_w, dff, R, d, dff, e2, s, splits));
+          }
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_MISC, s);
+          hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.slabs, splits, (size_t)R * d,
+                             lw.ff2_b, w.x, lw.n3w, lw.n3b, R, w.x, xt);
+          CN_LAUNCH_CHECK();
+        } else {
+          {
+            CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+            EpiResid e2{lw.ff2_b, nullptr, w.x, w.tmp, d};
+            CN_TRY(cn_mm(ffh, dff, (const T*)lw.ff2_w, dff, R, d, dff, e2, s));
+          }
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_MISC, s);
+          hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, 1, (size_t)0,
+                             (const float*)nullptr, (const float*)nullptr, lw.n3w, lw.n3b, R, w.x, xt);
+          CN_LAUNCH_CHECK();
+        }
+      }
+      {
+        CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+        EpiBiasAct<float> ec{ctx->cls_b, w.logits, w.ldv, ACT_NONE};
+        CN_TRY(cn_mm(xt, d, (const T*)ctx->cls_w, d, R, V, d, ec, s));
+      }
     }
     if (step == 0 && step0_logits)
       CN_HIP(hipMemcpyAsync(step0_logits, w.logits, (size_t)R * w.ldv * 4, hipMemcpyDeviceToDevice, s));
     CnProfScope ps_search(ctx, CONETTE_PROF_SEARCH, s);
-    hipLaunchKernelGGL(cn_search_step_kernel, dim3(B), dim3(256), 0, s, w.logits, w.ldv, V, beam, maxp, step, min_pred,
-                       cfg.eos_id, forbid, w.n_active, w.slot, w.sum_lp, w.prefix, w.anc, w.cur_tok, mult_preds,
-                       mult_lprobs, w.out_len, trace_sel, trace_val);
+    const size_t search_smem = (size_t)beam * V * sizeof(float);
+    if (search_smem <= 120 * 1024) {
+      static bool configured = false;
+      if (!configured) {
+        CN_HIP(hipFuncSetAttribute((const void*)cn_search_step2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   120 * 1024));
+        configured = true;
+      }
+      hipLaunchKernelGGL(cn_search_step2_kernel, dim3(B), dim3(256), search_smem, s, w.logits, w.ldv, V, beam, maxp,
+                         step, min_pred, cfg.eos_id, forbid, w.n_active, w.slot, w.sum_lp, w.prefix, w.anc, w.cur_tok,
+                         mult_preds, mult_lprobs, w.out_len, trace_sel, trace_val);
+    } else {
+      hipLaunchKernelGGL(cn_search_step_kernel, dim3(B), dim3(256), 0, s, w.logits, w.ldv, V, beam, maxp, step,
+                         min_pred, cfg.eos_id, forbid, w.n_active, w.slot, w.sum_lp, w.prefix, w.anc, w.cur_tok,
+                         mult_preds, mult_lprobs, w.out_len, trace_sel, trace_val);
+    }
     CN_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(cn_finalize_kernel, dim3(cn_cdiv(B, 64)), dim3(64), 0, s, B, beam, maxp, cfg.eos_id, mult_preds,

@@ -48,21 +48,94 @@ struct EpiSlab {
   }
 };
 
-template <int BM, int BN, int BK, class Epi>
+// ---- shared pieces ------------------------------------------------------------------------------
+template <int BK> struct G2Geom {
+  static constexpr int RBY = BK * 2;                       // bytes per tile row
+  static constexpr int CPR = RBY / 16;                     // 16-byte chunks per row (4, 8 or 32)
+  static constexpr int RPB = RBY >= 256 ? 1 : 256 / RBY;   // tile rows per 256-byte LDS bank row
+  static constexpr int SWM = CPR > 16 ? 15 : CPR - 1;      // chunk ^= (row / RPB) & SWM
+  static constexpr int RPI = 1024 / RBY;                   // tile rows per 1 KiB DMA piece
+};
+
+// all MFMAs of one staged k-tile: acc[a][b] += W-tile(a) . A-tile(b)^T
+template <int BM, int BN, int BK>
+__device__ __forceinline__ void cn_g2_compute(const char* sA, const char* sW, int lane, int wm, int wn,
+                                              f32x4 (&acc)[BN / 32][BM / 32]) {
+  typedef G2Geom<BK> G;
+  constexpr int TM = BM / 32, TN = BN / 32, KS = BK / 32;
+  const int lr = lane & 15;
+  const int sw = (lr / G::RPB) & G::SWM;
+  const int row_off = lr * G::RBY;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int coff = (((lane >> 4) + 4 * ks) ^ sw) * 16;
+    bf16x8 fw[TN], fa[TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a) fw[a] = *(const bf16x8*)(sW + (wn * (BN / 2) + a * 16) * G::RBY + row_off + coff);
+#pragma unroll
+    for (int b = 0; b < TM; ++b) fa[b] = *(const bf16x8*)(sA + (wm * (BM / 2) + b * 16) * G::RBY + row_off + coff);
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[a], fa[b], acc[a][b], 0, 0, 0);
+  }
+}
+
+// Epilogue.  fp32 outputs store 16 bytes per lane straight from the MFMA layout (64 contiguous
+// bytes per row and instruction; staging a 64 KB fp32 tile only costs occupancy: pw2 +35 %).
+// bf16 outputs go registers -> LDS tile [BM][BN] -> whole-row 16-byte chunks: direct stores would be
+// 8 bytes per lane scattered over 16 rows = up to 2.2x write amplification at HBM (rocprof
+// WRITE_SIZE).  Must be entered after a barrier (the LDS pipeline buffers are reused).
+template <int BM, int BN, class Epi>
+__device__ __forceinline__ void cn_g2_epilogue(char* smem, f32x4 (&acc)[BN / 32][BM / 32], int m0, int n0, int M, int N,
+                                               const Epi& epi, int ks, int tid, int wm, int wn) {
+  constexpr int TM = BM / 32, TN = BN / 32;
+  const int lane = tid & 63;
+  typedef typename Epi::stage_t ST;
+  if constexpr (sizeof(ST) == 4) {
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const int m = m0 + wm * (BM / 2) + b * 16 + (lane & 15);
+        const int n = n0 + wn * (BN / 2) + a * 16 + 4 * (lane >> 4);
+        if (m < M && n < N) epi(m, n, acc[a][b], N, ks);
+      }
+  } else {
+    constexpr int EPC = 16 / (int)sizeof(ST);  // elements per 16-byte chunk
+    constexpr int PITCH = BN + EPC;            // padded row pitch (elements)
+    constexpr int CH = BN / EPC;               // chunks per row
+    ST* tile = (ST*)smem;
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const int ml = wm * (BM / 2) + b * 16 + (lane & 15);
+        const int nl = wn * (BN / 2) + a * 16 + 4 * (lane >> 4);
+        const f32x4 v = acc[a][b];
+        cn_store4(tile + ml * PITCH + nl, epi.pre(n0 + nl, v[0], N), epi.pre(n0 + nl + 1, v[1], N),
+                  epi.pre(n0 + nl + 2, v[2], N), epi.pre(n0 + nl + 3, v[3], N));
+      }
+    __syncthreads();
+    for (int idx = tid; idx < BM * CH; idx += 256) {
+      const int r = idx / CH, c = idx % CH;
+      const int m = m0 + r, n = n0 + c * EPC;
+      if (m < M && n < N) epi.commit(m, n, tile + r * PITCH + c * EPC, N, ks);
+    }
+  }
+}
+
+template <int BM, int BN, int BK, int NST, class Epi>
 __global__ __launch_bounds__(256) void cn_gemm2_kernel(const bf16_t* __restrict__ A, int lda,
                                                        const bf16_t* __restrict__ W, int ldw, int M, int N, int K,
                                                        int k_slice, Epi epi) {
-  constexpr int RBY = BK * 2;          // bytes per tile row
-  constexpr int CPR = RBY / 16;        // 16-byte chunks per row (4 or 8)
-  constexpr int RPB = RBY >= 256 ? 1 : 256 / RBY;  // tile rows per 256-byte LDS bank row (4, 2 or 1)
-  constexpr int SWM = CPR > 16 ? 15 : CPR - 1;       // swizzle mask: XOR the chunk index with (row / RPB) & SWM
-  constexpr int RPI = 1024 / RBY;      // tile rows written by one DMA wave-instruction (16, 8 or 2)
+  typedef G2Geom<BK> G;
+  constexpr int RBY = G::RBY, CPR = G::CPR, RPB = G::RPB, SWM = G::SWM, RPI = G::RPI;
   constexpr int A_BYTES = BM * RBY, W_BYTES = BN * RBY, BUF = A_BYTES + W_BYTES;
   constexpr int N_DMA = BUF / 1024;
   static_assert(BUF % 1024 == 0 && A_BYTES % 1024 == 0, "tile must be a whole number of 1 KiB DMA pieces");
   constexpr int DPW = (N_DMA + 3) / 4;  // DMA instructions per wave and stage
   constexpr int TM = BM / 32, TN = BN / 32;
-  constexpr int KS = BK / 32;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int n_tiles = (N + BN - 1) / BN;
@@ -113,96 +186,189 @@ __global__ __launch_bounds__(256) void cn_gemm2_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int lr = lane & 15;
-  const int sw = (lr / RPB) & SWM;
-  const int row_off = lr * RBY;
-
-  constexpr int NBUF = BK >= 256 ? 1 : 2;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int buf = 0;
-  for (int kt = 0; kt < KT; ++kt) {
-    if (NBUF == 2 && kt + 1 < KT) stage(buf ^ 1, kt + 1);
-    const char* sA = smem + buf * BUF;
-    const char* sW = sA + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const int coff = (((lane >> 4) + 4 * ks) ^ sw) * 16;
-      bf16x8 fw[TN], fa[TM];
-#pragma unroll
-      for (int a = 0; a < TN; ++a) fw[a] = *(const bf16x8*)(sW + (wn * (BN / 2) + a * 16) * RBY + row_off + coff);
-#pragma unroll
-      for (int b = 0; b < TM; ++b) fa[b] = *(const bf16x8*)(sA + (wm * (BM / 2) + b * 16) * RBY + row_off + coff);
-#pragma unroll
-      for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[a], fa[b], acc[a][b], 0, 0, 0);
-    }
-    if (NBUF == 1 && kt + 1 < KT) {  // single stage: refill only after every wave has read it
-      __syncthreads();
-      stage(0, kt + 1);
-    }
+  if constexpr (NST == 1) {
+    // single stage (BK = 256 skinny GEMMs): refill only after every wave has read the tile
+    stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (NBUF == 2) buf ^= 1;
-  }
-
-  // ---- staged epilogue: registers -> LDS tile [BM][BN] (output type) -> whole-row 16-byte stores.
-  // Direct stores from the MFMA layout are 8/16 bytes per lane scattered over 16 rows, which cost
-  // up to 2.2x write amplification at HBM (rocprof WRITE_SIZE); through LDS every wave-instruction
-  // stores contiguous 16-byte chunks of a few rows.  (The loop above ended on a barrier.)
-  typedef typename Epi::stage_t ST;
-  if constexpr (sizeof(ST) == 4) {
-    // fp32 outputs already store 16 bytes per lane (64 contiguous bytes per row and instruction):
-    // staging a 64 KB fp32 tile only costs occupancy (measured: pw2 +35 %), so store directly
-#pragma unroll
-    for (int a = 0; a < TN; ++a)
-#pragma unroll
-      for (int b = 0; b < TM; ++b) {
-        const int m = m0 + wm * (BM / 2) + b * 16 + (lane & 15);
-        const int n = n0 + wn * (BN / 2) + a * 16 + 4 * (lane >> 4);
-        if (m < M && n < N) epi(m, n, acc[a][b], N, (int)blockIdx.y);
+    for (int kt = 0; kt < KT; ++kt) {
+      cn_g2_compute<BM, BN, BK>(smem, smem + A_BYTES, lane, wm, wn, acc);
+      if (kt + 1 < KT) {
+        __syncthreads();
+        stage(0, kt + 1);
       }
-    return;
-  }
-  constexpr int EPC = 16 / (int)sizeof(ST);          // elements per 16-byte chunk
-  constexpr int PITCH = BN + EPC;                     // padded row pitch (elements)
-  constexpr int CH = BN / EPC;                        // chunks per row
-  ST* tile = (ST*)smem;
-#pragma unroll
-  for (int a = 0; a < TN; ++a)
-#pragma unroll
-    for (int b = 0; b < TM; ++b) {
-      const int ml = wm * (BM / 2) + b * 16 + (lane & 15);
-      const int nl = wn * (BN / 2) + a * 16 + 4 * (lane >> 4);
-      const f32x4 v = acc[a][b];
-      cn_store4(tile + ml * PITCH + nl, epi.pre(n0 + nl, v[0], N), epi.pre(n0 + nl + 1, v[1], N),
-                epi.pre(n0 + nl + 2, v[2], N), epi.pre(n0 + nl + 3, v[3], N));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
-  __syncthreads();
-  for (int idx = tid; idx < BM * CH; idx += 256) {
-    const int r = idx / CH, c = idx % CH;
-    const int m = m0 + r, n = n0 + c * EPC;
-    if (m < M && n < N) epi.commit(m, n, tile + r * PITCH + c * EPC, N, (int)blockIdx.y);
+  } else {
+    // NST-deep LDS ring: NST-1 k-tiles are in flight while one is consumed.  The DMA stays in flight
+    // ACROSS the barrier (raw s_barrier + counted vmcnt; __syncthreads() would drain it -- cdna guide
+    // "Pipelining across barriers"): each wave waits until all but its newest NST-2 stages landed,
+    // the barrier makes every wave's pieces of tile kt visible and proves tile kt-1 is no longer read,
+    // so its buffer is refilled right away.
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+      if (t < KT) stage(t, t);
+    for (int kt = 0; kt < KT; ++kt) {
+      const int newer = KT - 1 - kt;  // stages issued after tile kt that may stay in flight
+      if (NST >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW) : "memory");
+      else if (NST >= 3 && newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + NST - 1 < KT) stage((kt + NST - 1) % NST, kt + NST - 1);
+      const char* sA = smem + (kt % NST) * BUF;
+      cn_g2_compute<BM, BN, BK>(sA, sA + A_BYTES, lane, wm, wn, acc);
+    }
+    __syncthreads();  // all fragment reads done before the epilogue reuses the LDS
   }
+  cn_g2_epilogue<BM, BN, Epi>(smem, acc, m0, n0, M, N, epi, (int)blockIdx.y, tid, wm, wn);
 }
 
-template <int BM, int BN, int BK, class Epi>
+// ---- skinny decoder GEMM with a LayerNorm prologue (d_model = 256) ---------------------------------
+//   a[m][:] = LayerNorm_256( sum_{s < nslab} in[s][m][:] + bias + resid[m][:] ) * g + b      (eps 1e-5)
+//   C[m][n] = sum_k a[m][k] W[n][k]
+// The normalised rows are produced by the block itself (one wave per row, wave-shuffle sums) and
+// written as bf16 straight into the swizzled LDS A tile while the W tile arrives by LDS-DMA; the
+// blocks of n-tile 0 also store them as fp32 (`x_out`: the residual stream of the next sub-layer).
+// Saves one launch (~5 us of dependent latency) per LayerNorm: 18 of the 69 launches per step.
+template <class Epi>
+__global__ __launch_bounds__(256) void cn_gemm2_ln256_kernel(const float* __restrict__ in, int nslab, size_t slab_stride,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ resid,
+                                                             const float* __restrict__ ln_w,
+                                                             const float* __restrict__ ln_b, float* __restrict__ x_out,
+                                                             const bf16_t* __restrict__ W, int ldw, int M, int N,
+                                                             Epi epi) {
+  constexpr int BM = 64, BN = 64, BK = 256;
+  typedef G2Geom<BK> G;
+  constexpr int A_BYTES = BM * G::RBY, W_BYTES = BN * G::RBY;
+  constexpr int DPW = W_BYTES / 1024 / 4;  // 8 DMA pieces per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n_tiles = (N + BN - 1) / BN;
+  const int m0 = (blockIdx.x / n_tiles) * BM;
+  const int n0 = (blockIdx.x % n_tiles) * BN;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  // W tile by LDS-DMA (2 rows of 512 bytes per piece)
+#pragma unroll
+  for (int i = 0; i < DPW; ++i) {
+    const int inst = wave * DPW + i;
+    const int r = inst * G::RPI + lane / G::CPR;
+    const int chunk = (lane % G::CPR) ^ (r & G::SWM);
+    const char* src = (const char*)(W + (size_t)min(n0 + r, N - 1) * ldw) + chunk * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(smem + A_BYTES + inst * 1024), 16, 0, 0);
+  }
+  // LayerNorm prologue: wave w normalises rows 16w .. 16w+15; lane owns columns 4l .. 4l+3.
+  // All 16 rows are loaded before any arithmetic (one memory latency per operand, not per row).
+  const f32x4 gw = *(const f32x4*)(ln_w + 4 * lane), gb = *(const f32x4*)(ln_b + 4 * lane);
+  f32x4 v[16];
+  size_t roff[16];
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    roff[rr] = (size_t)min(m0 + wave * 16 + rr, M - 1) * 256 + 4 * lane;
+    v[rr] = *(const f32x4*)(in + roff[rr]);
+  }
+  for (int sl = 1; sl < nslab; ++sl) {
+    f32x4 u[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) u[rr] = *(const f32x4*)(in + sl * slab_stride + roff[rr]);
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[rr][i] += u[rr][i];
+  }
+  if (resid) {
+    f32x4 u[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) u[rr] = *(const f32x4*)(resid + roff[rr]);
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[rr][i] += u[rr][i];
+  }
+  if (bias) {
+    const f32x4 bv = *(const f32x4*)(bias + 4 * lane);
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[rr][i] += bv[i];
+  }
+  float mean[16], rstd[16];
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) mean[rr] = v[rr][0] + v[rr][1] + v[rr][2] + v[rr][3];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) mean[rr] += __shfl_xor(mean[rr], o);
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    mean[rr] *= (1.0f / 256.0f);
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s2 = fmaf(v[rr][i] - mean[rr], v[rr][i] - mean[rr], s2);
+    rstd[rr] = s2;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) rstd[rr] += __shfl_xor(rstd[rr], o);
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    const int r = wave * 16 + rr;
+    const float rs = 1.0f / sqrtf(rstd[rr] * (1.0f / 256.0f) + 1e-5f);
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (v[rr][i] - mean[rr]) * rs * gw[i] + gb[i];
+    if (n0 == 0 && m0 + r < M) *(f32x4*)(x_out + (size_t)(m0 + r) * 256 + 4 * lane) = o;
+    // columns 4l..4l+3 = 16-byte chunk l/2, half l%2 of the 512-byte row r
+    cn_store4((bf16_t*)(smem + r * G::RBY + (((lane >> 1) ^ (r & G::SWM)) * 16) + (lane & 1) * 8), o[0], o[1], o[2], o[3]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  f32x4 acc[BN / 32][BM / 32];
+#pragma unroll
+  for (int a = 0; a < BN / 32; ++a)
+#pragma unroll
+    for (int b = 0; b < BM / 32; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  cn_g2_compute<BM, BN, BK>(smem, smem + A_BYTES, lane, wm, wn, acc);
+  __syncthreads();
+  cn_g2_epilogue<BM, BN, Epi>(smem, acc, m0, n0, M, N, epi, 0, tid, wm, wn);
+}
+
+template <class Epi>
+static int cn_gemm2_ln256(const float* in, int nslab, size_t slab_stride, const float* bias, const float* resid,
+                          const float* ln_w, const float* ln_b, float* x_out, const bf16_t* W, int ldw, int M, int N,
+                          const Epi& epi, hipStream_t stream) {
+  constexpr int SMEM = 2 * 64 * 512;
+  static bool configured = false;
+  if (!configured) {
+    CN_HIP(hipFuncSetAttribute((const void*)cn_gemm2_ln256_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               SMEM));
+    configured = true;
+  }
+  hipLaunchKernelGGL((cn_gemm2_ln256_kernel<Epi>), dim3((unsigned)(cn_cdiv(M, 64) * cn_cdiv(N, 64))), dim3(256), SMEM,
+                     stream, in, nslab, slab_stride, bias, resid, ln_w, ln_b, x_out, W, ldw, M, N, epi);
+  CN_LAUNCH_CHECK();
+  return CN_OK;
+}
+
+template <int BM, int BN, int BK, int NST, class Epi>
 static int cn_launch_gemm2_t(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, int splits,
                              const Epi& epi, hipStream_t stream) {
   constexpr int EPI_BYTES = sizeof(typename Epi::stage_t) == 4 ? 0 : BM * (BN * 2 + 16);
-  constexpr int PIPE_BYTES = (BK >= 256 ? 1 : 2) * (BM + BN) * BK * 2;  // BK = 256: single stage per slice
+  constexpr int PIPE_BYTES = NST * (BM + BN) * BK * 2;
   constexpr int SMEM = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
   static bool configured = false;
   if (!configured) {
-    CN_HIP(hipFuncSetAttribute((const void*)cn_gemm2_kernel<BM, BN, BK, Epi>,
+    CN_HIP(hipFuncSetAttribute((const void*)cn_gemm2_kernel<BM, BN, BK, NST, Epi>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     configured = true;
   }
   const long blocks = (long)cn_cdiv(M, BM) * cn_cdiv(N, BN);
   const int k_slice = K / splits;
-  hipLaunchKernelGGL((cn_gemm2_kernel<BM, BN, BK, Epi>), dim3((unsigned)blocks, (unsigned)splits), dim3(256), SMEM,
+  hipLaunchKernelGGL((cn_gemm2_kernel<BM, BN, BK, NST, Epi>), dim3((unsigned)blocks, (unsigned)splits), dim3(256), SMEM,
                      stream, A, lda, W, ldw, M, N, K, k_slice, epi);
   CN_LAUNCH_CHECK();
   return CN_OK;
@@ -217,15 +383,21 @@ static int cn_gemm2(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, i
     return CN_ERR_ARG;
   }
   const bool k64 = (K % 64 == 0);
+  static const int cfg = getenv("CN_G2_CFG") ? atoi(getenv("CN_G2_CFG")) : 0;
   if (M >= 4096) {
     const bool n96 = (N % 96 == 0) && (N % 128 != 0);
-    if (!k64 || getenv("CN_GEMM_BK32")) return cn_launch_gemm2_t<128, 128, 32, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
-    if (n96) return cn_launch_gemm2_t<128, 96, 64, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
-    return cn_launch_gemm2_t<128, 128, 64, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+    if (!k64) return cn_launch_gemm2_t<128, 128, 32, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+    if (n96) return cn_launch_gemm2_t<128, 96, 64, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+    if (cfg == 1) return cn_launch_gemm2_t<128, 128, 64, 3, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+    if (cfg == 2) return cn_launch_gemm2_t<128, 128, 32, 4, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+    if (cfg == 3) return cn_launch_gemm2_t<128, 128, 32, 3, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+    return cn_launch_gemm2_t<128, 128, 64, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
   }
-  if (!k64) return cn_launch_gemm2_t<64, 64, 32, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
-  if ((K / splits) % 256 == 0) return cn_launch_gemm2_t<64, 64, 256, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
-  return cn_launch_gemm2_t<64, 64, 64, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+  if (!k64) return cn_launch_gemm2_t<64, 64, 32, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+  static const int small_bk256 = getenv("CN_G2_SMALL256") ? atoi(getenv("CN_G2_SMALL256")) : 0;
+  if (small_bk256 && (K / splits) % 256 == 0)
+    return cn_launch_gemm2_t<64, 64, 256, 1, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+  return cn_launch_gemm2_t<64, 64, 64, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
 }
 
 // type-generic front end: bf16 -> v2, fp32 -> gemm.h

@@ -25,7 +25,8 @@ EXPORTS = (
     "conette_last_error", "conette_abi_version", "conette_create", "conette_destroy", "conette_num_frames",
     "conette_num_audio_frames", "conette_encode_workspace_bytes", "conette_decode_workspace_bytes",
     "conette_frontend_logmel", "conette_encode", "conette_decode", "conette_resample", "conette_resample_len",
-    "conette_set_option", "conette_profile_enable", "conette_profile_read",
+    "conette_set_option", "conette_profile_enable", "conette_profile_read", "conette_stream_create_masked",
+    "conette_stream_destroy",
 )
 OPT_DECODE_GRAPH = 1
 PROF_CLASSES = ("frontend", "stem", "dwconv_ln", "pw1_gemm", "pw2_gemm", "downsample", "heads", "dec_prepare",
@@ -85,6 +86,10 @@ def load_library() -> C.CDLL:
     lib.conette_profile_enable.argtypes = [C.c_void_p, C.c_uint32]
     lib.conette_profile_read.restype = C.c_int
     lib.conette_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+    lib.conette_stream_create_masked.restype = C.c_int
+    lib.conette_stream_create_masked.argtypes = [C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_void_p)]
+    lib.conette_stream_destroy.restype = C.c_int
+    lib.conette_stream_destroy.argtypes = [C.c_void_p]
     lib.conette_resample.restype = C.c_int
     lib.conette_resample.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.conette_resample_len.restype = C.c_int32
@@ -117,6 +122,25 @@ def encoder_geometry(n_samples: int) -> Tuple[int, list, list]:
         h.append(h[-1] // 2)
         w.append(w[-1] // 2)
     return f, h, w
+
+
+def make_partitioned_streams(device: torch.device, decode_share: int = 8, n_cus: int = 256):
+    """(encode_stream, decode_stream): the decode stream owns every ``decode_share``-th CU-mask bit
+    (1/decode_share of the chip), the encode stream the complement.  Returns torch ExternalStreams."""
+    lib = load_library()
+    words = (n_cus + 31) // 32
+    dec = [0] * words
+    for i in range(0, n_cus, decode_share):
+        dec[i // 32] |= 1 << (i % 32)
+    enc = [(~w) & 0xFFFFFFFF for w in dec]
+    out = []
+    with torch.cuda.device(device):
+        for mask in (enc, dec):
+            h = C.c_void_p()
+            _check(lib.conette_stream_create_masked((C.c_uint32 * words)(*mask), words, C.byref(h)),
+                   "conette_stream_create_masked")
+            out.append(torch.cuda.ExternalStream(h.value, device=device))
+    return out[0], out[1]
 
 
 class Engine:

@@ -117,6 +117,14 @@ int conette_resample(const float* in, int32_t rows, int32_t n_in, int32_t orig_s
                      void* stream);
 int32_t conette_resample_len(int32_t n_in, int32_t orig_sr, int32_t new_sr);
 
+/* CU-partitioned streams (hipExtStreamCreateWithCUMask).  The decode phase is a chain of ~10^3 tiny
+ * dependent launches; sharing the whole chip with the encoder's big grids makes every one of them
+ * queue behind resident encoder workgroups.  Giving the decode stream a private slice of CUs and
+ * the encode stream the complement lets both phases of consecutive batches run side by side.
+ * mask_words: 32-bit words, bit i = CU i enabled; returns a hipStream_t in *out_stream. */
+int conette_stream_create_masked(const uint32_t* mask_words, int32_t n_words, void** out_stream);
+int conette_stream_destroy(void* stream);
+
 /* Runtime options. */
 #define CONETTE_OPT_DECODE_GRAPH 1 /* 1 (default): replay conette_decode from a cached hipGraph */
 int conette_set_option(conette_ctx* ctx, int32_t option, int32_t value);
