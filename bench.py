@@ -39,18 +39,30 @@ PEAK_BF16_TFLOPS = 2500.0                    # dense MFMA bf16 (MI355X_MICROARCH
 PEAK_HBM_GBS = 8000.0                        # HBM3E spec (MI355X_MICROARCH.md)
 
 
+FUSED_STAGES = (0, 1)  # C = 96 / 192: pw1 + GELU + pw2 run as ONE kernel (mlp_fused.h), timed under "pw1_gemm"
+
+
 def algorithmic_work(cls: str, batch: int):
-    """(flops, bytes) of ALL launches of a kernel class for one batch."""
+    """(flops, bytes) of ALL launches of a kernel class for one batch.
+
+    Classes follow the library's profiling scopes: "pw1_gemm" = the fused MLP launches of stages 0-1
+    (both GEMMs) + the pw1 GEMMs of stages 2-3; "pw2_gemm" = the pw2 GEMMs of stages 2-3."""
     fl = by = 0.0
-    for c, d, p in zip(DIMS, DEPTHS, POS):
+    for st, (c, d, p) in enumerate(zip(DIMS, DEPTHS, POS)):
         n = batch * p
-        if cls == "pw1_gemm":      # (P x C) . (C x 4C) + bias + GELU -> bf16
-            fl += d * 2.0 * n * c * 4 * c
-            by += d * (2.0 * n * c + 2.0 * n * 4 * c + 2.0 * 4 * c * c)
-        elif cls == "pw2_gemm":    # (P x 4C) . (4C x C), x layer-scale + fp32 residual in/out
-            fl += d * 2.0 * n * c * 4 * c
-            by += d * (2.0 * n * 4 * c + 4.0 * n * c + 4.0 * n * c + 2.0 * 4 * c * c)
-        elif cls == "dwconv_ln":   # 49 MAC per element (VALU); fp32 in, bf16 out
+        gemm = 2.0 * n * c * 4 * c
+        wbytes = 2.0 * 4 * c * c
+        if cls == "pw1_gemm":
+            if st in FUSED_STAGES:   # y (bf16) in, x (fp32) in + out, both weight matrices; hidden stays on chip
+                fl += d * 2 * gemm
+                by += d * (2.0 * n * c + 8.0 * n * c + 2 * wbytes)
+            else:                    # (P x C) . (C x 4C) + bias + GELU -> bf16 hidden
+                fl += d * gemm
+                by += d * (2.0 * n * c + 2.0 * n * 4 * c + wbytes)
+        elif cls == "pw2_gemm" and st not in FUSED_STAGES:  # (P x 4C) . (4C x C), LayerScale, fp32 residual in/out
+            fl += d * gemm
+            by += d * (2.0 * n * 4 * c + 8.0 * n * c + wbytes)
+        elif cls == "dwconv_ln":     # 49 MAC per element on the VALU; fp32 in, bf16 out
             fl += d * 2.0 * 49 * n * c
             by += d * (4.0 * n * c + 2.0 * n * c)
     return fl, by

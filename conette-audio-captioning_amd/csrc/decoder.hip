@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "gemm2.h"
+#include "dec_block.h"
 
 #define CN_MAX_BEAM 8
 #define CN_MAX_PRED 64
@@ -758,6 +759,54 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
         EpiBiasAct<float> ec{ctx->cls_b, w.logits, w.ldv, ACT_NONE};
         CN_TRY(cn_gemm2_ln256(w.slabs, splits, slab, pw.ff2_b, xc, pw.n3w, pw.n3b, xn, (const bf16_t*)ctx->cls_w, d, R,
                               V, ec, s));
+      }
+    }
+    static const int dec_block = getenv("CN_DEC_BLOCK") ? atoi(getenv("CN_DEC_BLOCK")) : 1;
+    if constexpr (std::is_same<T, bf16_t>::value) if (!fused_done && dec_block) {
+      // default bf16 path: 5 launches per layer -- QKV GEMM, fused attention block (dec_block.h),
+      // FFN1 GEMM + GELU, FFN2 split-K slabs, slab-sum + residual + LN3
+      fused_done = true;
+      int splits = ff2_splits_env();
+      if (splits < 1 || splits > FF2_SPLITS || dff % (splits * 64) != 0) splits = 1;
+      const size_t slab = (size_t)R * d;
+      for (int l = 0; l < NL; ++l) {
+        const CnLayerW& lw = ctx->layers[l];
+        bf16_t* kc = (bf16_t*)w.kc + (size_t)l * maxp * R * d;
+        bf16_t* vc = (bf16_t*)w.vc + (size_t)l * maxp * R * d;
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+          EpiBiasAct<float> eq{lw.sa_in_b, w.qkv, 3 * d, ACT_NONE};
+          CN_TRY(cn_gemm2(xt, d, (const bf16_t*)lw.sa_in_w, d, R, 3 * d, d, eq, s));
+        }
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_ATTN, s);
+          hipLaunchKernelGGL(cn_dec_block_kernel, dim3(cn_cdiv(R, DB_ROWS)), dim3(256), 0, s, w.qkv, kc, vc, w.anc, step,
+                             R, beam, maxp, (const bf16_t*)kvc, kv_ld, l * 2 * d, frame_lens, Ta,
+                             (const bf16_t*)lw.sa_out_w, lw.sa_out_b, lw.n1w, lw.n1b, (const bf16_t*)lw.ca_q_w,
+                             lw.ca_q_b, (const bf16_t*)lw.ca_out_w, lw.ca_out_b, lw.n2w, lw.n2b, w.x, xt, scale);
+          CN_LAUNCH_CHECK();
+        }
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+          EpiBiasAct<bf16_t> e1{lw.ff1_b, ffh, dff, ACT_GELU_FAST};
+          CN_TRY(cn_gemm2(xt, d, (const bf16_t*)lw.ff1_w, d, R, dff, d, e1, s));
+        }
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+          EpiSlab e2{w.slabs, d, slab};
+          CN_TRY(cn_gemm2(ffh, dff, (const bf16_t*)lw.ff2_w, dff, R, d, dff, e2, s, splits));
+        }
+        {
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_MISC, s);
+          hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.slabs, splits, slab, lw.ff2_b, w.x,
+                             lw.n3w, lw.n3b, R, w.x, xt);
+          CN_LAUNCH_CHECK();
+        }
+      }
+      {
+        CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+        EpiBiasAct<float> ec{ctx->cls_b, w.logits, w.ldv, ACT_NONE};
+        CN_TRY(cn_gemm2(xt, d, (const bf16_t*)ctx->cls_w, d, R, V, d, ec, s));
       }
     }
     if (!fused_done) {

@@ -48,3 +48,17 @@ for name, (s1, s2) in (("plain", (torch.cuda.Stream(dev), torch.cuda.Stream(dev)
             with torch.cuda.stream(s2):
                 eng.decode(fe[1], lens, bos, forbid, 3, 3, 20, clone=False, slot=1)
     print(f"   encode alone on s1 {t(enc_masked):.2f}  decode alone on s2 {t(dec_masked):.2f}")
+
+# ---- two decode chains on two streams (+ optional encoder on a third) ---------------------------------
+sA, sB, sE = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+def two_dec():
+    for _ in range(N):
+        with torch.cuda.stream(sA):
+            eng.decode(fe[0], lens, bos, forbid, 3, 3, 20, clone=False, slot=0)
+        with torch.cuda.stream(sB):
+            eng.decode(fe[1], lens, bos, forbid, 3, 3, 20, clone=False, slot=1)
+try:
+    two_dec(); torch.cuda.synchronize()
+    print(f"two decodes on two streams: {t(two_dec):.2f} ms per pair (one decode alone {dec_only:.2f})")
+except Exception as e:
+    print("two-decode probe failed:", e)
