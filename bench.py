@@ -109,7 +109,7 @@ def main() -> None:
     forbid = sd["model.forbid_rep_mask"].to(dev)
     # Two pipeline slots and two HIP streams: the decode of batch i (small latency-bound launches,
     # replayed from a hipGraph) overlaps the encode of batch i+1 (big MFMA / VALU kernels).
-    share = int(os.environ.get("CN_DEC_SHARE", "8"))
+    share = int(os.environ.get("CN_DEC_SHARE", "0"))  # CU-masked streams measured no gain on this stack
     if share > 0:   # CU-partitioned streams: decode owns 1/share of the CUs, encode the rest
         from conette_amd.engine import make_partitioned_streams
         s_enc, s_dec = make_partitioned_streams(dev, decode_share=share)
