@@ -17,9 +17,27 @@ def __getattr__(name):  # lazy: importing the package must not need a GPU or the
     raise AttributeError(name)
 
 
-def conette(pretrained_model_name_or_path: str = "Labbeti/conette", **kwargs):
-    """Factory mirroring reference src/conette/__init__.py:25-49."""
+DEFAULT_MODEL_NAME = "Labbeti/conette"
+
+
+def conette(pretrained_model_name_or_path=DEFAULT_MODEL_NAME, config_kwds=None, model_kwds=None):
+    """Create a pretrained CoNeTTEModel for inference (reference src/conette/__init__.py:25-49)."""
     import importlib
     CoNeTTEModel = importlib.import_module(__name__ + ".model").CoNeTTEModel
-    config = CoNeTTEConfig.from_pretrained(pretrained_model_name_or_path)
-    return CoNeTTEModel.from_pretrained(pretrained_model_name_or_path, config=config, **kwargs)
+    config_kwds = {} if config_kwds is None else config_kwds
+    model_kwds = {} if model_kwds is None else model_kwds
+    if pretrained_model_name_or_path is None:
+        return CoNeTTEModel(CoNeTTEConfig(**config_kwds), **model_kwds)
+    config = CoNeTTEConfig.from_pretrained(pretrained_model_name_or_path, **config_kwds)
+    return CoNeTTEModel.from_pretrained(pretrained_model_name_or_path, config=config, **model_kwds)
+
+
+def get_offline_transform(model):
+    """Offline feature producer with the per-file (batch = 1) semantics of the reference's
+    ``get_resample_mean_convnext`` (transforms/get.py:240-310):
+    ``f(waveform (C, T), sr) -> {"audio": (T', 768), "audio_shape": (2,), "clip_probs": (527,)}``,
+    the columns the training HDF files store and ``model(..., preprocess=False)`` consumes."""
+    def transform(waveform, sr=32000):
+        batch = model.preprocessor(waveform, sr, None)
+        return {"audio": batch["audio"][0], "audio_shape": batch["audio_shape"][0], "clip_probs": batch["clip_probs"][0]}
+    return transform

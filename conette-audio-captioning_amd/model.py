@@ -31,6 +31,8 @@ FORBID_MODES = ("none", "all", "content_words")
 
 def load_audioset_idx_to_name(offline: bool = False, cache_path: Union[str, Path, None] = None) -> Dict[int, str]:
     """transforms/audioset_mapping.py:102-107: index -> display_name from class_labels_indices.csv."""
+    if cache_path is None:  # reference default: ~/.cache/audioset_mapping (audioset_mapping.py:16-24)
+        cache_path = os.environ.get("CONETTE_AUDIOSET_CACHE")
     cache = Path(cache_path) if cache_path is not None else Path.home().joinpath(".cache", "audioset_mapping")
     fpath = cache.joinpath("class_labels_indices.csv")
     if not osp.isfile(fpath):

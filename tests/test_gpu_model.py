@@ -145,3 +145,47 @@ def test_properties_at_benchmark_batch(model_bf16):
     o1 = eng.decode(fe, lens, bos, model_bf16.forbid_rep_mask, 1, 3, 20)
     assert torch.equal(o1["best_preds"], o1["mult_preds"][:, 0])               # beam 1 == greedy chain
     assert torch.equal(o1["best_lprobs"], o1["mult_lprobs"][:, 0])
+
+
+def test_predict_cli_and_offline_features(model_dir, model_fp32, tmp_path):
+    """conette-predict row format / CSV, and the offline per-file feature producer
+    feeding the preprocess=False entry."""
+    import csv
+    import wave
+    import conette_amd
+    from conette_amd import synth
+    from conette_amd.predict import main_predict
+    paths = []
+    for i in range(2):
+        wav = synth.synth_waveforms(1, 40000 + 8000 * i, 77 + i)[0]
+        pcm = np.clip(np.round(wav * 32768.0), -32768, 32767).astype("<i2")
+        p = str(tmp_path / f"clip{i}.wav")
+        with wave.open(p, "wb") as w:
+            w.setnchannels(1), w.setsampwidth(2), w.setframerate(32000)
+            w.writeframes(pcm.tobytes())
+        paths.append(p)
+    # the CLI needs the AudioSet CSV like the reference (class_labels_indices.csv in its cache directory)
+    cache = tmp_path / "audioset_mapping"
+    cache.mkdir()
+    with open(cache / "class_labels_indices.csv", "w") as f:
+        f.write("index,mid,display_name\n" + "".join(f"{i},/m/{i},tag{i}\n" for i in range(527)))
+    os.environ["CONETTE_AUDIOSET_CACHE"] = str(cache)
+    try:
+        out_csv = str(tmp_path / "out.csv")
+        res = main_predict(["--audio", *paths, "--task", "audiocaps", "--model_name", model_dir, "--precision", "fp32",
+                            "--csv_export", out_csv, "--verbose", "0"])
+    finally:
+        os.environ.pop("CONETTE_AUDIOSET_CACHE", None)
+    ref = model_fp32(paths, task="audiocaps")
+    assert [r["candidate"] for r in res] == ref["cands"]
+    rows = list(csv.DictReader(open(out_csv)))
+    assert [r["audio"] for r in rows] == ["clip0.wav", "clip1.wav"] and rows[0]["task"] == "audiocaps"
+    assert list(rows[0].keys()) == ["audio", "task", "candidate"]
+    # offline producer (batch = 1 per file) -> preprocess=False consumer == online path on the same single clip
+    tr = conette_amd.get_offline_transform(model_fp32)
+    wav0 = torch.from_numpy(synth.synth_waveforms(1, 48000, 5))
+    feats = tr(wav0, 32000)
+    assert feats["audio"].shape[1] == 768 and feats["audio_shape"].tolist() == [768, feats["audio"].shape[0]]
+    off = model_fp32(feats["audio"][None], x_shapes=feats["audio_shape"][None], preprocess=False, task="clotho")
+    on = model_fp32(wav0, sr=32000, task="clotho")
+    assert off["preds"].cpu().tolist() == on["preds"].cpu().tolist()
