@@ -84,14 +84,24 @@ __global__ __launch_bounds__(256) void cn_stem_kernel(const float* __restrict__ 
 // channels, so the LayerNorm over C is local to the block: conv results go through an LDS tile
 // [pos][C] and one wave normalises a position (two-pass mean / variance, wave-shuffle sums).
 // ---------------------------------------------------------------------------------------------
+__device__ unsigned long long g_dw_prof[8];
+#define DW_STAMP(i)                                                   \
+  if (dbg) {                                                          \
+    const unsigned long long t_ = clock64();                          \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_dw_prof[i], t_ - t_prev); \
+    t_prev = t_;                                                      \
+  }
+
 template <typename T, int C, int S, int TH>
 __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(const float* __restrict__ x, int H, int W, int tiles_h,
                                                             int tiles_w, const float* __restrict__ dw_w /*[49][C]*/,
                                                             const float* __restrict__ dw_b,
                                                             const float* __restrict__ ln_w,
-                                                            const float* __restrict__ ln_b, T* __restrict__ y) {
+                                                            const float* __restrict__ ln_b, T* __restrict__ y,
+                                                            int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* s_v = (float*)smem_raw;  // [TH*4*S][C]
+  unsigned long long t_prev = dbg ? clock64() : 0;
   constexpr int NP = TH * 4;      // positions per thread
   constexpr int CT = C > 384 ? 384 : C;  // threads along the channel axis (C = 768: two passes)
   constexpr int PITCH = C + 1;           // LDS tile pitch: rows of C floats would all start on bank 0
@@ -117,6 +127,7 @@ __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(c
   float k[49];
 #pragma unroll
   for (int i = 0; i < 49; ++i) k[i] = dw_w[i * C + c];
+  DW_STAMP(0)
   float acc[TH][4];
   const float bias = dw_b[c];
 #pragma unroll
@@ -184,8 +195,10 @@ __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(c
   for (int oh = 0; oh < TH; ++oh)
 #pragma unroll
     for (int ow = 0; ow < 4; ++ow) s_v[((sidx * NP) + oh * 4 + ow) * PITCH + c] = acc[oh][ow];
+  DW_STAMP(1)
   }
   __syncthreads();
+  DW_STAMP(2)
 
   // ---- LayerNorm over C.  Phase A: statistics, PARTS threads per position (two-pass mean / variance,
   // partial sums through LDS).  Phase B: normalise + store with the conv mapping (lanes = channels,
@@ -226,23 +239,34 @@ __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(c
     }
     __syncthreads();
   }
-#pragma unroll 1
-  for (int c = c0; c < C; c += CT) {
-    const float gw = ln_w[c], gb = ln_b[c];
+  DW_STAMP(3)
+  // Phase B: normalise + store, 8 consecutive channels per item (one 16-byte bf16 store; 2-byte
+  // stores per lane made this phase as long as the convolution itself -- store-issue bound)
+  constexpr int C8 = C / 8;
+  for (int item = tid; item < NPOS * C8; item += NT) {
+    const int pos = item / C8, c8 = (item % C8) * 8;
+    const int ps = pos / NP, oh = (pos % NP) >> 2, ow = pos & 3;
+    const int h = h0 + oh, w = tw * (4 * S) + ps * 4 + ow;
+    if (h >= H || w >= W) continue;
+    const float mean = s_mean[pos], rstd = s_rstd[pos];
+    const float* src = s_v + pos * PITCH + c8;
+    T* dst = y + (((size_t)b * H + h) * W + w) * C + c8;
+    float o[8];
 #pragma unroll
-    for (int oh = 0; oh < TH; ++oh) {
-      const int h = h0 + oh;
-      if (h >= H) continue;
-#pragma unroll
-      for (int ow = 0; ow < 4; ++ow) {
-        const int w = w0 + ow;
-        if (w >= W) continue;
-        const int pos = sidx * NP + oh * 4 + ow;
-        const float v = (s_v[pos * PITCH + c] - s_mean[pos]) * s_rstd[pos] * gw + gb;
-        y[(((size_t)b * H + h) * W + w) * C + c] = cn_from_f32<T>(v);
-      }
-    }
+    for (int i = 0; i < 8; ++i) o[i] = (src[i] - mean) * rstd * ln_w[c8 + i] + ln_b[c8 + i];
+    cn_store4(dst, o[0], o[1], o[2], o[3]);
+    cn_store4(dst + 4, o[4], o[5], o[6], o[7]);
   }
+  DW_STAMP(4)
+}
+
+extern "C" int conette_debug_dwprof(unsigned long long* out8, int reset) {
+  if (out8) CN_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dw_prof), 64));
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    CN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dw_prof), z, 64));
+  }
+  return CN_OK;
 }
 
 template <typename T, int C, int S, int TH>
@@ -257,7 +281,8 @@ static int launch_dwconv(const float* x, int B, int H, int W, const CnBlockW& bw
     configured = true;
   }
   hipLaunchKernelGGL((cn_dwconv_ln_kernel<T, C, S, TH>), dim3((unsigned)(B * tiles_h * tiles_w)),
-                     dim3((C > 384 ? 384 : C) * S), smem, s, x, H, W, tiles_h, tiles_w, bw.dw_w, bw.dw_b, bw.ln_w, bw.ln_b, y);
+                     dim3((C > 384 ? 384 : C) * S), smem, s, x, H, W, tiles_h, tiles_w, bw.dw_w, bw.dw_b, bw.ln_w, bw.ln_b, y,
+                     getenv("CN_DW_DEBUG") ? atoi(getenv("CN_DW_DEBUG")) : 0);
   CN_LAUNCH_CHECK();
   return CN_OK;
 }
@@ -271,39 +296,57 @@ template <typename T, int C>
 __global__ __launch_bounds__(256) void cn_ln_patchify_kernel(const float* __restrict__ x, int H, int W, long n_pos,
                                                              const float* __restrict__ ln_w,
                                                              const float* __restrict__ ln_b, T* __restrict__ p) {
-  constexpr int PER = (C + 63) / 64;
+  // one wave normalises PPW consecutive positions: all their loads are issued before any reduction
+  // (a wave per position was a pure latency chain: load -> 12 shuffles -> store, 1.3 TB/s)
+  constexpr int PER = (C + 63) / 64, PPW = 4;
   const int lane = threadIdx.x & 63;
-  const long pos = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (pos >= n_pos) return;
+  const long pos0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW;
+  if (pos0 >= n_pos) return;
   const int H2 = H / 2, W2 = W / 2;
-  const int w = (int)(pos % W);
-  const long t = pos / W;
-  const int h = (int)(t % H);
-  const int b = (int)(t / H);
-  if (h >= 2 * H2 || w >= 2 * W2) return;
-  const float* xi = x + (size_t)pos * C;
-  float v[PER];
-  float s = 0.f;
+  float v[PPW][PER];
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int cc = lane + 64 * i;
-    v[i] = (C % 64 == 0 || cc < C) ? xi[cc] : 0.f;
-    s += v[i];
+  for (int u = 0; u < PPW; ++u) {
+    const long pos = min(pos0 + u, n_pos - 1);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int cc = lane + 64 * i;
+      v[u][i] = (C % 64 == 0 || cc < C) ? x[(size_t)pos * C + cc] : 0.f;
+    }
   }
-  const float mean = cn_wave_sum(s) * (1.0f / C);
-  float s2 = 0.f;
+  float gw[PER], gb[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int cc = lane + 64 * i;
-    const float d = (C % 64 == 0 || cc < C) ? v[i] - mean : 0.f;
-    s2 = fmaf(d, d, s2);
+    gw[i] = (C % 64 == 0 || cc < C) ? ln_w[cc] : 0.f;
+    gb[i] = (C % 64 == 0 || cc < C) ? ln_b[cc] : 0.f;
   }
-  const float rstd = 1.0f / sqrtf(cn_wave_sum(s2) * (1.0f / C) + 1e-6f);
-  T* o = p + ((((size_t)b * H2 + (h >> 1)) * W2 + (w >> 1)) * 4 + ((h & 1) * 2 + (w & 1))) * C;
 #pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int cc = lane + 64 * i;
-    if (C % 64 == 0 || cc < C) o[cc] = cn_from_f32<T>((v[i] - mean) * rstd * ln_w[cc] + ln_b[cc]);
+  for (int u = 0; u < PPW; ++u) {
+    const long pos = pos0 + u;
+    if (pos >= n_pos) break;
+    const int w = (int)(pos % W);
+    const long t = pos / W;
+    const int h = (int)(t % H);
+    const int b = (int)(t / H);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) s += v[u][i];
+    const float mean = cn_wave_sum(s) * (1.0f / C);
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int cc = lane + 64 * i;
+      const float d = (C % 64 == 0 || cc < C) ? v[u][i] - mean : 0.f;
+      s2 = fmaf(d, d, s2);
+    }
+    const float rstd = 1.0f / sqrtf(cn_wave_sum(s2) * (1.0f / C) + 1e-6f);
+    if (h >= 2 * H2 || w >= 2 * W2) continue;  // odd trailing row / column is dropped by the stride-2 conv
+    T* o = p + ((((size_t)b * H2 + (h >> 1)) * W2 + (w >> 1)) * 4 + ((h & 1) * 2 + (w & 1))) * C;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int cc = lane + 64 * i;
+      if (C % 64 == 0 || cc < C) o[cc] = cn_from_f32<T>((v[u][i] - mean) * rstd * gw[i] + gb[i]);
+    }
   }
 }
 
@@ -464,7 +507,7 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
       const long n_in = (long)B * Hp * Wp;
       const CnDownW& dw = ctx->down[st - 1];
       CnProfScope ps(ctx, CONETTE_PROF_DOWNSAMPLE, s);
-      const dim3 pg((unsigned)((n_in + 3) / 4));
+      const dim3 pg((unsigned)((n_in + 15) / 16));  // 4 waves x 4 positions per block
       if (Cp == 96)
         hipLaunchKernelGGL((cn_ln_patchify_kernel<T, 96>), pg, dim3(256), 0, s, ws.x, Hp, Wp, n_in, dw.ln_w, dw.ln_b, y);
       else if (Cp == 192)
