@@ -69,6 +69,29 @@ __device__ __forceinline__ float cn_gelu_fast(float x) {
   return 0.5f * x + 0.5f * fabsf(x) * e;            // 0.5 x (1 + sign(x) erf(|x|/sqrt2))
 }
 
+// Same approximation on 4 values with packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32 do two lanes'
+// worth per issue slot; the GELU epilogues are VALU-issue bound): ~8.5 instructions per element
+// instead of ~15.
+__device__ __forceinline__ f32x2 cn_gelu_fast2(f32x2 x) {
+  const f32x2 ax = __builtin_elementwise_abs(x);
+  const f32x2 d = ax * (0.70710678118654752440f * 0.3275911f) + 1.0f;
+  const f32x2 t = f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  f32x2 p = t * 1.061405429f + (-1.453152027f);
+  p = p * t + 1.421413741f;
+  p = p * t + (-0.284496736f);
+  p = p * t + 0.254829592f;
+  const f32x2 u = x * 0.84932180028801904272f;  // sqrt(0.5 * log2(e)): exp(-x^2/2) = exp2(-u^2)
+  const f32x2 zz = -(u * u);
+  const f32x2 e = f32x2{__builtin_amdgcn_exp2f(zz[0]), __builtin_amdgcn_exp2f(zz[1])};
+  const f32x2 er = 1.0f - (p * t) * e;  // erf(|x| / sqrt2)
+  const f32x2 h = x * 0.5f;
+  return __builtin_elementwise_abs(h) * er + h;
+}
+__device__ __forceinline__ f32x4 cn_gelu_fast4(f32x4 x) {
+  const f32x2 a = cn_gelu_fast2(f32x2{x[0], x[1]}), b = cn_gelu_fast2(f32x2{x[2], x[3]});
+  return f32x4{a[0], a[1], b[0], b[1]};
+}
+
 // XCD-aware block remap (cdna guide T1, bijective form): workgroups are dealt round-robin over the
 // 8 XCDs, each with a private L2, so blocks b and b+8 share an L2.  Give every XCD one CONTIGUOUS
 // chunk of the logical grid so that neighbouring tiles (shared halos / shared A panels) hit in L2

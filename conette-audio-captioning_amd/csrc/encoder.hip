@@ -260,6 +260,15 @@ __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(c
   DW_STAMP(4)
 }
 
+extern "C" int conette_debug_mlpprof(unsigned long long* out8, int reset) {
+  if (out8) CN_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_mlp_prof), 64));
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    CN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_prof), z, 64));
+  }
+  return CN_OK;
+}
+
 extern "C" int conette_debug_dwprof(unsigned long long* out8, int reset) {
   if (out8) CN_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dw_prof), 64));
   if (reset) {

@@ -42,6 +42,17 @@ template <typename TOut> struct EpiBiasAct {
     else if (act == ACT_SIGMOID) x = 1.0f / (1.0f + __expf(-x));
     return x;
   }
+  // 4 consecutive columns at once (packed-math GELU)
+  __device__ __forceinline__ f32x4 pre4(int n, f32x4 v, int N) const {
+    if (act == ACT_GELU_FAST && n + 3 < N) {
+      if (bias != nullptr) {
+        const f32x4 b = *(const f32x4*)(bias + n);
+        v = f32x4{v[0] + b[0], v[1] + b[1], v[2] + b[2], v[3] + b[3]};
+      }
+      return cn_gelu_fast4(v);
+    }
+    return f32x4{pre(n, v[0], N), pre(n + 1, v[1], N), pre(n + 2, v[2], N), pre(n + 3, v[3], N)};
+  }
   __device__ __forceinline__ void commit(int m, int n, const TOut* chunk, int N, int /*ks*/) const {
     constexpr int E = 16 / (int)sizeof(TOut);
     TOut* p = out + (size_t)m * ldo + n;

@@ -112,9 +112,8 @@ __device__ __forceinline__ void cn_g2_epilogue(char* smem, f32x4 (&acc)[BN / 32]
       for (int b = 0; b < TM; ++b) {
         const int ml = wm * (BM / 2) + b * 16 + (lane & 15);
         const int nl = wn * (BN / 2) + a * 16 + 4 * (lane >> 4);
-        const f32x4 v = acc[a][b];
-        cn_store4(tile + ml * PITCH + nl, epi.pre(n0 + nl, v[0], N), epi.pre(n0 + nl + 1, v[1], N),
-                  epi.pre(n0 + nl + 2, v[2], N), epi.pre(n0 + nl + 3, v[3], N));
+        const f32x4 v = epi.pre4(n0 + nl, acc[a][b], N);
+        cn_store4(tile + ml * PITCH + nl, v[0], v[1], v[2], v[3]);
       }
     __syncthreads();
     for (int idx = tid; idx < BM * CH; idx += 256) {

@@ -15,7 +15,17 @@
 // source-side XOR swizzle as gemm2.h keeps the ds_read_b128 fragment reads conflict-free.
 // 4 waves as 2 (rows) x 2 (hidden / channel halves); two barriers per chunk.
 #pragma once
+#include <stdlib.h>
+
 #include "gemm.h"
+
+__device__ unsigned long long g_mlp_prof[8];
+#define MLP_STAMP(i)                                                     \
+  if (dbg) {                                                             \
+    const unsigned long long t_ = clock64();                             \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_mlp_prof[i], t_ - t_prev); \
+    t_prev = t_;                                                         \
+  }
 
 template <int C, int TM>
 __global__ __launch_bounds__(256) void cn_mlp_fused_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ W1,
@@ -23,7 +33,8 @@ __global__ __launch_bounds__(256) void cn_mlp_fused_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ W2,
                                                            const float* __restrict__ b2,
                                                            const float* __restrict__ scale, float* __restrict__ X,
-                                                           int M) {
+                                                           int M, int dbg) {
+  unsigned long long t_prev = dbg ? clock64() : 0;
   constexpr int BM = 32 * TM;           // rows per block (TM 16-row tiles per wave-row-half)
   constexpr int KS1 = C / 32;           // k-steps of GEMM1
   constexpr int TN2 = C / 32;           // 16-channel tiles per wave in GEMM2 (wave owns C/2 channels)
@@ -35,7 +46,10 @@ __global__ __launch_bounds__(256) void cn_mlp_fused_kernel(const bf16_t* __restr
   constexpr int DPW = N_DMA / 4;
   static_assert(N_DMA % 4 == 0, "DMA pieces must split evenly over 4 waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sH = smem + 2 * BUF;            // [BM][64 B]
+  constexpr int NST = 3;                // weight-chunk ring: chunks j+1, j+2 in flight during chunk j
+  char* sH = smem + NST * BUF;          // [BM][64 B]
+  float* sB1 = (float*)(sH + BM * 64);  // [4C] pwconv1 bias (no ordinary global load may sit inside the loop:
+                                        // with LDS-DMA in flight hipcc would wait vmcnt(0) for it every chunk)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,12 +103,26 @@ __global__ __launch_bounds__(256) void cn_mlp_fused_kernel(const bf16_t* __restr
 #pragma unroll
     for (int b = 0; b < TM; ++b) acc2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  for (int i = tid; i < 4 * C; i += 256) sB1[i] = b1[i];
   stage(0, 0);
+  stage(1, 1);
+  // retire the ordinary loads (y fragments, bias) HERE, once: touching the registers makes the compiler
+  // place its vmcnt wait before the loop instead of a vmcnt(0) in front of the first MFMA of every chunk
+#pragma unroll
+  for (int b = 0; b < TM; ++b)
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) asm volatile("" : "+v"(fa[b][ks]));
+  MLP_STAMP(0)
   for (int j = 0; j < NCH; ++j) {
-    const int buf = j & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                     // chunk j landed; everyone is done with chunk j-1 (buffers + H)
-    if (j + 1 < NCH) stage(buf ^ 1, j + 1);
+    const int buf = j % NST;
+    // chunk j landed for this wave when at most the newer chunk's DPW pieces are outstanding; the raw
+    // barrier (no vmcnt drain) then publishes every wave's pieces and proves chunk j-1 (buffers + H) is
+    // no longer read, so its ring slot is refilled with chunk j+2
+    if (j + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    MLP_STAMP(1)
+    if (j + 2 < NCH) stage((j + 2) % NST, j + 2);
     const char* sW1 = smem + buf * BUF;
     const char* sW2 = sW1 + W1C_BYTES;
 
@@ -108,19 +136,23 @@ __global__ __launch_bounds__(256) void cn_mlp_fused_kernel(const bf16_t* __restr
 #pragma unroll
       for (int b = 0; b < TM; ++b) acc1[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, fa[b][ks], acc1[b], 0, 0, 0);
     }
+    MLP_STAMP(2)
     // epilogue 1: + b1, GELU, -> bf16 -> H tile; lane holds hidden 4lq..4lq+3 (of this wave's 16) of row lr
     {
-      const f32x4 bb = *(const f32x4*)(b1 + j * 32 + wn * 16 + 4 * lq);
+      const f32x4 bb = *(const f32x4*)(sB1 + j * 32 + wn * 16 + 4 * lq);
       const int chunk = wn * 2 + (lq >> 1);
 #pragma unroll
       for (int b = 0; b < TM; ++b) {
         const int ml = wm * (BM / 2) + b * 16 + lr;
         bf16_t* dst = (bf16_t*)(sH + ml * 64 + ((chunk ^ sw) * 16) + (lq & 1) * 8);
-        cn_store4(dst, cn_gelu_fast(acc1[b][0] + bb[0]), cn_gelu_fast(acc1[b][1] + bb[1]),
-                  cn_gelu_fast(acc1[b][2] + bb[2]), cn_gelu_fast(acc1[b][3] + bb[3]));
+        const f32x4 g = cn_gelu_fast4(f32x4{acc1[b][0] + bb[0], acc1[b][1] + bb[1], acc1[b][2] + bb[2], acc1[b][3] + bb[3]});
+        cn_store4(dst, g[0], g[1], g[2], g[3]);
       }
     }
-    __syncthreads();                     // H chunk complete
+    MLP_STAMP(3)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my H writes are in LDS ...
+    __builtin_amdgcn_s_barrier();                        // ... and so are everyone's (raw: keeps the DMA in flight)
+    MLP_STAMP(4)
     // GEMM2: rows wm*(BM/2).. (TM tiles) x channels wn*(C/2).. (TN2 tiles), K = 32
     bf16x8 fh[TM];
 #pragma unroll
@@ -131,6 +163,7 @@ __global__ __launch_bounds__(256) void cn_mlp_fused_kernel(const bf16_t* __restr
 #pragma unroll
       for (int b = 0; b < TM; ++b) acc2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2, fh[b], acc2[a][b], 0, 0, 0);
     }
+    MLP_STAMP(5)
   }
 
   // ---- final epilogue: x += scale * (acc + b2), 16 bytes per lane (4 consecutive channels) ---------
@@ -151,12 +184,13 @@ __global__ __launch_bounds__(256) void cn_mlp_fused_kernel(const bf16_t* __restr
       }
     }
   }
+  MLP_STAMP(6)
 }
 
 template <int C, int TM>
 static int cn_launch_mlp_fused(const bf16_t* Y, const bf16_t* W1, const float* b1, const bf16_t* W2, const float* b2,
                                const float* scale, float* X, int M, hipStream_t s) {
-  constexpr int SMEM = 2 * (32 * C * 2 + C * 64) + 32 * TM * 64;
+  constexpr int SMEM = 3 * (32 * C * 2 + C * 64) + 32 * TM * 64 + 4 * C * 4;
   static bool configured = false;
   if (!configured) {
     CN_HIP(hipFuncSetAttribute((const void*)cn_mlp_fused_kernel<C, TM>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -164,7 +198,7 @@ static int cn_launch_mlp_fused(const bf16_t* Y, const bf16_t* W1, const float* b
     configured = true;
   }
   hipLaunchKernelGGL((cn_mlp_fused_kernel<C, TM>), dim3((unsigned)cn_cdiv(M, 32 * TM)), dim3(256), SMEM, s, Y, W1, b1,
-                     W2, b2, scale, X, M);
+                     W2, b2, scale, X, M, getenv("CN_MLP_DEBUG") ? 1 : 0);
   CN_LAUNCH_CHECK();
   return CN_OK;
 }
