@@ -109,6 +109,17 @@ __global__ void pk_down(const float* __restrict__ src, T* __restrict__ dst, int 
   const size_t n = nc / C;
   dst[(n * 4 + kk) * C + c] = cn_from_f32<T>(src[i]);
 }
+// decoder block stream (dec_block.h): 16-byte unit u = ((((m*4 + w)*4 + qd)*4 + a)*2 + kk)*64 + lane holds
+// W_m[64w + 16a + (lane & 15)][32(2qd + kk) + 8(lane >> 4) .. +8]
+struct PkBlockSrc { const float* W[6]; };
+__global__ void pk_block_stream(PkBlockSrc src, bf16_t* __restrict__ dst) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= 6 * 4 * 4 * 4 * 2 * 64) return;
+  const int lane = u & 63, kk = (u >> 6) & 1, a = (u >> 7) & 3, qd = (u >> 9) & 3, w = (u >> 11) & 3, m = u >> 13;
+  const float* s = src.W[m] + (size_t)(64 * w + 16 * a + (lane & 15)) * 256 + 32 * (2 * qd + kk) + 8 * (lane >> 4);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dst[(size_t)u * 8 + i] = (bf16_t)s[i];
+}
 __global__ void pk_bn(const float* w, const float* b, const float* mean, const float* var, float* scale, float* shift,
                       int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -370,6 +381,31 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
       lw.n2b = B.f32(p + "norm2.bias", d);
       lw.n3w = B.f32(p + "norm3.weight", d);
       lw.n3b = B.f32(p + "norm3.bias", d);
+      lw.blk_w = nullptr;
+      lw.blk_p = nullptr;
+      if (ctx->esize == 2) {
+        bf16_t* bw = (bf16_t*)B.alloc((size_t)6 * d * d * 2);
+        const float* ipw = B.find(p + "self_attn.in_proj_weight", (int64_t)3 * d * d);
+        const float* sow = B.find(p + "self_attn.out_proj.weight", (int64_t)d * d);
+        const float* cow = B.find(p + "multihead_attn.out_proj.weight", (int64_t)d * d);
+        if (ipw && sow && caw && cow) {
+          PkBlockSrc ps;
+          ps.W[0] = ipw, ps.W[1] = ipw + (size_t)d * d, ps.W[2] = ipw + (size_t)2 * d * d, ps.W[3] = sow, ps.W[4] = caw, ps.W[5] = cow;
+          hipLaunchKernelGGL(pk_block_stream, dim3(6 * 4 * 4 * 4 * 2 * 64 / 256), dim3(256), 0, 0, ps, bw);
+        }
+        lw.blk_w = bw;
+      }
+      {
+        float* bp = (float*)B.alloc(2560 * 4);
+        const float* parts[8] = {lw.sa_in_b, lw.sa_out_b, lw.ca_q_b, lw.ca_out_b, lw.n1w, lw.n1b, lw.n2w, lw.n2b};
+        size_t off = 0;
+        for (int i = 0; i < 8; ++i) {
+          const size_t n = i == 0 ? 768 : 256;
+          if (parts[i]) hipMemcpy(bp + off, parts[i], n * 4, hipMemcpyDeviceToDevice);
+          off += n;
+        }
+        lw.blk_p = bp;
+      }
     }
   }
   ctx->emb = B.f32(D + "emb_layer.weight", (int64_t)V * d);

@@ -1,140 +1,107 @@
 // Fused decoder "attention block" for one new token per row (bf16 operands, d_model 256, 8 heads):
 //
-//   a  = SelfAttn(qkv row, cached K/V of its ancestors)          (writes this step's K/V)
+//   x  = E[tok] * sqrt(d) + PE[step]                     (layer 0)
+//      | LN3_prev(x + FFN2 split-K slabs + b2_prev)      (layers > 0: the previous layer's tail)
+//   q | k | v = x Win^T + bin
+//   a  = SelfAttn(q, cached K/V of the row's ancestors + this step's k, v)   (writes this step's K/V)
 //   x1 = LN1(x + a Wo^T + bo)
 //   c  = CrossAttn(x1 Wq^T + bq, audio K/V of the row's clip, frame mask)
-//   x2 = LN2(x1 + c Wo2^T + bo2)                                   -> x (fp32) and xt (bf16)
+//   x2 = LN2(x1 + c Wo2^T + bo2)                                              -> x (fp32) and xt (bf16)
 //
 // i.e. torch's post-norm TransformerDecoderLayer up to the feed-forward (aac_tfmer.py:46-58,
-// 108-115).  Everything here is row-local, so a block owns DB_ROWS rows (padded to one MFMA M tile of
-// 16) and keeps them on chip across all seven sub-steps; the unfused path needs 7 dependent launches for the same
-// work and the decode phase is bound by per-launch latency (~5 us each, rocprof), not by bytes.
+// 100-115).  Everything here is row-local, so a block owns DB_ROWS rows (padded to one MFMA M tile of
+// 16) and keeps them on chip across all sub-steps; the unfused path needs 10 dependent launches for
+// the same work and the decode phase is bound by per-launch latency (~5 us each, rocprof), not bytes.
 //
-//   * GEMMs (16 x 256 x 256): activations are the MFMA B operand from a swizzled 8 KB LDS tile,
-//     weights go straight from L2 to registers (each weight byte is used by exactly one wave of
-//     one block -- no LDS reuse to exploit at M = 16; cdna guide "GEMV / M <= 16" row);
-//     wave w owns output columns 64w .. 64w+63.
-//   * attention: one wave per row, lane = 4 dims of one head, keys in batches of 8 (all loads of a
-//     batch in flight), wave-shuffle dot products, online softmax in fp32.
-//   * LayerNorm: per-lane partials -> xor-16/32 shuffles -> 4-wave LDS reduction; two-pass.
+// The block is a dependent chain of tiny phases, so what matters is that nothing it will need is
+// still un-requested when a phase starts.  Two wave roles with separate VMEM queues (vmcnt is per wave
+// and returns in order, so mixing the streams would serialise them):
+//
+//   * 4 GEMM waves: wave w owns output columns 64w .. 64w+63 of all six 256 x 256 weight matrices and
+//     holds the current matrix as 32 MFMA A-fragments in registers (128 VGPRs).  The matrices are
+//     stored in fragment order (api.hip pk_block_stream: every load instruction moves 1 KB of
+//     consecutive bytes -- strided 64-byte row pieces streamed at half the rate), and a fragment's
+//     registers are re-loaded with the same fragment of the NEXT matrix right behind the MFMA that
+//     consumed it, so one whole matrix (128 KB per block) is always in flight; hipcc counts the
+//     vmcnt per fragment because these waves issue no other global access.  Activations are the
+//     MFMA B operand from a swizzled LDS tile.  (An LDS ring filled by global_load_lds was as fast
+//     in isolation but its 128 KB left no room for the encoder's blocks on the CU: rocprof, bench.)
+//   * 4 row waves (wave = row, lane = 4 dims of one head): prologue, both attentions, both
+//     LayerNorms, all global stores.  Self-attention K/V (<= 24 steps) are requested at kernel start,
+//     cross-attention K/V (<= 32 frames) right after the self-attention, both into registers, so they
+//     arrive while the GEMM waves work.  fp32 online softmax, wave-shuffle dot products and LN sums.
+//
+// The roles hand over through LDS with raw s_barrier (lgkmcnt(0) only: __syncthreads() would also
+// drain the prefetch queues).  Per-CU ingest (~80 GB/s) bounds the kernel: 768 KB of weights per block.
 #pragma once
 #include "gemm2.h"
 
 #define DB_ROWS 4   // rows (= waves) per block: many small blocks spread the K/V and weight streams over more CUs
 
-__device__ __forceinline__ f32x4 db_cvt4(const bf16x8& v, int hi) {
-  return f32x4{(float)v[4 * hi], (float)v[4 * hi + 1], (float)v[4 * hi + 2], (float)v[4 * hi + 3]};
-}
-
-// Weight fragments of one 256 x 256 matrix for this wave's 64 output columns, straight from L2 to
-// registers: fw[a][ks] = W[64w + 16a + (lane & 15)][32ks + 8(lane >> 4) .. +8].  Issued one phase
-// EARLY (weights do not depend on data) so their latency hides under the attention / LayerNorm work;
-// at one wave per SIMD the 512-entry register file holds them (128 VGPRs per matrix).
-__device__ __forceinline__ void db_wload(const bf16_t* __restrict__ W, int wave, int lane, bf16x8 (&fw)[4][8]) {
-  const bf16_t* wrow = W + (size_t)(64 * wave + (lane & 15)) * 256 + 8 * (lane >> 4);
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) fw[a][ks] = *(const bf16x8*)(wrow + (size_t)a * 16 * 256 + ks * 32);
-}
-
-// out(n, m) tile-set: acc[a] holds columns n = 64*wave + 16a + 4*(lane>>4) + j of row m = lane & 15
-__device__ __forceinline__ void db_gemm16(const bf16x8 (&fw)[4][8], const char* sA, int lane, f32x4 (&acc)[4]) {
-  typedef G2Geom<256> G;
-  const int lr = lane & 15, lq = lane >> 4;
-#pragma unroll
-  for (int a = 0; a < 4; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks) {
-    const bf16x8 fa = *(const bf16x8*)(sA + lr * G::RBY + (((lq + 4 * ks) ^ (lr & G::SWM)) * 16));
-#pragma unroll
-    for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[a][ks], fa, acc[a], 0, 0, 0);
-  }
-}
-
-// v[a][j] (column n, row m = lane & 15) -> LayerNorm over the 256 columns of each row (eps 1e-5).
-// s_red: [2][4][16] floats.  Returns normalised * g + b in place.
-__device__ __forceinline__ void db_layernorm(f32x4 (&v)[4], const float* __restrict__ g, const float* __restrict__ b,
-                                             float* s_red, int wave, int lane) {
-  const int lr = lane & 15, lq = lane >> 4;
-  float s = 0.f;
-#pragma unroll
-  for (int a = 0; a < 4; ++a) s += v[a][0] + v[a][1] + v[a][2] + v[a][3];
-  s += __shfl_xor(s, 16);
-  s += __shfl_xor(s, 32);
-  if (lq == 0) s_red[wave * 16 + lr] = s;
-  __syncthreads();
-  const float mean = (s_red[lr] + s_red[16 + lr] + s_red[32 + lr] + s_red[48 + lr]) * (1.0f / 256.0f);
-  float q = 0.f;
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) q = fmaf(v[a][j] - mean, v[a][j] - mean, q);
-  q += __shfl_xor(q, 16);
-  q += __shfl_xor(q, 32);
-  if (lq == 0) s_red[64 + wave * 16 + lr] = q;
-  __syncthreads();
-  const float rstd =
-      1.0f / sqrtf((s_red[64 + lr] + s_red[80 + lr] + s_red[96 + lr] + s_red[112 + lr]) * (1.0f / 256.0f) + 1e-5f);
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int n = 64 * wave + 16 * a + 4 * lq;
-    const f32x4 gg = *(const f32x4*)(g + n), bb = *(const f32x4*)(b + n);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[a][j] = (v[a][j] - mean) * rstd * gg[j] + bb[j];
-  }
-}
-
-// write v (column-n layout) as bf16 into the swizzled A tile: columns n..n+3 of row m
-__device__ __forceinline__ void db_store_tile(char* sA, const f32x4 (&v)[4], int wave, int lane) {
-  typedef G2Geom<256> G;
-  const int lr = lane & 15, lq = lane >> 4;
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int n = 64 * wave + 16 * a + 4 * lq;  // chunk n/8, half (n%8)/4
-    cn_store4((bf16_t*)(sA + lr * G::RBY + ((((n >> 3)) ^ (lr & G::SWM)) * 16) + ((n >> 2) & 1) * 8), v[a][0], v[a][1],
-              v[a][2], v[a][3]);
-  }
-}
-
 // Wave-per-row attention: lane l owns dims 4l..4l+3 (head l >> 3); keys in batches of NB with all
 // loads of a batch in flight; fp32 online softmax.  kp(s) / vp(s): this lane's 4 bf16 of key / value s.
+template <int NB> struct DbKV { bf16x4 k[NB], v[NB]; };
+
 template <int NB, class KeyPtr, class ValPtr>
-__device__ __forceinline__ void db_attend(const f32x4& q, int n_keys, KeyPtr kp, ValPtr vp, float& m, float& l,
-                                          f32x4& o) {
-  for (int s0 = 0; s0 < n_keys; s0 += NB) {
-    bf16x4 kr[NB], vr[NB];
+__device__ __forceinline__ void db_kv_load(DbKV<NB>& kv, int s0, int n_keys, KeyPtr kp, ValPtr vp) {
 #pragma unroll
-    for (int u = 0; u < NB; ++u) {
-      const int s = min(s0 + u, n_keys - 1);
-      kr[u] = *(const bf16x4*)kp(s);
-      vr[u] = *(const bf16x4*)vp(s);
+  for (int u = 0; u < NB; ++u) {
+    const int s = min(s0 + u, n_keys - 1);
+    kv.k[u] = *(const bf16x4*)kp(s);
+    kv.v[u] = *(const bf16x4*)vp(s);
+  }
+}
+
+template <int NB>
+__device__ __forceinline__ void db_kv_consume(const DbKV<NB>& kv, const f32x4& q, int s0, int n_keys, float& m,
+                                              float& l, f32x4& o) {
+  float sc[NB];
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    float d = q[0] * (float)kv.k[u][0] + q[1] * (float)kv.k[u][1] + q[2] * (float)kv.k[u][2] + q[3] * (float)kv.k[u][3];
+    d += __shfl_xor(d, 1);
+    d += __shfl_xor(d, 2);
+    d += __shfl_xor(d, 4);
+    sc[u] = (s0 + u < n_keys) ? d : -INFINITY;
+  }
+  float mb = sc[0];
+#pragma unroll
+  for (int u = 1; u < NB; ++u) mb = fmaxf(mb, sc[u]);
+  const float mn = fmaxf(m, mb);
+  const float corr = __expf(m - mn);
+  l *= corr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] *= corr;
+#pragma unroll
+  for (int u = 0; u < NB; ++u) {
+    const float p = __expf(sc[u] - mn);
+    l += p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = fmaf(p, (float)kv.v[u][i], o[i]);
+  }
+  m = mn;
+}
+
+// Rolling K/V pipeline over DEPTH register buffers: db_kv_prefetch issues batches 0 .. DEPTH-1 (early, while
+// other work runs), db_kv_attend consumes batch b and re-issues its buffer with batch b + DEPTH.
+template <int NB, int DEPTH, class KeyPtr, class ValPtr>
+__device__ __forceinline__ void db_kv_prefetch(DbKV<NB> (&buf)[DEPTH], int n_keys, KeyPtr kp, ValPtr vp) {
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+    if (d * NB < n_keys) db_kv_load(buf[d], d * NB, n_keys, kp, vp);
+}
+template <int NB, int DEPTH, class KeyPtr, class ValPtr>
+__device__ __forceinline__ void db_kv_attend(DbKV<NB> (&buf)[DEPTH], const f32x4& q, int n_keys, KeyPtr kp, ValPtr vp,
+                                             float& m, float& l, f32x4& o) {
+  for (int s0 = 0; s0 < n_keys; s0 += NB * DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int sb = s0 + d * NB;
+      if (sb < n_keys) {
+        db_kv_consume(buf[d], q, sb, n_keys, m, l, o);
+        if (sb + NB * DEPTH < n_keys) db_kv_load(buf[d], sb + NB * DEPTH, n_keys, kp, vp);
+      }
     }
-    float sc[NB];
-#pragma unroll
-    for (int u = 0; u < NB; ++u) {
-      float d = q[0] * (float)kr[u][0] + q[1] * (float)kr[u][1] + q[2] * (float)kr[u][2] + q[3] * (float)kr[u][3];
-      d += __shfl_xor(d, 1);
-      d += __shfl_xor(d, 2);
-      d += __shfl_xor(d, 4);
-      sc[u] = (s0 + u < n_keys) ? d : -INFINITY;
-    }
-    float mb = sc[0];
-#pragma unroll
-    for (int u = 1; u < NB; ++u) mb = fmaxf(mb, sc[u]);
-    const float mn = fmaxf(m, mb);
-    const float corr = __expf(m - mn);
-    l *= corr;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] *= corr;
-#pragma unroll
-    for (int u = 0; u < NB; ++u) {
-      const float p = __expf(sc[u] - mn);
-      l += p;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = fmaf(p, (float)vr[u][i], o[i]);
-    }
-    m = mn;
   }
 }
 
@@ -145,52 +112,313 @@ __device__ __forceinline__ void db_store_row(char* sA, int wave, int lane, const
             o[1] * inv, o[2] * inv, o[3] * inv);
 }
 
-__global__ __launch_bounds__(256, 1) void cn_dec_block_kernel(
-    const float* __restrict__ qkv,                       // (R, 768) fp32: this step's q | k | v
+struct DbPrologue {
+  // layer 0: x = emb[tok] * sqrt(d) + pe[step]   (aac_tfmer.py:100-106)
+  const int* tok;
+  const float* emb;
+  const float* pe_row;
+  float emb_scale;
+  // layer > 0: x = LN3_prev( sum_s slabs[s] + b2_prev + x_prev )   (FFN2 split-K partials of the previous layer)
+  const float* slabs;
+  int nslab;  // <= 8
+  size_t slab_stride;
+  const float* b2_prev;
+  const float* g3;
+  const float* b3;
+};
+
+// the six 256 x 256 weight matrices in the order they are consumed, and the per-column parameters
+struct DbWeights {
+  const bf16_t* stream;  // CnLayerW::blk_w: in_proj q | k | v rows, self out-proj, cross q-proj, cross out-proj in fragment order
+  const float* params;   // CnLayerW::blk_p: bin 768 | bo | bq | bo2 | g1 | b1 | g2 | b2
+};
+
+// LDS map (dynamic, bytes)
+#define DB_OFF_A 0                               // activation tile: DB_ROWS rows + one zero row, 512 B each
+#define DB_OFF_X (DB_OFF_A + (DB_ROWS + 1) * 512)  // fp32 residual rows
+#define DB_OFF_V (DB_OFF_X + DB_ROWS * 1024)     // q | k | v rows (fp32); later: pre-LN rows (Y) and cross q (Q)
+#define DB_OFF_P (DB_OFF_V + 3 * DB_ROWS * 1024)  // parameters: bin 768 | bo | bq | bo2 | g1 | b1 | g2 | b2
+#define DB_LDS_BYTES (DB_OFF_P + 2560 * 4)
+#define DB_P_BO 768
+#define DB_P_BQ 1024
+#define DB_P_BO2 1280
+#define DB_P_G1 1536
+#define DB_P_B1 1792
+#define DB_P_G2 2048
+#define DB_P_B2 2304
+
+#define DB_SYNC()                                        \
+  do {                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_s_barrier();                        \
+    asm volatile("" ::: "memory");                       \
+  } while (0)
+
+// fragment (a, ks) of matrix m for this wave: fw[a][ks] = W_m[64w + 16a + (lane & 15)][32ks + 8(lane >> 4) .. +8],
+// 1 KB of consecutive bytes per wave instruction in the packed stream.  Uniform base + 32-bit lane offset
+// (voff = (wave * 16384 + lane * 8) * 2 bytes) keeps the address in an SGPR pair + one VGPR for all 192 loads.
+struct DbStream {
+  const bf16_t* base;
+  unsigned voff;
+};
+// Written as inline asm: hipcc otherwise keeps a 64-bit VGPR address per 4 KB window (35 pairs) and renames the
+// destination registers (+28), which pushed the kernel past the register budget that lets a block start on a CU
+// that still runs one of the encoder's GEMM workgroups.  The loads are invisible to hipcc's waitcnt insertion,
+// so db_gemm_regs counts them itself.
+__device__ __forceinline__ void db_frag_load(bf16x8& dst, const DbStream& st, int m, int a, int ks) {
+  const bf16_t* p = st.base + (size_t)(m * 16 + (ks >> 1)) * 4096 + (a * 2 + (ks & 1)) * 512;
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(st.voff), "s"(p));
+}
+
+// acc[a] (columns n = 64w + 16a + 4(lane >> 4) + j, row m = lane & 15) = A-tile . W[M]^T for this wave's columns;
+// each fragment register is re-loaded with matrix M + 1 right behind its MFMA.  Fragments are consumed in issue
+// order and every consumed one is re-issued, so exactly 31 younger loads are in flight at each wait (fewer only
+// while the last matrix drains); the GEMM waves issue no other vector memory instruction.
+template <int M>
+__device__ __forceinline__ void db_gemm_regs(const DbStream& wlane, bf16x8 (&fw)[4][8], const char* sA, int lane,
+                                             f32x4 (&acc)[4]) {
+  typedef G2Geom<256> G;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int arow = lr < DB_ROWS ? lr : DB_ROWS;  // padding rows of the M tile all read the zero row
+  const int asw = lr < DB_ROWS ? (lr & G::SWM) : 0;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa = *(const bf16x8*)(sA + arow * G::RBY + ((lq ^ asw) * 16));
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const bf16x8 fc = fa;
+    if (ks < 7) fa = *(const bf16x8*)(sA + arow * G::RBY + (((lq + 4 * (ks + 1)) ^ asw) * 16));
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if (M < 5) {
+        asm volatile("s_waitcnt vmcnt(31)" : "+v"(fw[a][ks]));
+      } else {
+        constexpr int kDummy = 0;
+        (void)kDummy;
+        switch (31 - (ks * 4 + a)) {  // compile-time after unrolling
+#define DB_WAIT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(fw[a][ks])); break;
+          DB_WAIT_CASE(31) DB_WAIT_CASE(30) DB_WAIT_CASE(29) DB_WAIT_CASE(28) DB_WAIT_CASE(27) DB_WAIT_CASE(26)
+          DB_WAIT_CASE(25) DB_WAIT_CASE(24) DB_WAIT_CASE(23) DB_WAIT_CASE(22) DB_WAIT_CASE(21) DB_WAIT_CASE(20)
+          DB_WAIT_CASE(19) DB_WAIT_CASE(18) DB_WAIT_CASE(17) DB_WAIT_CASE(16) DB_WAIT_CASE(15) DB_WAIT_CASE(14)
+          DB_WAIT_CASE(13) DB_WAIT_CASE(12) DB_WAIT_CASE(11) DB_WAIT_CASE(10) DB_WAIT_CASE(9) DB_WAIT_CASE(8)
+          DB_WAIT_CASE(7) DB_WAIT_CASE(6) DB_WAIT_CASE(5) DB_WAIT_CASE(4) DB_WAIT_CASE(3) DB_WAIT_CASE(2)
+          DB_WAIT_CASE(1) DB_WAIT_CASE(0)
+#undef DB_WAIT_CASE
+        }
+      }
+      acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[a][ks], fc, acc[a], 0, 0, 0);
+      if (M < 5) db_frag_load(fw[a][ks], wlane, M + 1, a, ks);
+    }
+  }
+}
+
+// row LayerNorm (eps 1e-5) of a lane's 4 columns of one 256-wide row
+__device__ __forceinline__ f32x4 db_row_ln(const f32x4& v, const float* g, const float* b, int lane) {
+  const float mean = cn_wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s2 = fmaf(v[i] - mean, v[i] - mean, s2);
+  const float rstd = __builtin_amdgcn_rsqf(cn_wave_sum(s2) * (1.0f / 256.0f) + 1e-5f);
+  const f32x4 gg = *(const f32x4*)(g + 4 * lane), bb = *(const f32x4*)(b + 4 * lane);
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = (v[i] - mean) * rstd * gg[i] + bb[i];
+  return r;
+}
+
+__device__ unsigned long long g_db_prof[16];
+#define DB_STAMP(i)                                            \
+  if (dbg) {                                                   \
+    const unsigned long long t_ = wall_clock64();              \
+    if (lane == 0 && rw == 0) atomicAdd(&g_db_prof[i], t_ - t_prev); \
+    t_prev = t_;                                               \
+  }
+
+#define DB_NB_SELF 8       // self-attention keys per batch
+#define DB_DEPTH_SELF 2    // batches in flight (register buffers): the first two are requested at kernel start
+#define DB_NB_CROSS 8      // cross-attention frames per batch
+#define DB_DEPTH_CROSS 2   // requested right after the self-attention; the rest roll while the first are consumed
+
+__global__ __launch_bounds__(512, 1) void cn_dec_block_kernel(
+    DbPrologue pro, DbWeights wt,
     bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,    // self K/V cache of this layer [step][R][256]
     const int* __restrict__ anc, int step, int R, int beam, int maxp,
     const bf16_t* __restrict__ kvx, int kv_ld, int kv_off, const int* __restrict__ lens, int Ta,  // cross K/V
-    const bf16_t* __restrict__ Wo, const float* __restrict__ bo, const float* __restrict__ g1,
-    const float* __restrict__ b1, const bf16_t* __restrict__ Wq, const float* __restrict__ bq,
-    const bf16_t* __restrict__ Wo2, const float* __restrict__ bo2, const float* __restrict__ g2,
-    const float* __restrict__ b2, float* __restrict__ x /* in: residual, out: x2 */, bf16_t* __restrict__ xt,
-    float scale) {
+    float* __restrict__ x /* in: previous layer's x2 (residual of its FFN), out: x2 */, bf16_t* __restrict__ xt,
+    float scale, int dbg) {
   typedef G2Geom<256> G;
-  __shared__ __attribute__((aligned(16))) char sA[16 * 512];   // MFMA M tile: rows >= DB_ROWS are padding
-  __shared__ __attribute__((aligned(16))) float sQ[DB_ROWS * 256];
-  __shared__ float s_red[128];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem + DB_OFF_A;
+  float* sX = (float*)(smem + DB_OFF_X);
+  float* sV = (float*)(smem + DB_OFF_V);
+  float* sY = sV;                      // pre-LayerNorm rows (after q | k | v are dead)
+  float* sQ = sV + DB_ROWS * 256;      // scaled cross-attention queries
+  float* sP = (float*)(smem + DB_OFF_P);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r0 = blockIdx.x * DB_ROWS;
-  const int lr = lane & 15, lq = lane >> 4;
-  const int tr = min(r0 + wave, R - 1);  // the row this wave attends for
 
-  for (int i = tid; i < (16 - DB_ROWS) * 512 / 16; i += 256) ((uint4*)(sA + DB_ROWS * 512))[i] = uint4{0, 0, 0, 0};
-  bf16x8 fw[4][8];
-  db_wload(Wo, wave, lane, fw);  // in flight during P1
+  if (wave < 4) {
+    // ======================= GEMM waves ========================================================
+    const int lr = lane & 15, lq = lane >> 4;
+    const DbStream wlane{wt.stream, (unsigned)(wave * 4 * 4096 + lane * 8) * 2u};
+    bf16x8 fw[4][8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) db_frag_load(fw[a][ks], wlane, 0, a, ks);
+    f32x4 acc[4];
+    DB_SYNC();  // b1: x rows (sA) and parameters (sP) are in LDS
+    {           // q | k | v
+      db_gemm_regs<0>(wlane, fw, sA, lane, acc);
+      if (lr < DB_ROWS)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int n = 64 * wave + 16 * a + 4 * lq;
+          const f32x4 bb = *(const f32x4*)(sP + n);
+          *(f32x4*)(sV + (0 * DB_ROWS + lr) * 256 + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
+        }
+      db_gemm_regs<1>(wlane, fw, sA, lane, acc);
+      if (lr < DB_ROWS)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int n = 64 * wave + 16 * a + 4 * lq;
+          const f32x4 bb = *(const f32x4*)(sP + 256 + n);
+          *(f32x4*)(sV + (1 * DB_ROWS + lr) * 256 + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
+        }
+      db_gemm_regs<2>(wlane, fw, sA, lane, acc);
+      if (lr < DB_ROWS)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int n = 64 * wave + 16 * a + 4 * lq;
+          const f32x4 bb = *(const f32x4*)(sP + 512 + n);
+          *(f32x4*)(sV + (2 * DB_ROWS + lr) * 256 + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
+        }
+    }
+    DB_SYNC();  // b2: q | k | v ready
+    DB_SYNC();  // b3: self-attention output in sA
+    {
+      db_gemm_regs<3>(wlane, fw, sA, lane, acc);
+      if (lr < DB_ROWS)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int n = 64 * wave + 16 * a + 4 * lq;
+          const f32x4 bb = *(const f32x4*)(sP + DB_P_BO + n), rs = *(const f32x4*)(sX + lr * 256 + n);
+          *(f32x4*)(sY + lr * 256 + n) = f32x4{acc[a][0] + bb[0] + rs[0], acc[a][1] + bb[1] + rs[1], acc[a][2] + bb[2] + rs[2], acc[a][3] + bb[3] + rs[3]};
+        }
+    }
+    DB_SYNC();  // b4: pre-LN1 rows ready
+    DB_SYNC();  // b5: x1 in sX / sA
+    {
+      db_gemm_regs<4>(wlane, fw, sA, lane, acc);
+      if (lr < DB_ROWS)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int n = 64 * wave + 16 * a + 4 * lq;
+          const f32x4 bb = *(const f32x4*)(sP + DB_P_BQ + n);
+          *(f32x4*)(sQ + lr * 256 + n) = f32x4{(acc[a][0] + bb[0]) * scale, (acc[a][1] + bb[1]) * scale, (acc[a][2] + bb[2]) * scale, (acc[a][3] + bb[3]) * scale};
+        }
+    }
+    DB_SYNC();  // b6: cross queries ready
+    DB_SYNC();  // b7: cross-attention output in sA
+    {
+      db_gemm_regs<5>(wlane, fw, sA, lane, acc);
+      if (lr < DB_ROWS)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int n = 64 * wave + 16 * a + 4 * lq;
+          const f32x4 bb = *(const f32x4*)(sP + DB_P_BO2 + n), rs = *(const f32x4*)(sX + lr * 256 + n);
+          *(f32x4*)(sY + lr * 256 + n) = f32x4{acc[a][0] + bb[0] + rs[0], acc[a][1] + bb[1] + rs[1], acc[a][2] + bb[2] + rs[2], acc[a][3] + bb[3] + rs[3]};
+        }
+    }
+    DB_SYNC();  // b8: pre-LN2 rows ready
+    return;
+  }
 
-  // ---- P1: self-attention -------------------------------------------------------------------------
+  // ========================= row waves ===========================================================
+  const int rw = wave - 4;                 // row of the block
+  const int tr = min(r0 + rw, R - 1);      // the row this wave works for (clamped: padding waves recompute the last row)
+  const bool live = r0 + rw < R;
+  const int rt = tid - 256;
+  unsigned long long t_prev = dbg ? wall_clock64() : 0ull;
+  if (rt < 32) ((uint4*)(sA + DB_ROWS * 512))[rt] = uint4{0, 0, 0, 0};  // the zero row
+  // parameters -> LDS, 10 pieces of 1 KB by LDS-DMA (landed before this wave's younger P0 loads, i.e. before b1)
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int piece = rw + 4 * c;
+    if (piece < 10)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt.params + piece * 256 + lane * 4),
+                                       (__attribute__((address_space(3))) void*)((char*)sP + piece * 1024), 16, 0, 0);
+  }
+  // ---- P0: this wave's row of the residual stream -----------------------------------------------------
+  const int rb = (tr / beam) * beam;
+  const int* arow = anc + (size_t)tr * maxp;
+  const int my_anc = lane < step ? arow[lane] : 0;  // step <= 63 (CN_MAX_PRED 64)
   {
-    const float* row = qkv + (size_t)tr * 768 + 4 * lane;
-    f32x4 q = *(const f32x4*)row;
-    f32x4 kn = *(const f32x4*)(row + 256), vn = *(const f32x4*)(row + 512);
+    f32x4 xr;
+    if (pro.slabs == nullptr) {
+      const f32x4 e = *(const f32x4*)(pro.emb + (size_t)pro.tok[tr] * 256 + 4 * lane);
+      const f32x4 pe = *(const f32x4*)(pro.pe_row + 4 * lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xr[i] = e[i] * pro.emb_scale + pe[i];
+    } else {
+      f32x4 u[8];
+      const int ns = pro.nslab;
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl)
+        u[sl] = sl < ns ? *(const f32x4*)(pro.slabs + sl * pro.slab_stride + (size_t)tr * 256 + 4 * lane)
+                        : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 rs = *(const f32x4*)(x + (size_t)tr * 256 + 4 * lane);
+      const f32x4 bb = *(const f32x4*)(pro.b2_prev + 4 * lane);
+      f32x4 v = u[0];
+#pragma unroll
+      for (int sl = 1; sl < 8; ++sl)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += u[sl][i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] += bb[i] + rs[i];
+      xr = db_row_ln(v, pro.g3, pro.b3, lane);
+    }
+    *(f32x4*)(sX + rw * 256 + 4 * lane) = xr;
+    db_store_row(sA, rw, lane, xr, 1.0f);
+  }
+  // self-attention K/V of the ancestors: requested now, consumed after the q | k | v GEMMs
+  auto skp = [&](int s) { return kc + ((size_t)s * R + rb + __builtin_amdgcn_readlane(my_anc, s)) * 256 + 4 * lane; };
+  auto svp = [&](int s) { return vc + ((size_t)s * R + rb + __builtin_amdgcn_readlane(my_anc, s)) * 256 + 4 * lane; };
+  DbKV<DB_NB_SELF> skv[DB_DEPTH_SELF];
+  db_kv_prefetch(skv, step, skp, svp);
+  DB_STAMP(0)
+  DB_SYNC();  // b1
+  DB_SYNC();  // b2: q | k | v ready
+  DB_STAMP(1)
+
+  // ---- P1: self-attention ----------------------------------------------------------------------------
+  DbKV<DB_NB_CROSS> xkv[DB_DEPTH_CROSS];
+  const int clip = tr / beam;
+  int n_fr = lens[clip];
+  n_fr = n_fr < 1 ? 1 : (n_fr > Ta ? Ta : n_fr);
+  const bf16_t* xbase = kvx + (size_t)clip * Ta * kv_ld + kv_off + 4 * lane;
+  auto xkp = [&](int t) { return xbase + (size_t)t * kv_ld; };
+  auto xvp = [&](int t) { return xbase + (size_t)t * kv_ld + 256; };
+  {
+    f32x4 q = *(const f32x4*)(sV + (0 * DB_ROWS + rw) * 256 + 4 * lane);
+    f32x4 kn = *(const f32x4*)(sV + (1 * DB_ROWS + rw) * 256 + 4 * lane);
+    f32x4 vn = *(const f32x4*)(sV + (2 * DB_ROWS + rw) * 256 + 4 * lane);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       q[i] *= scale;
       kn[i] = (float)(bf16_t)kn[i];  // cache precision
       vn[i] = (float)(bf16_t)vn[i];
     }
-    if (r0 + wave < R) {
+    if (live) {
       cn_store4(kc + ((size_t)step * R + tr) * 256 + 4 * lane, kn[0], kn[1], kn[2], kn[3]);
       cn_store4(vc + ((size_t)step * R + tr) * 256 + 4 * lane, vn[0], vn[1], vn[2], vn[3]);
     }
-    const int rb = (tr / beam) * beam;
-    const int* arow = anc + (size_t)tr * maxp;
     float m = -INFINITY, l = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    db_attend<8>(
-        q, step, [&](int s) { return kc + ((size_t)s * R + rb + arow[s]) * 256 + 4 * lane; },
-        [&](int s) { return vc + ((size_t)s * R + rb + arow[s]) * 256 + 4 * lane; }, m, l, o);
+    db_kv_attend(skv, q, step, skp, svp, m, l, o);
+    // the audio K/V of the clip: first batches requested here, consumed after out-proj, LN1 and the query GEMM
+    db_kv_prefetch(xkv, n_fr, xkp, xvp);
     {  // own key / value
       float d = q[0] * kn[0] + q[1] * kn[1] + q[2] * kn[2] + q[3] * kn[3];
       d += __shfl_xor(d, 1);
@@ -202,79 +430,57 @@ __global__ __launch_bounds__(256, 1) void cn_dec_block_kernel(
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = o[i] * corr + p * vn[i];
     }
-    db_store_row(sA, wave, lane, o, 1.0f / l);
+    db_store_row(sA, rw, lane, o, 1.0f / l);
   }
-  __syncthreads();
+  DB_STAMP(2)
+  DB_SYNC();  // b3
+  DB_SYNC();  // b4: pre-LN1 rows ready
+  DB_STAMP(3)
 
-  // ---- P2: out-proj + residual + LN1 -----------------------------------------------------------------
-  const int mrow = min(r0 + min(lr, DB_ROWS - 1), R - 1);
-  f32x4 v[4];
-  db_gemm16(fw, sA, lane, v);
-  db_wload(Wq, wave, lane, fw);  // in flight during the residual add + LN1
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int n = 64 * wave + 16 * a + 4 * lq;
-    const f32x4 bb = *(const f32x4*)(bo + n), rs = *(const f32x4*)(x + (size_t)mrow * 256 + n);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[a][j] += bb[j] + rs[j];
-  }
-  db_layernorm(v, g1, b1, s_red, wave, lane);   // v = x1 (kept in registers as the next residual)
-  __syncthreads();
-  if (lr < DB_ROWS) db_store_tile(sA, v, wave, lane);
-  __syncthreads();
-
-  // ---- P3: cross-attention query ------------------------------------------------------------------------
+  // ---- LN1 --------------------------------------------------------------------------------------------
   {
-    f32x4 qv[4];
-    db_gemm16(fw, sA, lane, qv);
-    db_wload(Wo2, wave, lane, fw);  // in flight during the cross-attention
-    if (lr < DB_ROWS) {
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const int n = 64 * wave + 16 * a + 4 * lq;
-        const f32x4 bb = *(const f32x4*)(bq + n);
-        *(f32x4*)(sQ + lr * 256 + n) = f32x4{(qv[a][0] + bb[0]) * scale, (qv[a][1] + bb[1]) * scale,
-                                             (qv[a][2] + bb[2]) * scale, (qv[a][3] + bb[3]) * scale};
-      }
-    }
+    const f32x4 y = *(const f32x4*)(sY + rw * 256 + 4 * lane);
+    const f32x4 x1 = db_row_ln(y, sP + DB_P_G1, sP + DB_P_B1, lane);
+    *(f32x4*)(sX + rw * 256 + 4 * lane) = x1;
+    db_store_row(sA, rw, lane, x1, 1.0f);
   }
-  __syncthreads();
+  DB_STAMP(4)
+  DB_SYNC();  // b5
+  DB_SYNC();  // b6: cross queries ready
+  DB_STAMP(5)
 
-  // ---- P4: cross-attention over the clip's audio memory --------------------------------------------------
+  // ---- cross-attention over the clip's audio memory -----------------------------------------------------
   {
-    const f32x4 q = *(const f32x4*)(sQ + wave * 256 + 4 * lane);
-    const int clip = tr / beam;
-    int n = lens[clip];
-    n = n < 1 ? 1 : (n > Ta ? Ta : n);
-    const bf16_t* base = kvx + (size_t)clip * Ta * kv_ld + kv_off + 4 * lane;
+    const f32x4 q = *(const f32x4*)(sQ + rw * 256 + 4 * lane);
     float m = -INFINITY, l = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    db_attend<8>(
-        q, n, [&](int t) { return base + (size_t)t * kv_ld; }, [&](int t) { return base + (size_t)t * kv_ld + 256; }, m,
-        l, o);
-    db_store_row(sA, wave, lane, o, 1.0f / l);
+    db_kv_attend(xkv, q, n_fr, xkp, xvp, m, l, o);
+    db_store_row(sA, rw, lane, o, 1.0f / l);
   }
-  __syncthreads();
+  DB_STAMP(6)
+  DB_SYNC();  // b7
+  DB_SYNC();  // b8: pre-LN2 rows ready
+  DB_STAMP(7)
 
-  // ---- P5: out-proj + residual (x1) + LN2 -> x, xt -----------------------------------------------------------
+  // ---- LN2 -> x, xt ---------------------------------------------------------------------------------------
   {
-    f32x4 y[4];
-    db_gemm16(fw, sA, lane, y);
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int n = 64 * wave + 16 * a + 4 * lq;
-      const f32x4 bb = *(const f32x4*)(bo2 + n);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) y[a][j] += bb[j] + v[a][j];
-    }
-    db_layernorm(y, g2, b2, s_red, wave, lane);
-    if (lr < DB_ROWS && r0 + lr < R) {
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const int n = 64 * wave + 16 * a + 4 * lq;
-        *(f32x4*)(x + (size_t)(r0 + lr) * 256 + n) = y[a];
-        cn_store4(xt + (size_t)(r0 + lr) * 256 + n, y[a][0], y[a][1], y[a][2], y[a][3]);
-      }
+    const f32x4 y = *(const f32x4*)(sY + rw * 256 + 4 * lane);
+    const f32x4 x2 = db_row_ln(y, sP + DB_P_G2, sP + DB_P_B2, lane);
+    if (live) {
+      *(f32x4*)(x + (size_t)tr * 256 + 4 * lane) = x2;
+      cn_store4(xt + (size_t)tr * 256 + 4 * lane, x2[0], x2[1], x2[2], x2[3]);
     }
   }
+  DB_STAMP(8)
+  if (dbg && lane == 0 && rw == 0) atomicAdd(&g_db_prof[9], 1ull);
+}
+
+static inline int cn_dec_block_setup() {
+  static bool done = false;
+  if (!done) {
+    CN_HIP(hipFuncSetAttribute((const void*)cn_dec_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               DB_LDS_BYTES));
+    done = true;
+  }
+  return CN_OK;
 }

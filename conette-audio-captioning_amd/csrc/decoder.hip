@@ -678,12 +678,16 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
   CN_LAUNCH_CHECK();
 
   for (int step = 0; step < maxp; ++step) {
-    hipLaunchKernelGGL((cn_embed_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.cur_tok, ctx->emb, ctx->pe, step, R,
-                       sqrtf((float)d), w.x, xt);
-    CN_LAUNCH_CHECK();
+    static const int dec_fused = getenv("CN_DEC_FUSED") ? atoi(getenv("CN_DEC_FUSED")) : 0;
+    static const int dec_block = getenv("CN_DEC_BLOCK") ? atoi(getenv("CN_DEC_BLOCK")) : 1;
+    const bool block_path = std::is_same<T, bf16_t>::value && !dec_fused && dec_block;
+    if (!block_path) {  // (the block path embeds in the prologue of layer 0's block kernel)
+      hipLaunchKernelGGL((cn_embed_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.cur_tok, ctx->emb, ctx->pe, step, R,
+                         sqrtf((float)d), w.x, xt);
+      CN_LAUNCH_CHECK();
+    }
     // LN-prologue GEMMs (cn_gemm2_ln256) measured SLOWER than LN kernel + plain GEMM (decode 9.1 vs 8.2 ms at
     // R = 192: the prologue serialises load -> reduce -> LDS write in front of the MFMAs); kept as an option.
-    static const int dec_fused = getenv("CN_DEC_FUSED") ? atoi(getenv("CN_DEC_FUSED")) : 0;
     bool fused_done = false;
     if constexpr (std::is_same<T, bf16_t>::value) if (dec_fused) {
       fused_done = true;
@@ -761,29 +765,35 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
                               V, ec, s));
       }
     }
-    static const int dec_block = getenv("CN_DEC_BLOCK") ? atoi(getenv("CN_DEC_BLOCK")) : 1;
-    if constexpr (std::is_same<T, bf16_t>::value) if (!fused_done && dec_block) {
-      // default bf16 path: 5 launches per layer -- QKV GEMM, fused attention block (dec_block.h),
-      // FFN1 GEMM + GELU, FFN2 split-K slabs, slab-sum + residual + LN3
+    static const int db_debug = getenv("CN_DB_DEBUG") ? atoi(getenv("CN_DB_DEBUG")) : 0;
+    if constexpr (std::is_same<T, bf16_t>::value) if (block_path) {
+      // default bf16 path: 3 launches per layer -- fused block (embedding | previous LN3, QKV, self-attention,
+      // cross-attention: dec_block.h), FFN1 GEMM + GELU, FFN2 split-K slabs (summed by the next layer's block
+      // prologue; the last layer's by the LN3 kernel in front of the classifier)
       fused_done = true;
       int splits = ff2_splits_env();
-      if (splits < 1 || splits > FF2_SPLITS || dff % (splits * 64) != 0) splits = 1;
+      if (splits < 1 || splits > FF2_SPLITS || splits > 8 || dff % (splits * 64) != 0) splits = 1;
       const size_t slab = (size_t)R * d;
       for (int l = 0; l < NL; ++l) {
         const CnLayerW& lw = ctx->layers[l];
         bf16_t* kc = (bf16_t*)w.kc + (size_t)l * maxp * R * d;
         bf16_t* vc = (bf16_t*)w.vc + (size_t)l * maxp * R * d;
         {
-          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-          EpiBiasAct<float> eq{lw.sa_in_b, w.qkv, 3 * d, ACT_NONE};
-          CN_TRY(cn_gemm2(xt, d, (const bf16_t*)lw.sa_in_w, d, R, 3 * d, d, eq, s));
-        }
-        {
           CnProfScope ps(ctx, CONETTE_PROF_DEC_ATTN, s);
-          hipLaunchKernelGGL(cn_dec_block_kernel, dim3(cn_cdiv(R, DB_ROWS)), dim3(256), 0, s, w.qkv, kc, vc, w.anc, step,
-                             R, beam, maxp, (const bf16_t*)kvc, kv_ld, l * 2 * d, frame_lens, Ta,
-                             (const bf16_t*)lw.sa_out_w, lw.sa_out_b, lw.n1w, lw.n1b, (const bf16_t*)lw.ca_q_w,
-                             lw.ca_q_b, (const bf16_t*)lw.ca_out_w, lw.ca_out_b, lw.n2w, lw.n2b, w.x, xt, scale);
+          DbPrologue pro;
+          pro.tok = w.cur_tok, pro.emb = ctx->emb, pro.pe_row = ctx->pe + (size_t)step * d, pro.emb_scale = sqrtf((float)d);
+          pro.slabs = nullptr, pro.nslab = 0, pro.slab_stride = slab, pro.b2_prev = nullptr, pro.g3 = nullptr, pro.b3 = nullptr;
+          if (l > 0) {
+            const CnLayerW& pw = ctx->layers[l - 1];
+            pro.slabs = w.slabs, pro.nslab = splits, pro.b2_prev = pw.ff2_b, pro.g3 = pw.n3w, pro.b3 = pw.n3b;
+          }
+          DbWeights wt;
+          wt.stream = (const bf16_t*)lw.blk_w;
+          wt.params = lw.blk_p;
+          CN_TRY(cn_dec_block_setup());
+          hipLaunchKernelGGL(cn_dec_block_kernel, dim3(cn_cdiv(R, DB_ROWS)), dim3(512), DB_LDS_BYTES, s, pro, wt, kc, vc,
+                             w.anc, step, R, beam, maxp, (const bf16_t*)kvc, kv_ld, l * 2 * d, frame_lens, Ta, w.x, xt,
+                             scale, db_debug);
           CN_LAUNCH_CHECK();
         }
         {
@@ -796,12 +806,13 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
           EpiSlab e2{w.slabs, d, slab};
           CN_TRY(cn_gemm2(ffh, dff, (const bf16_t*)lw.ff2_w, dff, R, d, dff, e2, s, splits));
         }
-        {
-          CnProfScope ps(ctx, CONETTE_PROF_DEC_MISC, s);
-          hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.slabs, splits, slab, lw.ff2_b, w.x,
-                             lw.n3w, lw.n3b, R, w.x, xt);
-          CN_LAUNCH_CHECK();
-        }
+      }
+      {
+        CnProfScope ps(ctx, CONETTE_PROF_DEC_MISC, s);
+        const CnLayerW& lw = ctx->layers[NL - 1];
+        hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.slabs, splits, slab, lw.ff2_b, w.x,
+                           lw.n3w, lw.n3b, R, w.x, xt);
+        CN_LAUNCH_CHECK();
       }
       {
         CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
@@ -1080,5 +1091,14 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
   e->exec = exec;
   e->graph = graph;
   CN_HIP(hipGraphLaunch(exec, s));
+  return CN_OK;
+}
+
+extern "C" int conette_debug_dbprof(unsigned long long* out16, int reset) {
+  if (out16) CN_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_db_prof), 128));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    CN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_db_prof), z, 128));
+  }
   return CN_OK;
 }
