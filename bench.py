@@ -114,7 +114,7 @@ def main() -> None:
         from conette_amd.engine import make_partitioned_streams
         s_enc, s_dec = make_partitioned_streams(dev, decode_share=share)
     else:
-        prio = int(os.environ.get("CN_DEC_PRIO", "0"))  # decode stream priority (negative = higher)
+        prio = int(os.environ.get("CN_DEC_PRIO", "-1"))  # decode stream priority (negative = higher)
         s_enc, s_dec = torch.cuda.Stream(dev), torch.cuda.Stream(dev, priority=prio)
     fe_buf = [eng.decode_input_buffer(B, t_audio, beam, max_pred, slot=i) for i in range(2)]
     clip_buf = [torch.empty((B, 527), dtype=torch.float32, device=dev) for _ in range(2)]

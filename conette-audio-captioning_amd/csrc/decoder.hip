@@ -545,6 +545,223 @@ __global__ __launch_bounds__(256) void cn_search_step2_kernel(const float* __res
   }
 }
 
+// Same step, register path (V <= 8192): 1024 threads per clip, every thread keeps its <= 8 logits of each live row
+// in registers (one coalesced pass over the logits, nothing staged in LDS: the kernel starts on any CU with a free
+// workgroup slot while the encoder's blocks hold the LDS), block reductions for the log-softmax, per-thread sorted
+// top-k, then a two-level merge: k rounds of wave arg-max inside each wave, and the 16 x k wave winners merged
+// redundantly by every wave.  Ties resolve to the lowest flat index exactly like the kernels above.
+#define S3_T 1024
+#define S3_VPT 8
+template <int NR>
+__global__ __launch_bounds__(S3_T) void cn_search_step3_kernel(const float* __restrict__ logits, int ldv, int V, int beam,
+                                                               int maxp, int step, int min_pred, int eos_id,
+                                                               const uint8_t* __restrict__ forbid, int* n_active,
+                                                               int* slot, float* sum_lp, int* prefix, int* anc,
+                                                               int* cur_tok, int* out_preds, float* out_avg,
+                                                               int* out_len, int* trace_sel, float* trace_val) {
+  __shared__ float s_redm[NR][16], s_reds[NR][16];
+  __shared__ ValIdx s_cand[16][CN_MAX_BEAM];
+  __shared__ int s_mask[NR][CN_MAX_PRED + 1];
+  __shared__ float s_base[CN_MAX_BEAM];
+  __shared__ float s_selv[CN_MAX_BEAM];
+  __shared__ int s_self[CN_MAX_BEAM];
+  __shared__ int s_prefix[CN_MAX_BEAM][CN_MAX_PRED + 1];
+  __shared__ int s_anc[CN_MAX_BEAM][CN_MAX_PRED];
+  __shared__ int s_slot[CN_MAX_BEAM];
+  __shared__ int s_newpos[CN_MAX_BEAM];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int k = n_active[b];
+  if (k == 0) return;
+  const int rb = b * beam;
+  const int nrows = step == 0 ? 1 : k;
+
+  float val[NR][S3_VPT];
+#pragma unroll
+  for (int p = 0; p < NR; ++p)
+#pragma unroll
+    for (int sl = 0; sl < S3_VPT; ++sl) {
+      const int v = sl * S3_T + tid;
+      val[p][sl] = (p < nrows && v < V) ? logits[(size_t)(rb + p) * ldv + v] : -INFINITY;
+    }
+  for (int i = tid; i < k * (maxp + 1); i += S3_T) s_prefix[i / (maxp + 1)][i % (maxp + 1)] = prefix[(size_t)rb * (maxp + 1) + i];
+  for (int i = tid; i < k * maxp; i += S3_T) s_anc[i / maxp][i % maxp] = anc[(size_t)rb * maxp + i];
+  if (tid < k) {
+    s_slot[tid] = slot[rb + tid];
+    s_base[tid] = step == 0 ? 0.f : sum_lp[rb + tid];
+  }
+  __syncthreads();
+  // forbid-repeat (beam.py:146-156): which prefix tokens are masked; EOS floor (beam.py:129-130) in slot step + 1
+  for (int i = tid; i < nrows * (step + 2); i += S3_T) {
+    const int p = i / (step + 2), j = i % (step + 2);
+    int tok = -1;
+    if (j == step + 1) {
+      if (step < min_pred) tok = eos_id;
+    } else if (forbid != nullptr) {
+      const int t = s_prefix[p][j];
+      if (forbid[t]) tok = t;
+    }
+    s_mask[p][j] = tok;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < NR; ++p)
+    if (p < nrows)
+      for (int j = 0; j < step + 2; ++j) {
+        const int tok = s_mask[p][j];
+        if (tok >= 0 && (tok & (S3_T - 1)) == tid) {
+#pragma unroll
+          for (int sl = 0; sl < S3_VPT; ++sl)
+            if (sl == (tok >> 10)) val[p][sl] = -INFINITY;
+        }
+      }
+  // log-softmax statistics of every live row
+#pragma unroll
+  for (int p = 0; p < NR; ++p)
+    if (p < nrows) {
+      float mx = val[p][0];
+#pragma unroll
+      for (int sl = 1; sl < S3_VPT; ++sl) mx = fmaxf(mx, val[p][sl]);
+      mx = cn_wave_max(mx);
+      if (lane == 0) s_redm[p][wv] = mx;
+    }
+  __syncthreads();
+  float rmx[NR], rlg[NR];
+#pragma unroll
+  for (int p = 0; p < NR; ++p)
+    if (p < nrows) {
+      float mx = s_redm[p][0];
+#pragma unroll
+      for (int w = 1; w < 16; ++w) mx = fmaxf(mx, s_redm[p][w]);
+      rmx[p] = mx;
+      float sm = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < S3_VPT; ++sl) sm += expf(val[p][sl] - mx);
+      sm = cn_wave_sum(sm);
+      if (lane == 0) s_reds[p][wv] = sm;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < NR; ++p)
+    if (p < nrows) {
+      float sm = s_reds[p][0];
+#pragma unroll
+      for (int w = 1; w < 16; ++w) sm += s_reds[p][w];
+      rlg[p] = logf(sm);
+    }
+  // per-thread sorted top-k (strict > keeps the earlier = lower flat index first on ties)
+  float bv[CN_MAX_BEAM];
+  int bi[CN_MAX_BEAM];
+#pragma unroll
+  for (int j = 0; j < CN_MAX_BEAM; ++j) {
+    bv[j] = -INFINITY;
+    bi[j] = 0x7fffffff;
+  }
+#pragma unroll
+  for (int p = 0; p < NR; ++p)
+    if (p < nrows) {
+      const float base = s_base[p];
+#pragma unroll
+      for (int sl = 0; sl < S3_VPT; ++sl) {
+        const int v = sl * S3_T + tid;
+        float cand = (val[p][sl] - rmx[p]) - rlg[p];
+        if (step != 0) cand = base + cand;
+        if (v < V && cand > bv[CN_MAX_BEAM - 1]) {
+          bv[CN_MAX_BEAM - 1] = cand;
+          bi[CN_MAX_BEAM - 1] = p * V + v;
+#pragma unroll
+          for (int j = CN_MAX_BEAM - 1; j > 0; --j) {
+            if (bv[j] > bv[j - 1]) {
+              const float tv = bv[j];
+              bv[j] = bv[j - 1];
+              bv[j - 1] = tv;
+              const int ti = bi[j];
+              bi[j] = bi[j - 1];
+              bi[j - 1] = ti;
+            }
+          }
+        }
+      }
+    }
+  // level 1: the wave's k best
+  {
+    int head = 0;
+#pragma unroll
+    for (int c = 0; c < CN_MAX_BEAM; ++c)
+      if (c < k) {
+        ValIdx mine{-INFINITY, 0x7fffffff};
+#pragma unroll
+        for (int j = 0; j < CN_MAX_BEAM; ++j)
+          if (head == j) mine = ValIdx{bv[j], bi[j]};
+        const ValIdx best = vi_wave(mine);
+        if (mine.i == best.i && mine.i != 0x7fffffff) ++head;
+        if (lane == 0) s_cand[wv][c] = best;
+      }
+  }
+  __syncthreads();
+  // level 2: merge the 16 x k wave winners (every wave computes the same result)
+  {
+    const int nc = 16 * k;  // <= 128: two entries per lane
+    ValIdx t0{-INFINITY, 0x7fffffff}, t1{-INFINITY, 0x7fffffff};
+    if (lane < nc) t0 = s_cand[lane / k][lane % k];
+    if (lane + 64 < nc) t1 = s_cand[(lane + 64) / k][(lane + 64) % k];
+#pragma unroll
+    for (int c = 0; c < CN_MAX_BEAM; ++c)
+      if (c < k) {
+        const ValIdx best = vi_wave(vi_better(t0, t1));
+        if (best.i != 0x7fffffff) {
+          if (t0.i == best.i) t0 = ValIdx{-INFINITY, 0x7fffffff};
+          else if (t1.i == best.i) t1 = ValIdx{-INFINITY, 0x7fffffff};
+        }
+        if (tid == 0) {
+          s_selv[c] = best.v;
+          s_self[c] = best.i;
+        }
+      }
+  }
+  __syncthreads();
+  // bookkeeping (beam.py:164-203)
+  if (tid < k) {
+    const size_t ti = ((size_t)step * gridDim.x + b) * beam + tid;
+    if (trace_sel) {
+      trace_sel[2 * ti] = s_self[tid] / V;
+      trace_sel[2 * ti + 1] = s_self[tid] % V;
+    }
+    if (trace_val) trace_val[ti] = s_selv[tid];
+  }
+  if (tid == 0) {
+    int cnt = 0;
+    for (int c = 0; c < k; ++c) {
+      const int token = s_self[c] % V;
+      const bool fin = (token == eos_id) || (step == maxp - 1);
+      s_newpos[c] = fin ? -1 : cnt++;
+    }
+    n_active[b] = cnt;
+  }
+  __syncthreads();
+  for (int c = 0; c < k; ++c) {
+    const int flat = s_self[c];
+    const int parent = flat / V, token = flat % V;
+    const int np = s_newpos[c];
+    if (np < 0) {
+      const int sl = rb + s_slot[c];
+      for (int j = tid; j <= step; j += S3_T) out_preds[(size_t)sl * maxp + j] = (j == step) ? token : s_prefix[parent][j + 1];
+      if (tid == 0) {
+        out_avg[sl] = s_selv[c] / (float)(step + 1);
+        out_len[sl] = step + 1;
+      }
+    } else {
+      const int dst = rb + np;
+      for (int j = tid; j <= step + 1; j += S3_T) prefix[(size_t)dst * (maxp + 1) + j] = (j == step + 1) ? token : s_prefix[parent][j];
+      for (int j = tid; j <= step; j += S3_T) anc[(size_t)dst * maxp + j] = (j == step) ? parent : s_anc[parent][j];
+      if (tid == 0) {
+        sum_lp[dst] = s_selv[c];
+        slot[dst] = s_slot[c];
+        cur_tok[dst] = token;
+      }
+    }
+  }
+}
+
 // best beam per clip (beam.py:205-220): first max of the averaged log-prob; pred_size via atomicMax
 __global__ void cn_finalize_kernel(int B, int beam, int maxp, int eos_id, const int* __restrict__ out_preds,
                                    const float* __restrict__ out_avg, const int* __restrict__ out_len,
@@ -909,7 +1126,17 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
       CN_HIP(hipMemcpyAsync(step0_logits, w.logits, (size_t)R * w.ldv * 4, hipMemcpyDeviceToDevice, s));
     CnProfScope ps_search(ctx, CONETTE_PROF_SEARCH, s);
     const size_t search_smem = (size_t)beam * V * sizeof(float);
-    if (search_smem <= 120 * 1024) {
+    static const int search_mode = getenv("CN_SEARCH_MODE") ? atoi(getenv("CN_SEARCH_MODE")) : 3;
+    if (search_mode >= 3 && V <= S3_T * S3_VPT) {
+      if (beam <= 4)
+        hipLaunchKernelGGL(cn_search_step3_kernel<4>, dim3(B), dim3(S3_T), 0, s, w.logits, w.ldv, V, beam, maxp, step,
+                           min_pred, cfg.eos_id, forbid, w.n_active, w.slot, w.sum_lp, w.prefix, w.anc, w.cur_tok,
+                           mult_preds, mult_lprobs, w.out_len, trace_sel, trace_val);
+      else
+        hipLaunchKernelGGL(cn_search_step3_kernel<8>, dim3(B), dim3(S3_T), 0, s, w.logits, w.ldv, V, beam, maxp, step,
+                           min_pred, cfg.eos_id, forbid, w.n_active, w.slot, w.sum_lp, w.prefix, w.anc, w.cur_tok,
+                           mult_preds, mult_lprobs, w.out_len, trace_sel, trace_val);
+    } else if (search_mode >= 2 && search_smem <= 120 * 1024) {
       static bool configured = false;
       if (!configured) {
         CN_HIP(hipFuncSetAttribute((const void*)cn_search_step2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
