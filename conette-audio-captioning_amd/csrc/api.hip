@@ -120,6 +120,19 @@ __global__ void pk_block_stream(PkBlockSrc src, bf16_t* __restrict__ dst) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) dst[(size_t)u * 8 + i] = (bf16_t)s[i];
 }
+// decoder FFN stream (dec_ffn.h): unit u = (((((c*2 + t)*4 + w)*4 + qd)*4 + a)*2 + kk)*64 + lane;
+// t = 0: W1[c*256 + 64w + 16a + (lane & 15)][32(2qd + kk) + 8(lane >> 4) .. +8]        (W1: [dff][256])
+// t = 1: W2[64w + 16a + (lane & 15)][c*256 + 32(2qd + kk) + 8(lane >> 4) .. +8]        (W2: [256][dff])
+__global__ void pk_ffn_stream(const float* __restrict__ W1, const float* __restrict__ W2, int dff, bf16_t* __restrict__ dst) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= (dff / 256) * 2 * 8192) return;
+  const int lane = u & 63, kk = (u >> 6) & 1, a = (u >> 7) & 3, qd = (u >> 9) & 3, w = (u >> 11) & 3, t = (u >> 13) & 1,
+            c = u >> 14;
+  const int r = 64 * w + 16 * a + (lane & 15), k = 32 * (2 * qd + kk) + 8 * (lane >> 4);
+  const float* s = t == 0 ? W1 + (size_t)(c * 256 + r) * 256 + k : W2 + (size_t)r * dff + c * 256 + k;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dst[(size_t)u * 8 + i] = (bf16_t)s[i];
+}
 __global__ void pk_bn(const float* w, const float* b, const float* mean, const float* var, float* scale, float* shift,
                       int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -383,6 +396,17 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
       lw.n3b = B.f32(p + "norm3.bias", d);
       lw.blk_w = nullptr;
       lw.blk_p = nullptr;
+      lw.ffn_w = nullptr;
+      if (ctx->esize == 2 && dff % 256 == 0 && dff <= 2048) {
+        bf16_t* fwp = (bf16_t*)B.alloc((size_t)2 * dff * d * 2);
+        const float* w1 = B.find(p + "linear1.weight", (int64_t)dff * d);
+        const float* w2 = B.find(p + "linear2.weight", (int64_t)dff * d);
+        if (w1 && w2) {
+          const int units = (dff / 256) * 2 * 8192;
+          hipLaunchKernelGGL(pk_ffn_stream, dim3(units / 256), dim3(256), 0, 0, w1, w2, dff, fwp);
+          lw.ffn_w = fwp;
+        }
+      }
       if (ctx->esize == 2) {
         bf16_t* bw = (bf16_t*)B.alloc((size_t)6 * d * d * 2);
         const float* ipw = B.find(p + "self_attn.in_proj_weight", (int64_t)3 * d * d);

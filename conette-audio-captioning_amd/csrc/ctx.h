@@ -52,6 +52,9 @@ struct CnLayerW {
   // cross out-proj) re-ordered into the MFMA-fragment stream of dec_block.h:
   // [matrix 6][wave 4][quarter 4][piece (a, kk) 8][lane 64][8 bf16]
   const void* blk_w;
+  // bf16, d_ff % 256 == 0, d_ff <= 2048: linear1 / linear2 as per-hidden-chunk fragment streams of dec_ffn.h:
+  // [chunk d_ff/256][tile 2 (W1 rows of the chunk | W2 columns of the chunk)][wave 4][quarter 4][piece 8][lane 64][8 bf16]
+  const void* ffn_w;
   const float* blk_p;  // 2560 floats: in_proj bias 768 | bo | bq | bo2 | g1 | b1 | g2 | b2 (one contiguous LDS fill)
 };
 

@@ -16,7 +16,7 @@
 #include <type_traits>
 
 #include "gemm2.h"
-#include "dec_block.h"
+#include "dec_ffn.h"
 
 #define CN_MAX_BEAM 8
 #define CN_MAX_PRED 64
@@ -990,6 +990,10 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
       fused_done = true;
       int splits = ff2_splits_env();
       if (splits < 1 || splits > FF2_SPLITS || splits > 8 || dff % (splits * 64) != 0) splits = 1;
+      // fused FFN (dec_ffn.h): one launch per layer, one slab per 256-wide hidden chunk
+      static const int ffn_env = getenv("CN_DEC_FFN") ? atoi(getenv("CN_DEC_FFN")) : 1;
+      const bool ffn_fused = ffn_env && ctx->layers[0].ffn_w != nullptr && dff / 256 <= FF2_SPLITS;
+      if (ffn_fused) splits = dff / 256;
       const size_t slab = (size_t)R * d;
       for (int l = 0; l < NL; ++l) {
         const CnLayerW& lw = ctx->layers[l];
@@ -1013,15 +1017,22 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
                              scale, db_debug);
           CN_LAUNCH_CHECK();
         }
-        {
+        if (ffn_fused) {
           CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-          EpiBiasAct<bf16_t> e1{lw.ff1_b, ffh, dff, ACT_GELU_FAST};
-          CN_TRY(cn_gemm2(xt, d, (const bf16_t*)lw.ff1_w, d, R, dff, d, e1, s));
-        }
-        {
-          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-          EpiSlab e2{w.slabs, d, slab};
-          CN_TRY(cn_gemm2(ffh, dff, (const bf16_t*)lw.ff2_w, dff, R, d, dff, e2, s, splits));
+          hipLaunchKernelGGL(cn_dec_ffn_kernel, dim3(cn_cdiv(R, DF_ROWS), dff / 256), dim3(256), 0, s, (const bf16_t*)xt, R,
+                             (const bf16_t*)lw.ffn_w, lw.ff1_b, w.slabs, slab);
+          CN_LAUNCH_CHECK();
+        } else {
+          {
+            CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+            EpiBiasAct<bf16_t> e1{lw.ff1_b, ffh, dff, ACT_GELU_FAST};
+            CN_TRY(cn_gemm2(xt, d, (const bf16_t*)lw.ff1_w, d, R, dff, d, e1, s));
+          }
+          {
+            CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+            EpiSlab e2{w.slabs, d, slab};
+            CN_TRY(cn_gemm2(ffh, dff, (const bf16_t*)lw.ff2_w, dff, R, d, dff, e2, s, splits));
+          }
         }
       }
       {
