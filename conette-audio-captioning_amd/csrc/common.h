@@ -108,6 +108,38 @@ __device__ __forceinline__ float cn_wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// DPP lane permutes (VALU, no LDS crossbar round trip like ds_bpermute): quad_perm [1,0,3,2] = 0xB1,
+// quad_perm [2,3,0,1] = 0x4E, row_half_mirror (i <-> 7-i in each 8) = 0x141, row_mirror (i <-> 15-i in each 16) = 0x140.
+// For commutative reductions the mirrors pair a lane with one from the other half exactly like xor 4 / xor 8.
+template <int CTRL> __device__ __forceinline__ float cn_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> __device__ __forceinline__ int cn_dpp(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+// sum over each aligned group of 8 / 16 lanes, result in every lane of the group
+__device__ __forceinline__ float cn_sum8_dpp(float v) {
+  v += cn_dpp<0xB1>(v);
+  v += cn_dpp<0x4E>(v);
+  v += cn_dpp<0x141>(v);
+  return v;
+}
+__device__ __forceinline__ float cn_wave_sum_dpp(float v) {
+  v = cn_sum8_dpp(v);
+  v += cn_dpp<0x140>(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+__device__ __forceinline__ float cn_wave_max_dpp(float v) {
+  v = fmaxf(v, cn_dpp<0xB1>(v));
+  v = fmaxf(v, cn_dpp<0x4E>(v));
+  v = fmaxf(v, cn_dpp<0x141>(v));
+  v = fmaxf(v, cn_dpp<0x140>(v));
+  v = fmaxf(v, __shfl_xor(v, 16));
+  v = fmaxf(v, __shfl_xor(v, 32));
+  return v;
+}
 __device__ __forceinline__ float cn_wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));

@@ -59,9 +59,7 @@ __device__ __forceinline__ void db_kv_consume(const DbKV<NB>& kv, const f32x4& q
 #pragma unroll
   for (int u = 0; u < NB; ++u) {
     float d = q[0] * (float)kv.k[u][0] + q[1] * (float)kv.k[u][1] + q[2] * (float)kv.k[u][2] + q[3] * (float)kv.k[u][3];
-    d += __shfl_xor(d, 1);
-    d += __shfl_xor(d, 2);
-    d += __shfl_xor(d, 4);
+    d = cn_sum8_dpp(d);
     sc[u] = (s0 + u < n_keys) ? d : -INFINITY;
   }
   float mb = sc[0];
@@ -214,11 +212,11 @@ __device__ __forceinline__ void db_gemm_regs(const DbStream& wlane, bf16x8 (&fw)
 
 // row LayerNorm (eps 1e-5) of a lane's 4 columns of one 256-wide row
 __device__ __forceinline__ f32x4 db_row_ln(const f32x4& v, const float* g, const float* b, int lane) {
-  const float mean = cn_wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+  const float mean = cn_wave_sum_dpp(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
   float s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) s2 = fmaf(v[i] - mean, v[i] - mean, s2);
-  const float rstd = __builtin_amdgcn_rsqf(cn_wave_sum(s2) * (1.0f / 256.0f) + 1e-5f);
+  const float rstd = __builtin_amdgcn_rsqf(cn_wave_sum_dpp(s2) * (1.0f / 256.0f) + 1e-5f);
   const f32x4 gg = *(const f32x4*)(g + 4 * lane), bb = *(const f32x4*)(b + 4 * lane);
   f32x4 r;
 #pragma unroll
@@ -421,9 +419,7 @@ __global__ __launch_bounds__(512, 1) void cn_dec_block_kernel(
     db_kv_prefetch(xkv, n_fr, xkp, xvp);
     {  // own key / value
       float d = q[0] * kn[0] + q[1] * kn[1] + q[2] * kn[2] + q[3] * kn[3];
-      d += __shfl_xor(d, 1);
-      d += __shfl_xor(d, 2);
-      d += __shfl_xor(d, 4);
+      d = cn_sum8_dpp(d);
       const float mn = fmaxf(m, d);
       const float corr = __expf(m - mn), p = __expf(d - mn);
       l = l * corr + p;

@@ -246,6 +246,24 @@ struct ValIdx {
 __device__ __forceinline__ ValIdx vi_better(ValIdx a, ValIdx b) {  // larger value, then lower flat index
   return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
 }
+template <int CTRL> __device__ __forceinline__ ValIdx vi_dpp_step(ValIdx x) {
+  return vi_better(x, ValIdx{cn_dpp<CTRL>(x.v), cn_dpp<CTRL>(x.i)});
+}
+// same result as vi_wave (the order relation is total), 4 of the 6 exchange steps on DPP
+__device__ __forceinline__ ValIdx vi_wave_dpp(ValIdx x) {
+  x = vi_dpp_step<0xB1>(x);
+  x = vi_dpp_step<0x4E>(x);
+  x = vi_dpp_step<0x141>(x);
+  x = vi_dpp_step<0x140>(x);
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {
+    ValIdx y;
+    y.v = __shfl_xor(x.v, o);
+    y.i = __shfl_xor(x.i, o);
+    x = vi_better(x, y);
+  }
+  return x;
+}
 __device__ __forceinline__ ValIdx vi_wave(ValIdx x) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -551,17 +569,23 @@ __global__ __launch_bounds__(256) void cn_search_step2_kernel(const float* __res
 // top-k, then a two-level merge: k rounds of wave arg-max inside each wave, and the 16 x k wave winners merged
 // redundantly by every wave.  Ties resolve to the lowest flat index exactly like the kernels above.
 #define S3_T 1024
-#define S3_VPT 8
-template <int NR>
+#define S3_VPT 8  // most logits per thread: V <= 8192
+__device__ unsigned long long g_s3_prof[16];
+#define S3_STAMP(i)                                            \
+  if (dbg) {                                                   \
+    const unsigned long long t_ = wall_clock64();              \
+    if (tid == 0 && b == 0) atomicAdd(&g_s3_prof[i], t_ - t_prev); \
+    t_prev = t_;                                               \
+  }
+template <int NR, int VPT>
 __global__ __launch_bounds__(S3_T) void cn_search_step3_kernel(const float* __restrict__ logits, int ldv, int V, int beam,
                                                                int maxp, int step, int min_pred, int eos_id,
                                                                const uint8_t* __restrict__ forbid, int* n_active,
                                                                int* slot, float* sum_lp, int* prefix, int* anc,
                                                                int* cur_tok, int* out_preds, float* out_avg,
-                                                               int* out_len, int* trace_sel, float* trace_val) {
+                                                               int* out_len, int* trace_sel, float* trace_val, int dbg) {
   __shared__ float s_redm[NR][16], s_reds[NR][16];
   __shared__ ValIdx s_cand[16][CN_MAX_BEAM];
-  __shared__ int s_mask[NR][CN_MAX_PRED + 1];
   __shared__ float s_base[CN_MAX_BEAM];
   __shared__ float s_selv[CN_MAX_BEAM];
   __shared__ int s_self[CN_MAX_BEAM];
@@ -570,58 +594,67 @@ __global__ __launch_bounds__(S3_T) void cn_search_step3_kernel(const float* __re
   __shared__ int s_slot[CN_MAX_BEAM];
   __shared__ int s_newpos[CN_MAX_BEAM];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int k = n_active[b];
-  if (k == 0) return;
+  unsigned long long t_prev = dbg ? wall_clock64() : 0ull;
   const int rb = b * beam;
-  const int nrows = step == 0 ? 1 : k;
-
-  float val[NR][S3_VPT];
+  // every global read is issued up front and none depends on another (rows that turn out to be dead are read
+  // and ignored): the step is a chain of dependent launches, a second round trip costs more than the bytes
+  const int k_ld = n_active[b];
+  const int rows_ld = step == 0 ? 1 : beam;
+  float val[NR][VPT];
+  bool fb[VPT];
+#pragma unroll
+  for (int sl = 0; sl < VPT; ++sl) {
+    const int v = sl * S3_T + tid;
+    fb[sl] = forbid != nullptr && v < V && forbid[v] != 0;
+  }
 #pragma unroll
   for (int p = 0; p < NR; ++p)
 #pragma unroll
-    for (int sl = 0; sl < S3_VPT; ++sl) {
+    for (int sl = 0; sl < VPT; ++sl) {
       const int v = sl * S3_T + tid;
-      val[p][sl] = (p < nrows && v < V) ? logits[(size_t)(rb + p) * ldv + v] : -INFINITY;
+      val[p][sl] = (p < rows_ld && v < V) ? logits[(size_t)(rb + p) * ldv + v] : -INFINITY;
     }
-  for (int i = tid; i < k * (maxp + 1); i += S3_T) s_prefix[i / (maxp + 1)][i % (maxp + 1)] = prefix[(size_t)rb * (maxp + 1) + i];
-  for (int i = tid; i < k * maxp; i += S3_T) s_anc[i / maxp][i % maxp] = anc[(size_t)rb * maxp + i];
-  if (tid < k) {
+  for (int i = tid; i < beam * (maxp + 1); i += S3_T) s_prefix[i / (maxp + 1)][i % (maxp + 1)] = prefix[(size_t)rb * (maxp + 1) + i];
+  for (int i = tid; i < beam * maxp; i += S3_T) s_anc[i / maxp][i % maxp] = anc[(size_t)rb * maxp + i];
+  if (tid < beam) {
     s_slot[tid] = slot[rb + tid];
     s_base[tid] = step == 0 ? 0.f : sum_lp[rb + tid];
   }
+  const int k = k_ld;
+  if (k == 0) return;
+  S3_STAMP(0)
+  const int nrows = step == 0 ? 1 : k;
   __syncthreads();
-  // forbid-repeat (beam.py:146-156): which prefix tokens are masked; EOS floor (beam.py:129-130) in slot step + 1
-  for (int i = tid; i < nrows * (step + 2); i += S3_T) {
-    const int p = i / (step + 2), j = i % (step + 2);
-    int tok = -1;
-    if (j == step + 1) {
-      if (step < min_pred) tok = eos_id;
-    } else if (forbid != nullptr) {
-      const int t = s_prefix[p][j];
-      if (forbid[t]) tok = t;
-    }
-    s_mask[p][j] = tok;
-  }
-  __syncthreads();
+  S3_STAMP(1)
+  // forbid-repeat (beam.py:146-156) over the row's prefix and EOS floor (beam.py:129-130), on the owner's registers
 #pragma unroll
   for (int p = 0; p < NR; ++p)
-    if (p < nrows)
-      for (int j = 0; j < step + 2; ++j) {
-        const int tok = s_mask[p][j];
-        if (tok >= 0 && (tok & (S3_T - 1)) == tid) {
+    if (p < nrows) {
+      for (int j = 0; j <= step; ++j) {
+        const int tok = s_prefix[p][j];
+        if ((((unsigned)tok & (S3_T - 1)) >> 6) == (unsigned)wv) {  // wave-uniform: only the owner wave looks closer
+          if ((tok & (S3_T - 1)) == tid) {
 #pragma unroll
-          for (int sl = 0; sl < S3_VPT; ++sl)
-            if (sl == (tok >> 10)) val[p][sl] = -INFINITY;
+            for (int sl = 0; sl < VPT; ++sl)
+              if (sl == (tok >> 10) && fb[sl]) val[p][sl] = -INFINITY;
+          }
         }
       }
+      if (step < min_pred && (eos_id & (S3_T - 1)) == tid) {
+#pragma unroll
+        for (int sl = 0; sl < VPT; ++sl)
+          if (sl == (eos_id >> 10)) val[p][sl] = -INFINITY;
+      }
+    }
+  S3_STAMP(2)
   // log-softmax statistics of every live row
 #pragma unroll
   for (int p = 0; p < NR; ++p)
     if (p < nrows) {
       float mx = val[p][0];
 #pragma unroll
-      for (int sl = 1; sl < S3_VPT; ++sl) mx = fmaxf(mx, val[p][sl]);
-      mx = cn_wave_max(mx);
+      for (int sl = 1; sl < VPT; ++sl) mx = fmaxf(mx, val[p][sl]);
+      mx = cn_wave_max_dpp(mx);
       if (lane == 0) s_redm[p][wv] = mx;
     }
   __syncthreads();
@@ -635,8 +668,8 @@ __global__ __launch_bounds__(S3_T) void cn_search_step3_kernel(const float* __re
       rmx[p] = mx;
       float sm = 0.f;
 #pragma unroll
-      for (int sl = 0; sl < S3_VPT; ++sl) sm += expf(val[p][sl] - mx);
-      sm = cn_wave_sum(sm);
+      for (int sl = 0; sl < VPT; ++sl) sm += __expf(val[p][sl] - mx);
+      sm = cn_wave_sum_dpp(sm);
       if (lane == 0) s_reds[p][wv] = sm;
     }
   __syncthreads();
@@ -648,11 +681,12 @@ __global__ __launch_bounds__(S3_T) void cn_search_step3_kernel(const float* __re
       for (int w = 1; w < 16; ++w) sm += s_reds[p][w];
       rlg[p] = logf(sm);
     }
+  S3_STAMP(3)
   // per-thread sorted top-k (strict > keeps the earlier = lower flat index first on ties)
-  float bv[CN_MAX_BEAM];
-  int bi[CN_MAX_BEAM];
+  float bv[NR];
+  int bi[NR];
 #pragma unroll
-  for (int j = 0; j < CN_MAX_BEAM; ++j) {
+  for (int j = 0; j < NR; ++j) {
     bv[j] = -INFINITY;
     bi[j] = 0x7fffffff;
   }
@@ -661,15 +695,15 @@ __global__ __launch_bounds__(S3_T) void cn_search_step3_kernel(const float* __re
     if (p < nrows) {
       const float base = s_base[p];
 #pragma unroll
-      for (int sl = 0; sl < S3_VPT; ++sl) {
+      for (int sl = 0; sl < VPT; ++sl) {
         const int v = sl * S3_T + tid;
         float cand = (val[p][sl] - rmx[p]) - rlg[p];
         if (step != 0) cand = base + cand;
-        if (v < V && cand > bv[CN_MAX_BEAM - 1]) {
-          bv[CN_MAX_BEAM - 1] = cand;
-          bi[CN_MAX_BEAM - 1] = p * V + v;
+        if (v < V && cand > bv[NR - 1]) {
+          bv[NR - 1] = cand;
+          bi[NR - 1] = p * V + v;
 #pragma unroll
-          for (int j = CN_MAX_BEAM - 1; j > 0; --j) {
+          for (int j = NR - 1; j > 0; --j) {
             if (bv[j] > bv[j - 1]) {
               const float tv = bv[j];
               bv[j] = bv[j - 1];
@@ -682,22 +716,24 @@ __global__ __launch_bounds__(S3_T) void cn_search_step3_kernel(const float* __re
         }
       }
     }
+  S3_STAMP(4)
   // level 1: the wave's k best
   {
     int head = 0;
 #pragma unroll
-    for (int c = 0; c < CN_MAX_BEAM; ++c)
+    for (int c = 0; c < NR; ++c)
       if (c < k) {
         ValIdx mine{-INFINITY, 0x7fffffff};
 #pragma unroll
-        for (int j = 0; j < CN_MAX_BEAM; ++j)
+        for (int j = 0; j < NR; ++j)
           if (head == j) mine = ValIdx{bv[j], bi[j]};
-        const ValIdx best = vi_wave(mine);
+        const ValIdx best = vi_wave_dpp(mine);
         if (mine.i == best.i && mine.i != 0x7fffffff) ++head;
         if (lane == 0) s_cand[wv][c] = best;
       }
   }
   __syncthreads();
+  S3_STAMP(5)
   // level 2: merge the 16 x k wave winners (every wave computes the same result)
   {
     const int nc = 16 * k;  // <= 128: two entries per lane
@@ -705,9 +741,9 @@ __global__ __launch_bounds__(S3_T) void cn_search_step3_kernel(const float* __re
     if (lane < nc) t0 = s_cand[lane / k][lane % k];
     if (lane + 64 < nc) t1 = s_cand[(lane + 64) / k][(lane + 64) % k];
 #pragma unroll
-    for (int c = 0; c < CN_MAX_BEAM; ++c)
+    for (int c = 0; c < NR; ++c)
       if (c < k) {
-        const ValIdx best = vi_wave(vi_better(t0, t1));
+        const ValIdx best = vi_wave_dpp(vi_better(t0, t1));
         if (best.i != 0x7fffffff) {
           if (t0.i == best.i) t0 = ValIdx{-INFINITY, 0x7fffffff};
           else if (t1.i == best.i) t1 = ValIdx{-INFINITY, 0x7fffffff};
@@ -719,6 +755,7 @@ __global__ __launch_bounds__(S3_T) void cn_search_step3_kernel(const float* __re
       }
   }
   __syncthreads();
+  S3_STAMP(6)
   // bookkeeping (beam.py:164-203)
   if (tid < k) {
     const size_t ti = ((size_t)step * gridDim.x + b) * beam + tid;
@@ -760,6 +797,8 @@ __global__ __launch_bounds__(S3_T) void cn_search_step3_kernel(const float* __re
       }
     }
   }
+  S3_STAMP(7)
+  if (dbg && tid == 0 && b == 0) atomicAdd(&g_s3_prof[9], 1ull);
 }
 
 // best beam per clip (beam.py:205-220): first max of the averaged log-prob; pred_size via atomicMax
@@ -1139,14 +1178,21 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
     const size_t search_smem = (size_t)beam * V * sizeof(float);
     static const int search_mode = getenv("CN_SEARCH_MODE") ? atoi(getenv("CN_SEARCH_MODE")) : 3;
     if (search_mode >= 3 && V <= S3_T * S3_VPT) {
-      if (beam <= 4)
-        hipLaunchKernelGGL(cn_search_step3_kernel<4>, dim3(B), dim3(S3_T), 0, s, w.logits, w.ldv, V, beam, maxp, step,
-                           min_pred, cfg.eos_id, forbid, w.n_active, w.slot, w.sum_lp, w.prefix, w.anc, w.cur_tok,
-                           mult_preds, mult_lprobs, w.out_len, trace_sel, trace_val);
-      else
-        hipLaunchKernelGGL(cn_search_step3_kernel<8>, dim3(B), dim3(S3_T), 0, s, w.logits, w.ldv, V, beam, maxp, step,
-                           min_pred, cfg.eos_id, forbid, w.n_active, w.slot, w.sum_lp, w.prefix, w.anc, w.cur_tok,
-                           mult_preds, mult_lprobs, w.out_len, trace_sel, trace_val);
+#define S3_LAUNCH(NR_, VPT_)                                                                                          \
+  hipLaunchKernelGGL((cn_search_step3_kernel<NR_, VPT_>), dim3(B), dim3(S3_T), 0, s, w.logits, w.ldv, V, beam, maxp,  \
+                     step, min_pred, cfg.eos_id, forbid, w.n_active, w.slot, w.sum_lp, w.prefix, w.anc, w.cur_tok,    \
+                     mult_preds, mult_lprobs, w.out_len, trace_sel, trace_val, db_debug)
+      const int vpt = cn_cdiv(V, S3_T);
+      if (beam <= 4) {
+        if (vpt <= 2) S3_LAUNCH(4, 2);
+        else if (vpt <= 4) S3_LAUNCH(4, 4);
+        else if (vpt <= 6) S3_LAUNCH(4, 6);
+        else S3_LAUNCH(4, 8);
+      } else {
+        if (vpt <= 4) S3_LAUNCH(8, 4);
+        else S3_LAUNCH(8, 8);
+      }
+#undef S3_LAUNCH
     } else if (search_mode >= 2 && search_smem <= 120 * 1024) {
       static bool configured = false;
       if (!configured) {
@@ -1333,10 +1379,14 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
 }
 
 extern "C" int conette_debug_dbprof(unsigned long long* out16, int reset) {
-  if (out16) CN_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_db_prof), 128));
+  if (out16) {
+    CN_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_db_prof), 128));
+    CN_HIP(hipMemcpyFromSymbol(out16 + 16, HIP_SYMBOL(g_s3_prof), 128));
+  }
   if (reset) {
     unsigned long long z[16] = {0};
     CN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_db_prof), z, 128));
+    CN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_s3_prof), z, 128));
   }
   return CN_OK;
 }

@@ -17,7 +17,7 @@ forbid = sd["model.forbid_rep_mask"].cuda()
 for _ in range(3):
     eng.decode(fe, lens, bos, forbid, 3, 3, 20)
 torch.cuda.synchronize()
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 32)()
 eng.lib.conette_debug_dbprof(buf, 1)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 ev[0].record(); eng.decode(fe, lens, bos, forbid, 3, 3, 20); ev[1].record(); torch.cuda.synchronize()
@@ -31,3 +31,12 @@ tot = sum(v[:9])
 for nm, x in zip(names, v[:9]):
     print(f"{nm:42s} {x / n * 10:9.1f} ns  {100 * x / max(tot, 1):5.1f}%")
 print(f"{'total per block (row wave 0)':42s} {tot / n * 10:9.1f} ns")
+
+sv = v[16:]
+n3 = max(sv[9], 1)
+names3 = ["loads issued + n_active arrives", "barrier (prefix/anc in LDS)", "masking", "softmax stats", "per-thread top-k",
+          "wave top-k + barrier", "merge + barrier", "bookkeeping"]
+print(f"--- search step kernel (block 0), instances {n3}")
+for nm, x in zip(names3, sv[:8]):
+    print(f"{nm:42s} {x / n3 * 10:9.1f} ns")
+print(f"{'total':42s} {sum(sv[:8]) / n3 * 10:9.1f} ns")
