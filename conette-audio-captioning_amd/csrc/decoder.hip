@@ -923,9 +923,9 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
     hipLaunchKernelGGL((cn_cvt_kernel<T>), dim3((unsigned)((n + 1023) / 1024 < 4096 ? (n + 1023) / 1024 : 4096)), dim3(256), 0, s,
                        frame_embs, fe_t, n);
     CN_LAUNCH_CHECK();
-    EpiBiasAct<T> ep{ctx->proj_b, mem, d, ACT_RELU};
+    EpiBiasAct<T, ACT_RELU> ep{ctx->proj_b, mem, d, ACT_RELU};
     CN_TRY(cn_mm(fe_t, CN_FEAT, (const T*)ctx->proj_w, CN_FEAT, B * Ta, d, CN_FEAT, ep, s));
-    EpiBiasAct<T> ekv{ctx->kv_b, kvc, kv_ld, ACT_NONE};
+    EpiBiasAct<T, ACT_NONE> ekv{ctx->kv_b, kvc, kv_ld, ACT_NONE};
     CN_TRY(cn_mm(mem, d, (const T*)ctx->kv_w, d, B * Ta, kv_ld, d, ekv, s));
   }
   hipLaunchKernelGGL(cn_init_state_kernel, dim3(64), dim3(256), 0, s, B, beam, maxp, bos_ids, w.n_active, w.slot,
@@ -961,7 +961,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
         bf16_t* vc = (bf16_t*)w.vc + (size_t)l * maxp * R * d;
         {
           CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-          EpiBiasAct<float> eq{lw.sa_in_b, w.qkv, 3 * d, ACT_NONE};
+          EpiBiasAct<float, ACT_NONE> eq{lw.sa_in_b, w.qkv, 3 * d, ACT_NONE};
           if (l == 0) {
             CN_TRY(cn_gemm2(xt, d, (const bf16_t*)lw.sa_in_w, d, R, 3 * d, d, eq, s));
           } else {  // x = LN3_{l-1}(x + FFN2 slabs + b2) fused in
@@ -984,7 +984,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
         }
         {
           CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);  // x = LN1(tmp); q = x Wq + b
-          EpiBiasAct<float> ecq{lw.ca_q_b, w.q, d, ACT_NONE};
+          EpiBiasAct<float, ACT_NONE> ecq{lw.ca_q_b, w.q, d, ACT_NONE};
           CN_TRY(cn_gemm2_ln256(w.tmp, 1, 0, nullptr, nullptr, lw.n1w, lw.n1b, xn, (const bf16_t*)lw.ca_q_w, d, R, d,
                                 ecq, s));
           float* t = xc; xc = xn; xn = t;
@@ -1002,7 +1002,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
         }
         {
           CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);  // x = LN2(tmp); h = gelu(x W1 + b1)
-          EpiBiasAct<bf16_t> e1{lw.ff1_b, ffh, dff, ACT_GELU_FAST};
+          EpiBiasAct<bf16_t, ACT_GELU_FAST> e1{lw.ff1_b, ffh, dff, ACT_GELU_FAST};
           CN_TRY(cn_gemm2_ln256(w.tmp, 1, 0, nullptr, nullptr, lw.n2w, lw.n2b, xn, (const bf16_t*)lw.ff1_w, d, R, dff,
                                 e1, s));
           float* t = xc; xc = xn; xn = t;
@@ -1016,7 +1016,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
       {
         CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);  // x = LN3_last(...); logits = x Wc + bc
         const CnLayerW& pw = ctx->layers[NL - 1];
-        EpiBiasAct<float> ec{ctx->cls_b, w.logits, w.ldv, ACT_NONE};
+        EpiBiasAct<float, ACT_NONE> ec{ctx->cls_b, w.logits, w.ldv, ACT_NONE};
         CN_TRY(cn_gemm2_ln256(w.slabs, splits, slab, pw.ff2_b, xc, pw.n3w, pw.n3b, xn, (const bf16_t*)ctx->cls_w, d, R,
                               V, ec, s));
       }
@@ -1064,7 +1064,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
         } else {
           {
             CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-            EpiBiasAct<bf16_t> e1{lw.ff1_b, ffh, dff, ACT_GELU_FAST};
+            EpiBiasAct<bf16_t, ACT_GELU_FAST> e1{lw.ff1_b, ffh, dff, ACT_GELU_FAST};
             CN_TRY(cn_gemm2(xt, d, (const bf16_t*)lw.ff1_w, d, R, dff, d, e1, s));
           }
           {
@@ -1083,7 +1083,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
       }
       {
         CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-        EpiBiasAct<float> ec{ctx->cls_b, w.logits, w.ldv, ACT_NONE};
+        EpiBiasAct<float, ACT_NONE> ec{ctx->cls_b, w.logits, w.ldv, ACT_NONE};
         CN_TRY(cn_gemm2(xt, d, (const bf16_t*)ctx->cls_w, d, R, V, d, ec, s));
       }
     }
@@ -1094,7 +1094,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
         T* vc = (T*)w.vc + (size_t)l * maxp * R * d;
         {
           CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-          EpiBiasAct<float> eq{lw.sa_in_b, w.qkv, 3 * d, ACT_NONE};
+          EpiBiasAct<float, ACT_NONE> eq{lw.sa_in_b, w.qkv, 3 * d, ACT_NONE};
           CN_TRY(cn_mm(xt, d, (const T*)lw.sa_in_w, d, R, 3 * d, d, eq, s));
         }
         {
@@ -1116,7 +1116,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
         }
         {
           CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-          EpiBiasAct<float> ecq{lw.ca_q_b, w.q, d, ACT_NONE};
+          EpiBiasAct<float, ACT_NONE> ecq{lw.ca_q_b, w.q, d, ACT_NONE};
           CN_TRY(cn_mm(xt, d, (const T*)lw.ca_q_w, d, R, d, d, ecq, s));
         }
         {
@@ -1168,7 +1168,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
       }
       {
         CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-        EpiBiasAct<float> ec{ctx->cls_b, w.logits, w.ldv, ACT_NONE};
+        EpiBiasAct<float, ACT_NONE> ec{ctx->cls_b, w.logits, w.ldv, ACT_NONE};
         CN_TRY(cn_mm(xt, d, (const T*)ctx->cls_w, d, R, V, d, ec, s));
       }
     }

@@ -269,6 +269,15 @@ extern "C" int conette_debug_mlpprof(unsigned long long* out8, int reset) {
   return CN_OK;
 }
 
+extern "C" int conette_debug_g2prof(unsigned long long* out16, int reset) {
+  if (out16) CN_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_g2_prof), 128));
+  if (reset) {
+    unsigned long long z[16] = {0};
+    CN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_g2_prof), z, 128));
+  }
+  return CN_OK;
+}
+
 extern "C" int conette_debug_dwprof(unsigned long long* out8, int reset) {
   if (out8) CN_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dw_prof), 64));
   if (reset) {
@@ -524,7 +533,7 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
       else
         hipLaunchKernelGGL((cn_ln_patchify_kernel<T, 384>), pg, dim3(256), 0, s, ws.x, Hp, Wp, n_in, dw.ln_w, dw.ln_b, y);
       CN_LAUNCH_CHECK();
-      EpiBiasAct<float> epi{dw.bias, ws.x, C, ACT_NONE};
+      EpiBiasAct<float, ACT_NONE> epi{dw.bias, ws.x, C, ACT_NONE};
       CN_TRY(cn_mm(y, 4 * Cp, (const T*)dw.w, 4 * Cp, (int)P, C, 4 * Cp, epi, s));
       if (taps) CN_TRY(tap_copy(taps->down[st], ws.x, (size_t)P * C, s));
     }
@@ -551,7 +560,12 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
       if (!fused) {
         {
           CnProfScope ps(ctx, CONETTE_PROF_PW1_GEMM, s);
-          EpiBiasAct<T> e1{bw.b1, hbuf, 4 * C, std::is_same<T, bf16_t>::value ? ACT_GELU_FAST : ACT_GELU};
+#ifdef CN_G2_NOACT  // timing experiment only (wrong results): how much of the epilogue is the activation?
+          constexpr int kAct = ACT_NONE;
+#else
+          constexpr int kAct = std::is_same<T, bf16_t>::value ? ACT_GELU_FAST : ACT_GELU;
+#endif
+          EpiBiasAct<T, kAct> e1{bw.b1, hbuf, 4 * C, kAct};
           CN_TRY(cn_mm(y, C, (const T*)bw.w1, C, (int)P, 4 * C, C, e1, s));
         }
         {

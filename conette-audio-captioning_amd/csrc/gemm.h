@@ -27,24 +27,29 @@ template <> struct GemmTraits<float> {
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3, ACT_GELU_FAST = 4 };
 
 // out[m][n] = act(acc + bias[n])
-template <typename TOut> struct EpiBiasAct {
+// ACT >= 0 fixes the activation at compile time: with the runtime switch every one of the 16 accumulator tiles of a
+// 128 x 128 block carried the code of all activations (libm erff included) -- a 12,000-instruction kernel whose
+// epilogue streamed ~90 KB through the instruction cache once per block (g2prof: 44 % of the block time).
+template <typename TOut, int ACT = -1> struct EpiBiasAct {
   const float* bias;  // may be null
   TOut* out;
   int ldo;
   int act;
+  static constexpr bool kBatched = false;
+  __device__ __forceinline__ int the_act() const { return ACT >= 0 ? ACT : act; }
   // --- staged interface (gemm2.h): registers -> pre() -> LDS tile -> commit() of 16-byte row chunks
   typedef TOut stage_t;
   __device__ __forceinline__ float pre(int n, float x, int N) const {
     if (bias != nullptr && n < N) x += bias[n];
-    if (act == ACT_GELU) x = cn_gelu(x);
-    else if (act == ACT_GELU_FAST) x = cn_gelu_fast(x);
-    else if (act == ACT_RELU) x = fmaxf(x, 0.0f);
-    else if (act == ACT_SIGMOID) x = 1.0f / (1.0f + __expf(-x));
+    if (the_act() == ACT_GELU) x = cn_gelu(x);
+    else if (the_act() == ACT_GELU_FAST) x = cn_gelu_fast(x);
+    else if (the_act() == ACT_RELU) x = fmaxf(x, 0.0f);
+    else if (the_act() == ACT_SIGMOID) x = 1.0f / (1.0f + __expf(-x));
     return x;
   }
   // 4 consecutive columns at once (packed-math GELU)
   __device__ __forceinline__ f32x4 pre4(int n, f32x4 v, int N) const {
-    if (act == ACT_GELU_FAST && n + 3 < N) {
+    if (the_act() == ACT_GELU_FAST && n + 3 < N) {
       if (bias != nullptr) {
         const f32x4 b = *(const f32x4*)(bias + n);
         v = f32x4{v[0] + b[0], v[1] + b[1], v[2] + b[2], v[3] + b[3]};
@@ -70,10 +75,10 @@ template <typename TOut> struct EpiBiasAct {
     for (int i = 0; i < 4; ++i) {
       float x = v[i];
       if (bias != nullptr && n + i < N) x += bias[n + i];
-      if (act == ACT_GELU) x = cn_gelu(x);
-      else if (act == ACT_GELU_FAST) x = cn_gelu_fast(x);
-      else if (act == ACT_RELU) x = fmaxf(x, 0.0f);
-      else if (act == ACT_SIGMOID) x = 1.0f / (1.0f + __expf(-x));
+      if (the_act() == ACT_GELU) x = cn_gelu(x);
+      else if (the_act() == ACT_GELU_FAST) x = cn_gelu_fast(x);
+      else if (the_act() == ACT_RELU) x = fmaxf(x, 0.0f);
+      else if (the_act() == ACT_SIGMOID) x = 1.0f / (1.0f + __expf(-x));
       r[i] = x;
     }
     TOut* p = out + (size_t)m * ldo + n;
@@ -111,6 +116,27 @@ struct EpiResid {
       for (int i = 0; i < 4; ++i)
         if (n + i < N) out[o + i] = resid[o + i] + chunk[i];
     }
+  }
+  // --- batched interface (gemm2.h direct epilogue): every load of a batch of tiles is issued before its first store.
+  // `resid` and `out` are the same buffer, so hipcc cannot move a tile's loads above the previous tile's store by
+  // itself: 16 tiles = 16 dependent HBM round trips (g2prof: 14 us of a 46 us block).
+  static constexpr bool kBatched = true;
+  struct Cols {
+    f32x4 b, s;
+  };
+  __device__ __forceinline__ bool fast(int N) const { return (ld & 3) == 0 && (N & 3) == 0; }
+  __device__ __forceinline__ Cols cols(int n) const {
+    Cols c;
+    c.b = *(const f32x4*)(bias + n);
+    c.s = scale ? *(const f32x4*)(scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+    return c;
+  }
+  __device__ __forceinline__ f32x4 prefetch(int m, int n) const { return *(const f32x4*)(resid + (size_t)m * ld + n); }
+  __device__ __forceinline__ void finish(int m, int n, f32x4 v, const Cols& c, f32x4 rs) const {
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = rs[i] + c.s[i] * (v[i] + c.b[i]);
+    *(f32x4*)(out + (size_t)m * ld + n) = r;
   }
   __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int N, int /*ks*/ = 0) const {
     const size_t o = (size_t)m * ld + n;

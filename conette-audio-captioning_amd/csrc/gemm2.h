@@ -25,6 +25,7 @@ struct EpiSlab {
   int ld;
   size_t slab_stride;
   typedef float stage_t;
+  static constexpr bool kBatched = false;
   __device__ __forceinline__ float pre(int, float x, int) const { return x; }
   __device__ __forceinline__ void commit(int m, int n, const float* chunk, int N, int ks) const {
     float* p = out + (size_t)ks * slab_stride + (size_t)m * ld + n;
@@ -81,6 +82,21 @@ __device__ __forceinline__ void cn_g2_compute(const char* sA, const char* sW, in
   }
 }
 
+__device__ unsigned long long g_g2_prof[16];
+// Phase stamps exist only in a profiling build (CN_G2_PROF=1 python build.py --force; tools/g2prof.py): the
+// accumulators cost 32 registers, which pushed the 128 x 128 tiles from 148 to 180 and broke the co-residency
+// budget of the decode kernels (dec_block.h).
+#ifndef CN_G2_PROF
+#define G2_STAMP(i)
+#else
+#define G2_STAMP(i)                                                        \
+  if (dbg & 1) { /* accumulated in registers: an atomic per stamp would sit in the vmcnt queue the loop waits on */ \
+    const unsigned long long t_ = wall_clock64();                          \
+    t_acc[i] += t_ - t_prev;                                               \
+    t_prev = t_;                                                           \
+  }
+#endif
+
 // Epilogue.  fp32 outputs store 16 bytes per lane straight from the MFMA layout (64 contiguous
 // bytes per row and instruction; staging a 64 KB fp32 tile only costs occupancy: pw2 +35 %).
 // bf16 outputs go registers -> LDS tile [BM][BN] -> whole-row 16-byte chunks: direct stores would be
@@ -88,11 +104,48 @@ __device__ __forceinline__ void cn_g2_compute(const char* sA, const char* sW, in
 // WRITE_SIZE).  Must be entered after a barrier (the LDS pipeline buffers are reused).
 template <int BM, int BN, class Epi>
 __device__ __forceinline__ void cn_g2_epilogue(char* smem, f32x4 (&acc)[BN / 32][BM / 32], int m0, int n0, int M, int N,
-                                               const Epi& epi, int ks, int tid, int wm, int wn) {
+                                               const Epi& epi, int ks, int tid, int wm, int wn
+#ifdef CN_G2_PROF
+                                               , int dbg, unsigned long long& t_prev, unsigned long long (&t_acc)[8]
+#endif
+) {
   constexpr int TM = BM / 32, TN = BN / 32;
   const int lane = tid & 63;
   typedef typename Epi::stage_t ST;
   if constexpr (sizeof(ST) == 4) {
+    if constexpr (Epi::kBatched) {
+      // interior tiles (the whole 128 x 128 block inside the matrix): column parameters once, then per column
+      // tile `a` all TM residual loads in flight before the first store, the next tile's loads issued before this
+      // tile's stores
+      if (epi.fast(N) && m0 + BM <= M && n0 + BN <= N) {
+        const int mb = m0 + wm * (BM / 2) + (lane & 15);
+        const int nb = n0 + wn * (BN / 2) + 4 * (lane >> 4);
+        // (register budget: the 128 x 128 tiles must stay at 148 registers so that a decode block can start next to
+        // one resident GEMM workgroup, dec_block.h; sched_barrier keeps hipcc from hoisting every accumulator read
+        // and column load to the top of the epilogue)
+        const float* rp = epi.resid + (size_t)mb * epi.ld + nb;  // one 64-bit base, immediate / scalar offsets from here
+        float* op = epi.out + (size_t)mb * epi.ld + nb;
+        const size_t rstride = (size_t)16 * epi.ld;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+          const typename Epi::Cols c = epi.cols(nb + a * 16);
+          f32x4 r[TM];
+#pragma unroll
+          for (int b = 0; b < TM; ++b) r[b] = *(const f32x4*)(rp + b * rstride + a * 16);
+#pragma unroll
+          for (int b = 0; b < TM; ++b) {
+            const f32x4 v = acc[a][b];
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = r[b][i] + c.s[i] * (v[i] + c.b[i]);
+            *(f32x4*)(op + b * rstride + a * 16) = o;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        G2_STAMP(7)
+        return;
+      }
+    }
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -115,7 +168,9 @@ __device__ __forceinline__ void cn_g2_epilogue(char* smem, f32x4 (&acc)[BN / 32]
         const f32x4 v = epi.pre4(n0 + nl, acc[a][b], N);
         cn_store4(tile + ml * PITCH + nl, v[0], v[1], v[2], v[3]);
       }
+    G2_STAMP(5)
     __syncthreads();
+    G2_STAMP(6)
     for (int idx = tid; idx < BM * CH; idx += 256) {
       const int r = idx / CH, c = idx % CH;
       const int m = m0 + r, n = n0 + c * EPC;
@@ -127,7 +182,11 @@ __device__ __forceinline__ void cn_g2_epilogue(char* smem, f32x4 (&acc)[BN / 32]
 template <int BM, int BN, int BK, int NST, class Epi>
 __global__ __launch_bounds__(256) void cn_gemm2_kernel(const bf16_t* __restrict__ A, int lda,
                                                        const bf16_t* __restrict__ W, int ldw, int M, int N, int K,
-                                                       int k_slice, Epi epi) {
+                                                       int k_slice, Epi epi, int dbg) {
+#ifdef CN_G2_PROF
+  unsigned long long t_prev = (dbg & 1) ? wall_clock64() : 0ull;
+  unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   typedef G2Geom<BK> G;
   constexpr int RBY = G::RBY, CPR = G::CPR, RPB = G::RPB, SWM = G::SWM, RPI = G::RPI;
   constexpr int A_BYTES = BM * RBY, W_BYTES = BN * RBY, BUF = A_BYTES + W_BYTES;
@@ -208,19 +267,39 @@ __global__ __launch_bounds__(256) void cn_gemm2_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
       if (t < KT) stage(t, t);
+    G2_STAMP(0)
     for (int kt = 0; kt < KT; ++kt) {
       const int newer = KT - 1 - kt;  // stages issued after tile kt that may stay in flight
       if (NST >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW) : "memory");
       else if (NST >= 3 && newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      if (kt == 0) { G2_STAMP(1) } else { G2_STAMP(2) }
       if (kt + NST - 1 < KT) stage((kt + NST - 1) % NST, kt + NST - 1);
       const char* sA = smem + (kt % NST) * BUF;
+#ifdef CN_G2_PROF
+      if (!(dbg & 4))
+#endif
       cn_g2_compute<BM, BN, BK>(sA, sA + A_BYTES, lane, wm, wn, acc);
+      G2_STAMP(3)
     }
     __syncthreads();  // all fragment reads done before the epilogue reuses the LDS
   }
+  G2_STAMP(4)
+#ifdef CN_G2_PROF
+  if (!(dbg & 2) || acc[0][0][0] == 12345.678f)  // experiment: skip the epilogue (wrong results)
+    cn_g2_epilogue<BM, BN, Epi>(smem, acc, m0, n0, M, N, epi, (int)blockIdx.y, tid, wm, wn, dbg & 1, t_prev, t_acc);
+#else
   cn_g2_epilogue<BM, BN, Epi>(smem, acc, m0, n0, M, N, epi, (int)blockIdx.y, tid, wm, wn);
+#endif
+  G2_STAMP(7)
+#ifdef CN_G2_PROF
+  if ((dbg & 1) && threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_g2_prof[i], t_acc[i]);
+    atomicAdd(&g_g2_prof[8], 1ull);
+  }
+#endif
 }
 
 // ---- skinny decoder GEMM with a LayerNorm prologue (d_model = 256) ---------------------------------
@@ -333,7 +412,15 @@ __global__ __launch_bounds__(256) void cn_gemm2_ln256_kernel(const float* __rest
     for (int b = 0; b < BM / 32; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   cn_g2_compute<BM, BN, BK>(smem, smem + A_BYTES, lane, wm, wn, acc);
   __syncthreads();
+#ifdef CN_G2_PROF
+  {
+    const int dbg = 0;
+    unsigned long long t_prev = 0, t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    cn_g2_epilogue<BM, BN, Epi>(smem, acc, m0, n0, M, N, epi, 0, tid, wm, wn, dbg, t_prev, t_acc);
+  }
+#else
   cn_g2_epilogue<BM, BN, Epi>(smem, acc, m0, n0, M, N, epi, 0, tid, wm, wn);
+#endif
 }
 
 template <class Epi>
@@ -353,6 +440,20 @@ static int cn_gemm2_ln256(const float* in, int nslab, size_t slab_stride, const 
   return CN_OK;
 }
 
+static inline int g2_debug_level() {  // CN_G2_DEBUG = BM + BN of the tile shape to instrument (256: the 128 x 128 tiles)
+  static const int v = getenv("CN_G2_DEBUG") ? atoi(getenv("CN_G2_DEBUG")) : 0;
+  return v;
+}
+
+static inline int g2_debug_skip() {  // profiling build only: CN_G2_SKIP bit 1 (2) = no epilogue, bit 2 (4) = no MFMA phase
+  static const int v = getenv("CN_G2_SKIP") ? atoi(getenv("CN_G2_SKIP")) : 0;
+  return v;
+}
+static inline int g2_debug_epi() {  // CN_G2_DEBUG_EPI = 2: bf16-output (staged) epilogues only, 4: fp32-output only
+  static const int v = getenv("CN_G2_DEBUG_EPI") ? atoi(getenv("CN_G2_DEBUG_EPI")) : 0;
+  return v;
+}
+
 template <int BM, int BN, int BK, int NST, class Epi>
 static int cn_launch_gemm2_t(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, int splits,
                              const Epi& epi, hipStream_t stream) {
@@ -368,7 +469,7 @@ static int cn_launch_gemm2_t(const bf16_t* A, int lda, const bf16_t* W, int ldw,
   const long blocks = (long)cn_cdiv(M, BM) * cn_cdiv(N, BN);
   const int k_slice = K / splits;
   hipLaunchKernelGGL((cn_gemm2_kernel<BM, BN, BK, NST, Epi>), dim3((unsigned)blocks, (unsigned)splits), dim3(256), SMEM,
-                     stream, A, lda, W, ldw, M, N, K, k_slice, epi);
+                     stream, A, lda, W, ldw, M, N, K, k_slice, epi, (g2_debug_level() == BM + BN && (g2_debug_epi() == 0 || g2_debug_epi() == (int)sizeof(typename Epi::stage_t)) ? 1 : 0) | g2_debug_skip());
   CN_LAUNCH_CHECK();
   return CN_OK;
 }

@@ -167,20 +167,38 @@ __global__ __launch_bounds__(256) void cn_mlp_fused_kernel(const bf16_t* __restr
   }
 
   // ---- final epilogue: x += scale * (acc + b2), 16 bytes per lane (4 consecutive channels) ---------
+  // X is read and written through the same pointer, so hipcc keeps every tile's load behind the previous tile's
+  // store: TN2 * TM dependent HBM round trips per block.  All residual loads of a channel tile `a` are issued
+  // before its stores, and tile a + 1's before tile a's stores (double-buffered registers).
+  {
+    f32x4 r[2][TM];
+    const int mrow = m0 + wm * (BM / 2) + lr;
 #pragma unroll
-  for (int a = 0; a < TN2; ++a) {
-    const int n = wn * (C / 2) + a * 16 + 4 * lq;
-    const f32x4 bb = *(const f32x4*)(b2 + n);
-    const f32x4 sc = *(const f32x4*)(scale + n);
+    for (int b = 0; b < TM; ++b)
+      r[0][b] = *(const f32x4*)(X + (size_t)min(mrow + b * 16, M - 1) * C + wn * (C / 2) + 4 * lq);
+    f32x4 bbv[TN2], scv[TN2];
 #pragma unroll
-    for (int b = 0; b < TM; ++b) {
-      const int m = m0 + wm * (BM / 2) + b * 16 + lr;
-      if (m < M) {
-        float* p = X + (size_t)m * C + n;
-        const f32x4 r = *(const f32x4*)p;
-        const f32x4 v = acc2[a][b];
-        *(f32x4*)p = f32x4{r[0] + sc[0] * (v[0] + bb[0]), r[1] + sc[1] * (v[1] + bb[1]), r[2] + sc[2] * (v[2] + bb[2]),
-                           r[3] + sc[3] * (v[3] + bb[3])};
+    for (int a = 0; a < TN2; ++a) {
+      const int n = wn * (C / 2) + a * 16 + 4 * lq;
+      bbv[a] = *(const f32x4*)(b2 + n);
+      scv[a] = *(const f32x4*)(scale + n);
+    }
+#pragma unroll
+    for (int a = 0; a < TN2; ++a) {
+      const int n = wn * (C / 2) + a * 16 + 4 * lq;
+      if (a + 1 < TN2) {
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+          r[(a + 1) & 1][b] = *(const f32x4*)(X + (size_t)min(mrow + b * 16, M - 1) * C + n + 16);
+      }
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const int m = mrow + b * 16;
+        if (m < M) {
+          const f32x4 v = acc2[a][b], rr = r[a & 1][b], bb = bbv[a], sc = scv[a];
+          *(f32x4*)(X + (size_t)m * C + n) = f32x4{rr[0] + sc[0] * (v[0] + bb[0]), rr[1] + sc[1] * (v[1] + bb[1]),
+                                                     rr[2] + sc[2] * (v[2] + bb[2]), rr[3] + sc[3] * (v[3] + bb[3])};
+        }
       }
     }
   }
