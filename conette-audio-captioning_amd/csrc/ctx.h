@@ -25,6 +25,9 @@ struct CnBlockW {
   const void* w2;  // [C][4C]
   const float* b2;
   const float* scale;
+  // bf16, C <= 384: w1 / w2 re-ordered into the exact LDS image of mlp_fused.h's weight ring, one 1 KB DMA piece
+  // after the other: [hidden chunk C/8][piece][lane 64][8 bf16]
+  const void* mlp_stream;
 };
 
 struct CnDownW {

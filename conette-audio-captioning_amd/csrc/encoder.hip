@@ -546,14 +546,13 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
       bool fused = false;
       if constexpr (std::is_same<T, bf16_t>::value) {
         // narrow stages: fused MLP keeps the 4C hidden in LDS (mlp_fused.h); timed under PW1
-        if (C == 96 || C == 192) {
+        static const int mlp384 = getenv("CN_MLP384") ? atoi(getenv("CN_MLP384")) : 1;
+        if (bw.mlp_stream != nullptr && (C == 96 || C == 192 || (C == 384 && mlp384))) {
           CnProfScope ps(ctx, CONETTE_PROF_PW1_GEMM, s);
-          if (C == 96)
-            CN_TRY((cn_launch_mlp_fused<96, 4>(y, (const bf16_t*)bw.w1, bw.b1, (const bf16_t*)bw.w2, bw.b2, bw.scale,
-                                               ws.x, (int)P, s)));
-          else
-            CN_TRY((cn_launch_mlp_fused<192, 2>(y, (const bf16_t*)bw.w1, bw.b1, (const bf16_t*)bw.w2, bw.b2, bw.scale,
-                                                ws.x, (int)P, s)));
+          const bf16_t* wsm = (const bf16_t*)bw.mlp_stream;
+          if (C == 96) CN_TRY((cn_launch_mlp_fused<96, 4, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
+          else if (C == 192) CN_TRY((cn_launch_mlp_fused<192, 2, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
+          else CN_TRY((cn_launch_mlp_fused<384, 2, 4>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
           fused = true;
         }
       }

@@ -1,4 +1,4 @@
-// Fused ConvNeXt MLP for the narrow stages (C = 96, 192), bf16:
+// Fused ConvNeXt MLP for stages 0-2 (C = 96, 192, 384), bf16:
 //
 //     x[m][:] += scale * ( W2 . gelu( W1 . y[m][:] + b1 ) + b2 )          (convnext.py:66-74)
 //
@@ -11,8 +11,11 @@
 //   GEMM2  O[BM][C]   += Hc[BM][32] . W2c[C][32]^T    fp32 accumulators live across all chunks
 //
 // so the hidden never leaves the CU.  W1c / W2c chunks (C*128 bytes) stream L2 -> LDS with
-// global_load_lds_dwordx4 into a double buffer (chunk j+1 in flight during chunk j); the same
-// source-side XOR swizzle as gemm2.h keeps the ds_read_b128 fragment reads conflict-free.
+// global_load_lds_dwordx4 into a 3-deep ring (chunks j+1, j+2 in flight during chunk j).  The weights
+// are stored a second time as the exact LDS image of that ring (api.hip pk_mlp_stream, XOR swizzle
+// for conflict-free ds_read_b128 included), so every DMA instruction moves 1 KB of consecutive bytes;
+// 64-byte row pieces gathered from the nn.Linear layout streamed at half the per-CU rate, which is
+// what bounds the kernel once C is large (2.4 MB of weights per block at C = 384).
 // 4 waves as 2 (rows) x 2 (hidden / channel halves); two barriers per chunk.
 #pragma once
 #include <stdlib.h>
@@ -27,15 +30,21 @@ __device__ unsigned long long g_mlp_prof[8];
     t_prev = t_;                                                         \
   }
 
-template <int C, int TM>
-__global__ __launch_bounds__(256) void cn_mlp_fused_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ W1,
+// NWM = wave rows (2 or 4): 2 * NWM waves per block, each owning TM 16-row tiles and one half of the hidden chunk /
+// of the channels.  C = 384 runs 8 waves (2 per SIMD, 250 registers each): with 4 waves of TM = 4 every LDS
+// fragment read in front of its MFMAs was exposed (one wave per SIMD, no registers left to prefetch into) and the
+// kernel was no faster than the two GEMMs it replaces.
+template <int C, int TM, int NWM>
+__global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* __restrict__ Y,
+                                                           const bf16_t* __restrict__ WS /* packed ring image */,
                                                            const float* __restrict__ b1,
-                                                           const bf16_t* __restrict__ W2,
                                                            const float* __restrict__ b2,
                                                            const float* __restrict__ scale, float* __restrict__ X,
                                                            int M, int dbg) {
   unsigned long long t_prev = dbg ? clock64() : 0;
-  constexpr int BM = 32 * TM;           // rows per block (TM 16-row tiles per wave-row-half)
+  constexpr int BM = NWM * 16 * TM;     // rows per block
+  constexpr int NT = NWM * 128;         // threads
+  constexpr int NW = NWM * 2;           // waves
   constexpr int KS1 = C / 32;           // k-steps of GEMM1
   constexpr int TN2 = C / 32;           // 16-channel tiles per wave in GEMM2 (wave owns C/2 channels)
   constexpr int NCH = 4 * C / 32;       // hidden chunks
@@ -43,8 +52,8 @@ __global__ __launch_bounds__(256) void cn_mlp_fused_kernel(const bf16_t* __restr
   constexpr int W2C_BYTES = C * 64;     // [C rows][64 B]
   constexpr int BUF = W1C_BYTES + W2C_BYTES;
   constexpr int N_DMA = BUF / 1024;     // per chunk
-  constexpr int DPW = N_DMA / 4;
-  static_assert(N_DMA % 4 == 0, "DMA pieces must split evenly over 4 waves");
+  constexpr int DPW = N_DMA / NW;
+  static_assert(N_DMA % NW == 0, "DMA pieces must split evenly over the waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NST = 3;                // weight-chunk ring: chunks j+1, j+2 in flight during chunk j
   char* sH = smem + NST * BUF;          // [BM][64 B]
@@ -62,36 +71,18 @@ __global__ __launch_bounds__(256) void cn_mlp_fused_kernel(const bf16_t* __restr
   bf16x8 fa[TM][KS1];
 #pragma unroll
   for (int b = 0; b < TM; ++b) {
-    const int m = min(m0 + wm * (BM / 2) + b * 16 + lr, M - 1);
+    const int m = min(m0 + wm * (16 * TM) + b * 16 + lr, M - 1);
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) fa[b][ks] = *(const bf16x8*)(Y + (size_t)m * C + ks * 32 + lq * 8);
   }
 
-  // ---- per-lane DMA sources for chunk 0 ----------------------------------------------------------
-  const char* src[DPW];
-  int adv[DPW];
-#pragma unroll
-  for (int i = 0; i < DPW; ++i) {
-    const int inst = wave * DPW + i;
-    const int slot = lane & 3;
-    if (inst < W1C_BYTES / 1024) {            // W1 chunk: sub-tile ks = inst / 2, 16 rows per piece
-      const int ks = inst >> 1;
-      const int r = (inst & 1) * 16 + (lane >> 2);
-      const int chunk = slot ^ ((r >> 2) & 3);
-      src[i] = (const char*)(W1 + (size_t)r * C + ks * 32) + chunk * 16;
-      adv[i] = 32 * C * 2;                    // next 32 hidden rows
-    } else {                                  // W2 chunk: rows = output channels, 64 bytes of K each
-      const int r = (inst - W1C_BYTES / 1024) * 16 + (lane >> 2);
-      const int chunk = slot ^ ((r >> 2) & 3);
-      src[i] = (const char*)(W2 + (size_t)r * (4 * C)) + chunk * 16;
-      adv[i] = 64;                            // next 32 hidden columns
-    }
-  }
+  // ---- weight ring: chunk j, piece inst = 1 KB at WS + (j * N_DMA + inst) * 1024 -----------------------------
+  const char* wsrc = (const char*)WS + (size_t)wave * DPW * 1024 + lane * 16;
   auto stage = [&](int buf, int j) {
 #pragma unroll
     for (int i = 0; i < DPW; ++i) {
       const int inst = wave * DPW + i;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)j * adv[i]),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)j * BUF + i * 1024),
                                        (__attribute__((address_space(3))) void*)(smem + buf * BUF + inst * 1024), 16, 0,
                                        0);
     }
@@ -103,7 +94,7 @@ __global__ __launch_bounds__(256) void cn_mlp_fused_kernel(const bf16_t* __restr
 #pragma unroll
     for (int b = 0; b < TM; ++b) acc2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int i = tid; i < 4 * C; i += 256) sB1[i] = b1[i];
+  for (int i = tid; i < 4 * C; i += NT) sB1[i] = b1[i];
   stage(0, 0);
   stage(1, 1);
   // retire the ordinary loads (y fragments, bias) HERE, once: touching the registers makes the compiler
@@ -143,7 +134,7 @@ __global__ __launch_bounds__(256) void cn_mlp_fused_kernel(const bf16_t* __restr
       const int chunk = wn * 2 + (lq >> 1);
 #pragma unroll
       for (int b = 0; b < TM; ++b) {
-        const int ml = wm * (BM / 2) + b * 16 + lr;
+        const int ml = wm * (16 * TM) + b * 16 + lr;
         bf16_t* dst = (bf16_t*)(sH + ml * 64 + ((chunk ^ sw) * 16) + (lq & 1) * 8);
         const f32x4 g = cn_gelu_fast4(f32x4{acc1[b][0] + bb[0], acc1[b][1] + bb[1], acc1[b][2] + bb[2], acc1[b][3] + bb[3]});
         cn_store4(dst, g[0], g[1], g[2], g[3]);
@@ -156,7 +147,7 @@ __global__ __launch_bounds__(256) void cn_mlp_fused_kernel(const bf16_t* __restr
     // GEMM2: rows wm*(BM/2).. (TM tiles) x channels wn*(C/2).. (TN2 tiles), K = 32
     bf16x8 fh[TM];
 #pragma unroll
-    for (int b = 0; b < TM; ++b) fh[b] = *(const bf16x8*)(sH + (wm * (BM / 2) + b * 16 + lr) * 64 + ((lq ^ sw) * 16));
+    for (int b = 0; b < TM; ++b) fh[b] = *(const bf16x8*)(sH + (wm * (16 * TM) + b * 16 + lr) * 64 + ((lq ^ sw) * 16));
 #pragma unroll
     for (int a = 0; a < TN2; ++a) {
       const bf16x8 fw2 = *(const bf16x8*)(sW2 + (wn * (C / 2) + a * 16 + lr) * 64 + ((lq ^ sw) * 16));
@@ -172,7 +163,7 @@ __global__ __launch_bounds__(256) void cn_mlp_fused_kernel(const bf16_t* __restr
   // before its stores, and tile a + 1's before tile a's stores (double-buffered registers).
   {
     f32x4 r[2][TM];
-    const int mrow = m0 + wm * (BM / 2) + lr;
+    const int mrow = m0 + wm * (16 * TM) + lr;
 #pragma unroll
     for (int b = 0; b < TM; ++b)
       r[0][b] = *(const f32x4*)(X + (size_t)min(mrow + b * 16, M - 1) * C + wn * (C / 2) + 4 * lq);
@@ -205,18 +196,18 @@ __global__ __launch_bounds__(256) void cn_mlp_fused_kernel(const bf16_t* __restr
   MLP_STAMP(6)
 }
 
-template <int C, int TM>
-static int cn_launch_mlp_fused(const bf16_t* Y, const bf16_t* W1, const float* b1, const bf16_t* W2, const float* b2,
+template <int C, int TM, int NWM>
+static int cn_launch_mlp_fused(const bf16_t* Y, const bf16_t* WS, const float* b1, const float* b2,
                                const float* scale, float* X, int M, hipStream_t s) {
-  constexpr int SMEM = 3 * (32 * C * 2 + C * 64) + 32 * TM * 64 + 4 * C * 4;
+  constexpr int SMEM = 3 * (32 * C * 2 + C * 64) + NWM * 16 * TM * 64 + 4 * C * 4;
   static bool configured = false;
   if (!configured) {
-    CN_HIP(hipFuncSetAttribute((const void*)cn_mlp_fused_kernel<C, TM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    CN_HIP(hipFuncSetAttribute((const void*)cn_mlp_fused_kernel<C, TM, NWM>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                SMEM));
     configured = true;
   }
-  hipLaunchKernelGGL((cn_mlp_fused_kernel<C, TM>), dim3((unsigned)cn_cdiv(M, 32 * TM)), dim3(256), SMEM, s, Y, W1, b1,
-                     W2, b2, scale, X, M, getenv("CN_MLP_DEBUG") ? 1 : 0);
+  hipLaunchKernelGGL((cn_mlp_fused_kernel<C, TM, NWM>), dim3((unsigned)cn_cdiv(M, NWM * 16 * TM)), dim3(NWM * 128), SMEM, s, Y, WS, b1,
+                     b2, scale, X, M, getenv("CN_MLP_DEBUG") ? 1 : 0);
   CN_LAUNCH_CHECK();
   return CN_OK;
 }
