@@ -22,13 +22,19 @@
 
 #include "gemm.h"
 
+// Phase stamps: profiling build only (CN_G2_PROF=1 python build.py --force), accumulated in registers -- an atomic
+// per stamp would sit in the vmcnt queue the chunk loop waits on.  CN_MLP_DEBUG = C selects the instantiation.
 __device__ unsigned long long g_mlp_prof[8];
-#define MLP_STAMP(i)                                                     \
-  if (dbg) {                                                             \
-    const unsigned long long t_ = clock64();                             \
-    if ((threadIdx.x & 63) == 0) atomicAdd(&g_mlp_prof[i], t_ - t_prev); \
-    t_prev = t_;                                                         \
+#ifndef CN_G2_PROF
+#define MLP_STAMP(i)
+#else
+#define MLP_STAMP(i)                              \
+  if (dbg) {                                      \
+    const unsigned long long t_ = wall_clock64(); \
+    t_acc[i] += t_ - t_prev;                      \
+    t_prev = t_;                                  \
   }
+#endif
 
 // NWM = wave rows (2 or 4): 2 * NWM waves per block, each owning TM 16-row tiles and one half of the hidden chunk /
 // of the channels.  C = 384 runs 8 waves (2 per SIMD, 250 registers each): with 4 waves of TM = 4 every LDS
@@ -41,7 +47,10 @@ __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* _
                                                            const float* __restrict__ b2,
                                                            const float* __restrict__ scale, float* __restrict__ X,
                                                            int M, int dbg) {
-  unsigned long long t_prev = dbg ? clock64() : 0;
+#ifdef CN_G2_PROF
+  unsigned long long t_prev = dbg ? wall_clock64() : 0;
+  unsigned long long t_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
   constexpr int BM = NWM * 16 * TM;     // rows per block
   constexpr int NT = NWM * 128;         // threads
   constexpr int NW = NWM * 2;           // waves
@@ -88,11 +97,20 @@ __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* _
     }
   };
 
+  // fp32 accumulators of GEMM2.  For the narrow stages they START from the residual x (requested here, together
+  // with the A fragments, so its HBM latency hides under the whole chunk loop; the final epilogue was 28 % of a
+  // C = 96 block, all of it waiting for these rows); at C = 384 the registers are needed for the operands.
+  constexpr bool kResidEarly = TN2 * TM <= 12;
   f32x4 acc2[TN2][TM];
+  f32x4 res[kResidEarly ? TN2 : 1][kResidEarly ? TM : 1];
 #pragma unroll
   for (int a = 0; a < TN2; ++a)
 #pragma unroll
-    for (int b = 0; b < TM; ++b) acc2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < TM; ++b) {
+      acc2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (kResidEarly)
+        res[a][b] = *(const f32x4*)(X + (size_t)min(m0 + wm * (16 * TM) + b * 16 + lr, M - 1) * C + wn * (C / 2) + a * 16 + 4 * lq);
+    }
 
   for (int i = tid; i < 4 * C; i += NT) sB1[i] = b1[i];
   stage(0, 0);
@@ -103,6 +121,12 @@ __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* _
   for (int b = 0; b < TM; ++b)
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) asm volatile("" : "+v"(fa[b][ks]));
+  if constexpr (kResidEarly) {
+#pragma unroll
+    for (int a = 0; a < TN2; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) asm volatile("" : "+v"(res[a][b]));
+  }
   MLP_STAMP(0)
   for (int j = 0; j < NCH; ++j) {
     const int buf = j % NST;
@@ -161,22 +185,32 @@ __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* _
   // X is read and written through the same pointer, so hipcc keeps every tile's load behind the previous tile's
   // store: TN2 * TM dependent HBM round trips per block.  All residual loads of a channel tile `a` are issued
   // before its stores, and tile a + 1's before tile a's stores (double-buffered registers).
-  {
+  if constexpr (kResidEarly) {
+    const int mrow = m0 + wm * (16 * TM) + lr;
+#pragma unroll
+    for (int a = 0; a < TN2; ++a) {
+      const int n = wn * (C / 2) + a * 16 + 4 * lq;
+      const f32x4 bb = *(const f32x4*)(b2 + n), sc = *(const f32x4*)(scale + n);
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const int m = mrow + b * 16;
+        if (m < M) {
+          const f32x4 v = acc2[a][b], rr = res[a][b];
+          *(f32x4*)(X + (size_t)m * C + n) = f32x4{rr[0] + sc[0] * (v[0] + bb[0]), rr[1] + sc[1] * (v[1] + bb[1]),
+                                                     rr[2] + sc[2] * (v[2] + bb[2]), rr[3] + sc[3] * (v[3] + bb[3])};
+        }
+      }
+    }
+  } else {
     f32x4 r[2][TM];
     const int mrow = m0 + wm * (16 * TM) + lr;
 #pragma unroll
     for (int b = 0; b < TM; ++b)
       r[0][b] = *(const f32x4*)(X + (size_t)min(mrow + b * 16, M - 1) * C + wn * (C / 2) + 4 * lq);
-    f32x4 bbv[TN2], scv[TN2];
 #pragma unroll
     for (int a = 0; a < TN2; ++a) {
       const int n = wn * (C / 2) + a * 16 + 4 * lq;
-      bbv[a] = *(const f32x4*)(b2 + n);
-      scv[a] = *(const f32x4*)(scale + n);
-    }
-#pragma unroll
-    for (int a = 0; a < TN2; ++a) {
-      const int n = wn * (C / 2) + a * 16 + 4 * lq;
+      const f32x4 bb = *(const f32x4*)(b2 + n), sc = *(const f32x4*)(scale + n);
       if (a + 1 < TN2) {
 #pragma unroll
         for (int b = 0; b < TM; ++b)
@@ -186,7 +220,7 @@ __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* _
       for (int b = 0; b < TM; ++b) {
         const int m = mrow + b * 16;
         if (m < M) {
-          const f32x4 v = acc2[a][b], rr = r[a & 1][b], bb = bbv[a], sc = scv[a];
+          const f32x4 v = acc2[a][b], rr = r[a & 1][b];
           *(f32x4*)(X + (size_t)m * C + n) = f32x4{rr[0] + sc[0] * (v[0] + bb[0]), rr[1] + sc[1] * (v[1] + bb[1]),
                                                      rr[2] + sc[2] * (v[2] + bb[2]), rr[3] + sc[3] * (v[3] + bb[3])};
         }
@@ -194,6 +228,13 @@ __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* _
     }
   }
   MLP_STAMP(6)
+#ifdef CN_G2_PROF
+  if (dbg && threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) atomicAdd(&g_mlp_prof[i], t_acc[i]);
+    atomicAdd(&g_mlp_prof[7], 1ull);
+  }
+#endif
 }
 
 template <int C, int TM, int NWM>
@@ -207,7 +248,7 @@ static int cn_launch_mlp_fused(const bf16_t* Y, const bf16_t* WS, const float* b
     configured = true;
   }
   hipLaunchKernelGGL((cn_mlp_fused_kernel<C, TM, NWM>), dim3((unsigned)cn_cdiv(M, NWM * 16 * TM)), dim3(NWM * 128), SMEM, s, Y, WS, b1,
-                     b2, scale, X, M, getenv("CN_MLP_DEBUG") ? 1 : 0);
+                     b2, scale, X, M, getenv("CN_MLP_DEBUG") && atoi(getenv("CN_MLP_DEBUG")) == C ? 1 : 0);
   CN_LAUNCH_CHECK();
   return CN_OK;
 }

@@ -19,7 +19,8 @@ buf2 = (C.c_ulonglong * 8)()
 eng.lib.conette_debug_mlpprof(buf2, 1)
 eng.encode(wave); torch.cuda.synchronize()
 eng.lib.conette_debug_mlpprof(buf2, 0)
-v = list(buf2)[:7]; tot = sum(v)
+v = list(buf2)[:7]; tot = sum(v); nblk = max(list(buf2)[7], 1)
 names = ["prologue (A frags, stage0)", "wait DMA + barrier", "GEMM1", "epilogue1 (GELU, H write)", "barrier H", "GEMM2", "final epilogue"]
 print("--- fused MLP")
-for n, x in zip(names, v): print(f"{n:28s} {x/1e6:10.1f} Mcycles  {100*x/max(tot,1):5.1f}%")
+for n, x in zip(names, v): print(f"{n:28s} {x / nblk * 10:10.1f} ns/block  {100*x/max(tot,1):5.1f}%")
+print(f"per block: {tot / nblk * 10:.0f} ns over {nblk} blocks (profiling build, CN_MLP_DEBUG=C)")
