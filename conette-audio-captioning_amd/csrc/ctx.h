@@ -67,6 +67,7 @@ struct conette_ctx {
   conette_config cfg;
   CnRuntime* rt;
   uint32_t prof_mask;
+  int dec_unfused;  // CONETTE_OPT_DECODE_FUSION = 0: one launch per sub-layer (the cross-check path of the tests)
   int esize;  // operand element size (2 or 4)
   // frontend tables
   const float* window;     // [1024]

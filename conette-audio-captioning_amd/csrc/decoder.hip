@@ -936,7 +936,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
   for (int step = 0; step < maxp; ++step) {
     static const int dec_fused = getenv("CN_DEC_FUSED") ? atoi(getenv("CN_DEC_FUSED")) : 0;
     static const int dec_block = getenv("CN_DEC_BLOCK") ? atoi(getenv("CN_DEC_BLOCK")) : 1;
-    const bool block_path = std::is_same<T, bf16_t>::value && !dec_fused && dec_block;
+    const bool block_path = std::is_same<T, bf16_t>::value && !dec_fused && dec_block && !ctx->dec_unfused;
     if (!block_path) {  // (the block path embeds in the prologue of layer 0's block kernel)
       hipLaunchKernelGGL((cn_embed_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.cur_tok, ctx->emb, ctx->pe, step, R,
                          sqrtf((float)d), w.x, xt);
@@ -1269,6 +1269,19 @@ extern "C" int conette_set_option(conette_ctx* ctx, int32_t option, int32_t valu
   if (option == CONETTE_OPT_DECODE_GRAPH) {
     DecGraphCache* c = graph_cache(ctx, true);
     if (c) c->enabled = value ? 1 : 0;
+    return CN_OK;
+  }
+  if (option == CONETTE_OPT_DECODE_FUSION) {
+    ctx->dec_unfused = value ? 0 : 1;
+    DecGraphCache* c = graph_cache(ctx, false);
+    if (c) {  // cached graphs hold the other launch sequence
+      for (int i = 0; i < c->n; ++i)
+        if (c->g[i].exec) {
+          (void)hipGraphExecDestroy(c->g[i].exec);
+          (void)hipGraphDestroy(c->g[i].graph);
+        }
+      c->n = 0;
+    }
     return CN_OK;
   }
   cn_set_error("set_option: unknown option %d", option);

@@ -29,6 +29,7 @@ EXPORTS = (
     "conette_stream_destroy",
 )
 OPT_DECODE_GRAPH = 1
+OPT_DECODE_FUSION = 2
 PROF_CLASSES = ("frontend", "stem", "dwconv_ln", "pw1_gemm", "pw2_gemm", "downsample", "heads", "dec_prepare",
                 "dec_gemm", "dec_attn", "dec_misc", "search")
 
@@ -317,6 +318,10 @@ class Engine:
     # ---- options / profiling ------------------------------------------------------------------
     def set_decode_graph(self, enabled: bool) -> None:
         _check(self.lib.conette_set_option(self._ctx, OPT_DECODE_GRAPH, int(bool(enabled))), "set_option")
+
+    def set_decode_fusion(self, enabled: bool) -> None:
+        """bf16: fused decoder-layer kernels (default) or one launch per sub-layer (cross-check path)."""
+        _check(self.lib.conette_set_option(self._ctx, OPT_DECODE_FUSION, int(bool(enabled))), "set_option")
 
     def profile_enable(self, classes=()) -> None:
         mask = 0

@@ -127,6 +127,7 @@ int conette_stream_destroy(void* stream);
 
 /* Runtime options. */
 #define CONETTE_OPT_DECODE_GRAPH 1 /* 1 (default): replay conette_decode from a cached hipGraph */
+#define CONETTE_OPT_DECODE_FUSION 2 /* 1 (default): fused decoder-layer kernels (bf16); 0: one launch per sub-layer */
 int conette_set_option(conette_ctx* ctx, int32_t option, int32_t value);
 
 /* Per-kernel-class timing with HIP events recorded on the caller's stream around each launch

@@ -189,3 +189,71 @@ def test_predict_cli_and_offline_features(model_dir, model_fp32, tmp_path):
     off = model_fp32(feats["audio"][None], x_shapes=feats["audio_shape"][None], preprocess=False, task="clotho")
     on = model_fp32(wav0, sr=32000, task="clotho")
     assert off["preds"].cpu().tolist() == on["preds"].cpu().tolist()
+
+
+def test_long_clips_long_captions_block_path(model_bf16, model_fp32):
+    """Clips longer than 32 audio frames and captions longer than the prefetched self-attention window: the
+    remainder loops of the fused decoder kernels (dec_block.h, dec_ffn.h).  Cross-checked against the same bf16
+    engine with CONETTE_OPT_DECODE_FUSION = 0 (one launch per sub-layer: the kernels the fp32 golden tests pin),
+    step by step while both searches are on the same branch, and against the fp32 engine on the scores."""
+    from conette_amd import synth
+    B, L = 12, 15 * 32000
+    lengths = [L - 7000 * i for i in range(B)]
+    wave = torch.from_numpy(synth.synth_waveforms(B, L, 4321, lengths=lengths)).cuda()
+    e16, e32 = model_bf16.engine, model_fp32.engine
+    fe32, _ = e32.encode(wave)
+    fe16, _ = e16.encode(wave)
+    assert fe32.shape[1] > 32
+    np.testing.assert_allclose(fe16.float().cpu().numpy(), fe32.cpu().numpy(), atol=0.08, rtol=0.08)
+    lens = torch.tensor([e32.lib.conette_num_audio_frames(n) for n in lengths], dtype=torch.int32)
+    bos = model_fp32.task_id_to_token_id[torch.zeros(B, dtype=torch.long)]
+    forbid = model_fp32.forbid_rep_mask
+    beam, min_pred, max_pred = 3, 27, 30
+    fused = e16.decode(fe32, lens, bos, forbid, beam, min_pred, max_pred, want_trace=True)
+    e16.set_decode_fusion(False)
+    try:
+        plain = e16.decode(fe32, lens, bos, forbid, beam, min_pred, max_pred, want_trace=True)
+    finally:
+        e16.set_decode_fusion(True)
+    sel_f, sel_p = fused["trace_sel"].cpu().numpy(), plain["trace_sel"].cpu().numpy()
+    val_f, val_p = fused["trace_val"].cpu().numpy(), plain["trace_val"].cpu().numpy()
+    n_same_steps, n_steps = 0, 0
+    for clip in range(B):
+        for step in range(max_pred):
+            if sel_p[step, clip, 0, 0] < 0:
+                break
+            n_steps += 1
+            if not np.array_equal(sel_f[step, clip], sel_p[step, clip]):
+                break  # a near-tie resolved the other way: later steps are no longer comparable
+            live = sel_p[step, clip, :, 0] >= 0
+            np.testing.assert_allclose(val_f[step, clip][live], val_p[step, clip][live], atol=0.02 * (step + 1))
+            n_same_steps += 1
+    assert n_same_steps >= 0.8 * n_steps, (n_same_steps, n_steps)
+    p16 = fused["best_preds"].cpu()
+    assert all(int((row != 0).sum()) >= 28 for row in p16)                       # EOS floor held until step 27
+    o32 = e32.decode(fe32, lens, bos, forbid, beam, min_pred, max_pred)
+    same = [b for b in range(B) if torch.equal(o32["best_preds"].cpu()[b], p16[b])]
+    np.testing.assert_allclose(fused["best_lprobs"].cpu().numpy()[same], o32["best_lprobs"].cpu().numpy()[same], atol=0.05)
+    assert np.all(np.abs(fused["best_lprobs"].cpu().numpy() - o32["best_lprobs"].cpu().numpy()) < 0.5)
+    # batch invariance of the fused path (4-row blocks, padded rows, frame masks)
+    sub = e16.decode(fe32[:5].contiguous(), lens[:5], bos[:5], forbid, beam, min_pred, max_pred)
+    assert torch.equal(sub["best_preds"].cpu()[:, :28], p16[:5, :28])
+    np.testing.assert_allclose(sub["best_lprobs"].cpu().numpy(), fused["best_lprobs"].cpu().numpy()[:5], atol=1e-5)
+
+
+def test_decode_at_256_clips(model_bf16):
+    """BASELINE configs[2] size: 768 decoder rows.  Tiling the 64-clip batch four times must reproduce its
+    captions four times (rows are independent in every decode kernel)."""
+    from conette_amd import synth
+    eng = model_bf16.engine
+    wave = torch.from_numpy(synth.synth_waveforms(64, 320000, 1234)).cuda()
+    fe, _ = eng.encode(wave)
+    lens = torch.full((64,), fe.shape[1], dtype=torch.int32)
+    bos = model_bf16.task_id_to_token_id[torch.zeros(64, dtype=torch.long)]
+    o64 = eng.decode(fe, lens, bos, model_bf16.forbid_rep_mask, 3, 3, 20)
+    fe4 = fe.repeat(4, 1, 1).contiguous()
+    o256 = eng.decode(fe4, lens.repeat(4), bos.repeat(4), model_bf16.forbid_rep_mask, 3, 3, 20)
+    w = min(o64["best_preds"].shape[1], o256["best_preds"].shape[1])
+    for q in range(4):
+        assert torch.equal(o256["best_preds"][64 * q:64 * (q + 1), :w], o64["best_preds"][:, :w]), q
+        assert torch.equal(o256["best_lprobs"][64 * q:64 * (q + 1)], o64["best_lprobs"]), q
