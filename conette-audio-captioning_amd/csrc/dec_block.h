@@ -54,13 +54,13 @@ __device__ __forceinline__ void db_kv_load(DbKV<NB>& kv, int s0, int n_keys, Key
 
 template <int NB>
 __device__ __forceinline__ void db_kv_consume(const DbKV<NB>& kv, const f32x4& q, int s0, int n_keys, float& m,
-                                              float& l, f32x4& o) {
+                                              float& l, f32x4& o, unsigned long long valid = ~0ull) {
   float sc[NB];
 #pragma unroll
   for (int u = 0; u < NB; ++u) {
     float d = q[0] * (float)kv.k[u][0] + q[1] * (float)kv.k[u][1] + q[2] * (float)kv.k[u][2] + q[3] * (float)kv.k[u][3];
     d = cn_sum8_dpp(d);
-    sc[u] = (s0 + u < n_keys) ? d : -INFINITY;
+    sc[u] = (s0 + u < n_keys && ((valid >> ((s0 + u) & 63)) & 1)) ? d : -INFINITY;
   }
   float mb = sc[0];
 #pragma unroll
@@ -90,13 +90,13 @@ __device__ __forceinline__ void db_kv_prefetch(DbKV<NB> (&buf)[DEPTH], int n_key
 }
 template <int NB, int DEPTH, class KeyPtr, class ValPtr>
 __device__ __forceinline__ void db_kv_attend(DbKV<NB> (&buf)[DEPTH], const f32x4& q, int n_keys, KeyPtr kp, ValPtr vp,
-                                             float& m, float& l, f32x4& o) {
+                                             float& m, float& l, f32x4& o, unsigned long long valid = ~0ull) {
   for (int s0 = 0; s0 < n_keys; s0 += NB * DEPTH) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
       const int sb = s0 + d * NB;
       if (sb < n_keys) {
-        db_kv_consume(buf[d], q, sb, n_keys, m, l, o);
+        db_kv_consume(buf[d], q, sb, n_keys, m, l, o, valid);
         if (sb + NB * DEPTH < n_keys) db_kv_load(buf[d], sb + NB * DEPTH, n_keys, kp, vp);
       }
     }
@@ -243,7 +243,8 @@ __global__ __launch_bounds__(512, 1) void cn_dec_block_kernel(
     const int* __restrict__ anc, int step, int R, int beam, int maxp,
     const bf16_t* __restrict__ kvx, int kv_ld, int kv_off, const int* __restrict__ lens, int Ta,  // cross K/V
     float* __restrict__ x /* in: previous layer's x2 (residual of its FFN), out: x2 */, bf16_t* __restrict__ xt,
-    float scale, int dbg) {
+    float scale, const unsigned long long* __restrict__ kvalid /* teacher forcing: non-pad caption positions */,
+    int dbg) {
   typedef G2Geom<256> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem + DB_OFF_A;
@@ -414,10 +415,11 @@ __global__ __launch_bounds__(512, 1) void cn_dec_block_kernel(
     }
     float m = -INFINITY, l = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    db_kv_attend(skv, q, step, skp, svp, m, l, o);
+    const unsigned long long valid = kvalid ? kvalid[tr] : ~0ull;
+    db_kv_attend(skv, q, step, skp, svp, m, l, o, valid);
     // the audio K/V of the clip: first batches requested here, consumed after out-proj, LN1 and the query GEMM
     db_kv_prefetch(xkv, n_fr, xkp, xvp);
-    {  // own key / value
+    if ((valid >> step) & 1) {  // own key / value
       float d = q[0] * kn[0] + q[1] * kn[1] + q[2] * kn[2] + q[3] * kn[3];
       d = cn_sum8_dpp(d);
       const float mn = fmaxf(m, d);

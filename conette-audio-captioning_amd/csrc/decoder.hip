@@ -158,10 +158,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void cn_self_attn_kernel(const float* __restrict__ qkv, T* __restrict__ kc,
                                                            T* __restrict__ vc, const int* __restrict__ anc, int step,
                                                            int R, int beam, int maxp, float scale,
-                                                           T* __restrict__ out) {
+                                                           T* __restrict__ out,
+                                                           const unsigned long long* __restrict__ kvalid) {
   constexpr int NB = 8;
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= R) return;
+  const unsigned long long valid = kvalid ? kvalid[r] : ~0ull;  // teacher forcing: padded caption positions are no keys
   const float* row = qkv + (size_t)r * 768 + 4 * lane;
   f32x4 q = *(const f32x4*)row;
 #pragma unroll
@@ -185,10 +187,11 @@ __global__ __launch_bounds__(256) void cn_self_attn_kernel(const float* __restri
     }
     float sc[NB];
 #pragma unroll
-    for (int u = 0; u < NB; ++u) sc[u] = (s0 + u < step) ? cn_dot8(q, kk[u]) : -INFINITY;
+    for (int u = 0; u < NB; ++u)
+      sc[u] = (s0 + u < step && ((valid >> (s0 + u)) & 1)) ? cn_dot8(q, kk[u]) : -INFINITY;
     cn_attn_update<NB>(sc, vv, m, l, acc);
   }
-  {  // own entry, at cache precision
+  if ((valid >> step) & 1) {  // own entry, at cache precision
     const f32x4 kk = f32x4{cn_to_f32(cn_from_f32<T>(kn[0])), cn_to_f32(cn_from_f32<T>(kn[1])),
                            cn_to_f32(cn_from_f32<T>(kn[2])), cn_to_f32(cn_from_f32<T>(kn[3]))};
     const f32x4 v1[1] = {f32x4{cn_to_f32(cn_from_f32<T>(vn[0])), cn_to_f32(cn_from_f32<T>(vn[1])),
@@ -846,10 +849,34 @@ __global__ void cn_finalize2_kernel(int B, const int* __restrict__ eos_idx, int*
 // ---------------------------------------------------------------------------------------------
 // workspace + orchestration
 // ---------------------------------------------------------------------------------------------
+// ---- teacher forcing (nn/decoding/forcing.py:12-71): the step loop fed with the given caption instead of the search
+__global__ void cn_force_init_kernel(const int32_t* __restrict__ caps, int B, int cap_len, int pad_id,
+                                     unsigned long long* __restrict__ kvalid, int* __restrict__ anc) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= B) return;
+  unsigned long long m = 0;
+  for (int j = 0; j < cap_len; ++j) {
+    if (caps[(size_t)r * cap_len + j] != pad_id) m |= 1ull << j;  // tensor_to_pad_mask(caps_in, pad_value=pad_id)
+    anc[(size_t)r * cap_len + j] = 0;                             // beam 1: every ancestor is the row itself
+  }
+  kvalid[r] = m;
+}
+__global__ void cn_force_tok_kernel(const int32_t* __restrict__ caps, int B, int cap_len, int step, int* __restrict__ cur_tok) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < B) cur_tok[r] = caps[(size_t)r * cap_len + step];
+}
+__global__ void cn_force_store_kernel(const float* __restrict__ logits, int ldv, int V, int cap_len, int step,
+                                      float* __restrict__ out) {
+  const int r = blockIdx.y;
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < V; v += gridDim.x * blockDim.x)
+    out[((size_t)r * cap_len + step) * V + v] = logits[(size_t)r * ldv + v];
+}
+
 struct DecWs {
   void *fe_t, *mem, *kvc, *xt, *attn_t, *ffh, *kc, *vc;
   float *x, *x2, *qkv, *q, *tmp, *logits, *slabs;
   int *n_active, *slot, *prefix, *anc, *cur_tok, *out_len, *eos_idx;
+  unsigned long long* kvalid;  // teacher forcing: bit s of row r = caption position s is not padding
   float* sum_lp;
   int ldv;
   size_t total;
@@ -889,6 +916,7 @@ static DecWs dec_ws(const conette_ctx* ctx, int B, int Ta, int beam, int maxp, c
   w.cur_tok = (int*)take((size_t)R * 4);
   w.out_len = (int*)take((size_t)R * 4);
   w.eos_idx = (int*)take((size_t)B * 4);
+  w.kvalid = (unsigned long long*)take((size_t)R * 8);
   w.total = off;
   return w;
 }
@@ -902,10 +930,13 @@ template <typename T>
 static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t* frame_lens, const int32_t* bos_ids,
                        const uint8_t* forbid, int B, int Ta, int beam, int min_pred, int maxp, int32_t* best_preds,
                        float* best_lprobs, int32_t* mult_preds, float* mult_lprobs, int32_t* out_sizes,
-                       float* step0_logits, int32_t* trace_sel, float* trace_val, char* wsp, hipStream_t s) {
+                       float* step0_logits, int32_t* trace_sel, float* trace_val, char* wsp, hipStream_t s,
+                       const int32_t* force_caps = nullptr, float* force_logits = nullptr) {
   const conette_config& cfg = ctx->cfg;
   const int d = cfg.d_model, NL = cfg.n_layers, R = B * beam, V = cfg.vocab_size, dff = cfg.d_ff;
   DecWs w = dec_ws(ctx, B, Ta, beam, maxp, wsp);
+  const bool forcing = force_caps != nullptr;  // beam == 1, maxp == caption length, no search
+  const unsigned long long* kvalid = forcing ? w.kvalid : nullptr;
   T* fe_t = (T*)w.fe_t;
   T* mem = (T*)w.mem;
   T* kvc = (T*)w.kvc;
@@ -932,8 +963,17 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
                      w.sum_lp, w.prefix, w.anc, w.cur_tok, mult_preds, mult_lprobs, w.out_len, out_sizes, cfg.pad_id,
                      trace_sel, trace_val);
   CN_LAUNCH_CHECK();
+  if (forcing) {
+    hipLaunchKernelGGL(cn_force_init_kernel, dim3(cn_cdiv(B, 64)), dim3(64), 0, s, force_caps, B, maxp, cfg.pad_id,
+                       w.kvalid, w.anc);
+    CN_LAUNCH_CHECK();
+  }
 
   for (int step = 0; step < maxp; ++step) {
+    if (forcing) {
+      hipLaunchKernelGGL(cn_force_tok_kernel, dim3(cn_cdiv(B, 64)), dim3(64), 0, s, force_caps, B, maxp, step, w.cur_tok);
+      CN_LAUNCH_CHECK();
+    }
     static const int dec_fused = getenv("CN_DEC_FUSED") ? atoi(getenv("CN_DEC_FUSED")) : 0;
     static const int dec_block = getenv("CN_DEC_BLOCK") ? atoi(getenv("CN_DEC_BLOCK")) : 1;
     const bool block_path = std::is_same<T, bf16_t>::value && !dec_fused && dec_block && !ctx->dec_unfused;
@@ -974,7 +1014,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
         {
           CnProfScope ps(ctx, CONETTE_PROF_DEC_ATTN, s);
           hipLaunchKernelGGL((cn_self_attn_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.qkv, kc, vc, w.anc, step, R,
-                             beam, maxp, scale, attn_t);
+                             beam, maxp, scale, attn_t, kvalid);
           CN_LAUNCH_CHECK();
         }
         {
@@ -1053,7 +1093,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
           CN_TRY(cn_dec_block_setup());
           hipLaunchKernelGGL(cn_dec_block_kernel, dim3(cn_cdiv(R, DB_ROWS)), dim3(512), DB_LDS_BYTES, s, pro, wt, kc, vc,
                              w.anc, step, R, beam, maxp, (const bf16_t*)kvc, kv_ld, l * 2 * d, frame_lens, Ta, w.x, xt,
-                             scale, db_debug);
+                             scale, kvalid, db_debug);
           CN_LAUNCH_CHECK();
         }
         if (ffn_fused) {
@@ -1100,7 +1140,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
         {
           CnProfScope ps(ctx, CONETTE_PROF_DEC_ATTN, s);
           hipLaunchKernelGGL((cn_self_attn_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.qkv, kc, vc, w.anc, step, R,
-                             beam, maxp, scale, attn_t);
+                             beam, maxp, scale, attn_t, kvalid);
           CN_LAUNCH_CHECK();
         }
         {
@@ -1174,6 +1214,12 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
     }
     if (step == 0 && step0_logits)
       CN_HIP(hipMemcpyAsync(step0_logits, w.logits, (size_t)R * w.ldv * 4, hipMemcpyDeviceToDevice, s));
+    if (forcing) {
+      hipLaunchKernelGGL(cn_force_store_kernel, dim3(cn_cdiv(V, 1024), R), dim3(256), 0, s, w.logits, w.ldv, V, maxp, step,
+                         force_logits);
+      CN_LAUNCH_CHECK();
+      continue;
+    }
     CnProfScope ps_search(ctx, CONETTE_PROF_SEARCH, s);
     const size_t search_smem = (size_t)beam * V * sizeof(float);
     static const int search_mode = getenv("CN_SEARCH_MODE") ? atoi(getenv("CN_SEARCH_MODE")) : 3;
@@ -1210,6 +1256,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
     }
     CN_LAUNCH_CHECK();
   }
+  if (forcing) return CN_OK;
   hipLaunchKernelGGL(cn_finalize_kernel, dim3(cn_cdiv(B, 64)), dim3(64), 0, s, B, beam, maxp, cfg.eos_id, mult_preds,
                      mult_lprobs, w.out_len, best_preds, best_lprobs, w.eos_idx, out_sizes);
   CN_LAUNCH_CHECK();
@@ -1389,6 +1436,52 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
   e->graph = graph;
   CN_HIP(hipGraphLaunch(exec, s));
   return CN_OK;
+}
+
+extern "C" size_t conette_forcing_workspace_bytes(const conette_ctx* ctx, int32_t batch, int32_t t_audio,
+                                                  int32_t cap_len) {
+  if (!ctx || batch <= 0 || t_audio <= 0 || cap_len <= 0) return 0;
+  // decode workspace at beam 1 + the int32 scratch the search bookkeeping of a normal decode writes into
+  return conette_decode_workspace_bytes(ctx, batch, t_audio, 1, cap_len) + cn_align((size_t)batch * cap_len * 8) +
+         cn_align((size_t)batch * 16);
+}
+
+extern "C" int conette_forcing(conette_ctx* ctx, const float* frame_embs, const int32_t* frame_lens,
+                               const int32_t* caps_in, int32_t batch, int32_t t_audio, int32_t cap_len, float* logits,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  if (!ctx || !frame_embs || !frame_lens || !caps_in || !logits || !workspace || batch <= 0 || t_audio <= 0) {
+    cn_set_error("forcing: bad argument");
+    return CN_ERR_ARG;
+  }
+  if (cap_len < 1 || cap_len > CN_MAX_PRED || cap_len > ctx->pe_len) {
+    cn_set_error("forcing: cap_len=%d unsupported (1..%d)", cap_len, CN_MAX_PRED);
+    return CN_ERR_ARG;
+  }
+  if (ctx->cfg.d_model != 256 || ctx->cfg.nhead != 8) {
+    cn_set_error("forcing: kernels are specialised for d_model=256, nhead=8");
+    return CN_ERR_ARG;
+  }
+  const size_t need = conette_forcing_workspace_bytes(ctx, batch, t_audio, cap_len);
+  if (workspace_bytes < need) {
+    cn_set_error("forcing: workspace %zu < %zu", workspace_bytes, need);
+    return CN_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  // outputs of the search bookkeeping that a forced pass does not produce: parked in the workspace tail
+  char* tail = (char*)workspace + conette_decode_workspace_bytes(ctx, batch, t_audio, 1, cap_len);
+  int32_t* mult_preds = (int32_t*)tail;
+  float* mult_lprobs = (float*)(tail + cn_align((size_t)batch * cap_len * 4));
+  tail += cn_align((size_t)batch * cap_len * 8);
+  int32_t* sizes = (int32_t*)tail;
+  int32_t* bos = sizes + 2;  // init kernel input; any valid ids: column 0 of the captions
+  (void)bos;
+  if (ctx->cfg.precision == CONETTE_PREC_BF16)
+    return decode_impl<bf16_t>(ctx, frame_embs, frame_lens, caps_in, nullptr, batch, t_audio, 1, 0, cap_len, mult_preds,
+                               mult_lprobs, mult_preds, mult_lprobs, sizes, nullptr, nullptr, nullptr, (char*)workspace, s,
+                               caps_in, logits);
+  return decode_impl<float>(ctx, frame_embs, frame_lens, caps_in, nullptr, batch, t_audio, 1, 0, cap_len, mult_preds,
+                            mult_lprobs, mult_preds, mult_lprobs, sizes, nullptr, nullptr, nullptr, (char*)workspace, s,
+                            caps_in, logits);
 }
 
 extern "C" int conette_debug_dbprof(unsigned long long* out16, int reset) {

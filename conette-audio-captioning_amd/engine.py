@@ -26,7 +26,7 @@ EXPORTS = (
     "conette_num_audio_frames", "conette_encode_workspace_bytes", "conette_decode_workspace_bytes",
     "conette_frontend_logmel", "conette_encode", "conette_decode", "conette_resample", "conette_resample_len",
     "conette_set_option", "conette_profile_enable", "conette_profile_read", "conette_stream_create_masked",
-    "conette_stream_destroy",
+    "conette_stream_destroy", "conette_forcing_workspace_bytes", "conette_forcing",
 )
 OPT_DECODE_GRAPH = 1
 OPT_DECODE_FUSION = 2
@@ -81,6 +81,11 @@ def load_library() -> C.CDLL:
     lib.conette_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.conette_forcing_workspace_bytes.restype = C.c_size_t
+    lib.conette_forcing_workspace_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    lib.conette_forcing.restype = C.c_int
+    lib.conette_forcing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.conette_set_option.restype = C.c_int
     lib.conette_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.conette_profile_enable.restype = C.c_int
@@ -309,6 +314,22 @@ class Engine:
         if want_trace:
             out["trace_sel"] = cp(buf["trace_sel"])
             out["trace_val"] = cp(buf["trace_val"])
+        return out
+
+    def forcing(self, frame_embs: torch.Tensor, frame_lens: torch.Tensor, caps_in: torch.Tensor) -> torch.Tensor:
+        """Teacher forcing (forcing.py:12-71): frame_embs (B, T, 768), caps_in (B, cap_len) ids right-padded with
+        pad_id -> logits (B, cap_len, vocab) fp32."""
+        b, t, _ = frame_embs.shape
+        cap_len = int(caps_in.shape[1])
+        fe = frame_embs.to(self.device, torch.float32).contiguous()
+        lens = frame_lens.to(self.device, torch.int32).contiguous()
+        caps = caps_in.to(self.device, torch.int32).contiguous()
+        out = torch.empty((b, cap_len, self.vocab_size), dtype=torch.float32, device=self.device)
+        need = self.lib.conette_forcing_workspace_bytes(self._ctx, b, t, cap_len)
+        wsb = self._workspace("dec", need)
+        st = self.lib.conette_forcing(self._ctx, _ptr(fe), _ptr(lens), _ptr(caps), b, t, cap_len, _ptr(out), _ptr(wsb),
+                                      wsb.numel(), _stream())
+        _check(st, "conette_forcing")
         return out
 
     def decode_input_buffer(self, b: int, t: int, beam: int, max_pred: int, slot: int = 0) -> torch.Tensor:

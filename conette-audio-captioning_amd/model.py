@@ -250,6 +250,34 @@ class CoNeTTEModel:
                             beam_size=beam_size, min_pred_size=min_pred_size, max_pred_size=max_pred_size,
                             forbid_rep_mode=forbid_rep_mode)
 
+    def teacher_forcing(self, x, caps_in: Tensor, sr=None, x_shapes=None, preprocess: bool = True) -> Tensor:
+        """CoNeTTEPLM.decode_audio(encode_audio(...), "forcing", caps_in=caps_in) (pl_modules/conette.py:392-417,
+        nn/decoding/forcing.py:12-71): logits (B, vocab, cap_len) of given input captions in one causal pass.
+
+        ``caps_in`` (B, cap_len): token ids, column 0 = the task token that replaced <bos>
+        (``batch_to_task_token_ids``), right-padded with pad_id.  ``x`` as in ``forward`` (waveforms, or the
+        preprocessor's output dict / (B, T, 768) embeddings with ``preprocess=False``)."""
+        caps_in = torch.as_tensor(caps_in)
+        if caps_in.ndim != 2 or caps_in.is_floating_point():
+            raise ValueError("caps_in must be an integer tensor of shape (bsize, caps_size).")
+        if bool(caps_in[:, 0].eq(self.tokenizer.bos_token_id).any()):
+            raise ValueError("BOS was not replaced in input captions for decode_method='forcing'.")
+        if preprocess:
+            batch = self.preprocessor(x, sr, x_shapes)
+            audio, audio_shape = batch["audio"], batch["audio_shape"]
+        elif isinstance(x, dict):
+            audio, audio_shape = x["audio"], x["audio_shape"]
+        else:
+            audio = x
+            audio_shape = x_shapes if x_shapes is not None else torch.as_tensor([list(a.shape) for a in x])
+        if audio.ndim == 4:
+            audio = audio.squeeze(dim=1)
+        if caps_in.shape[0] != audio.shape[0]:
+            raise ValueError(f"Invalid number of captions {caps_in.shape[0]} for {audio.shape[0]} audio clips.")
+        lens = torch.as_tensor(audio_shape)[:, 1].to(torch.int32)
+        logits = self.engine.forcing(audio, lens, caps_in)  # (B, cap_len, V)
+        return logits.permute(0, 2, 1)
+
     def _generate(self, audio: Tensor, audio_shape: Tensor, datasets: List[str], sources: List[Optional[str]], *,
                   beam_size=None, min_pred_size=None, max_pred_size=None, forbid_rep_mode=None) -> Dict[str, Any]:
         """CoNeTTEPLM.forward("generate") = encode_audio + decode_audio + decode_text (conette.py:352-450)."""

@@ -111,6 +111,18 @@ int conette_decode(conette_ctx* ctx, const float* frame_embs, const int32_t* fra
                    int32_t* mult_preds, float* mult_lprobs, int32_t* out_sizes, float* step0_logits,
                    int32_t* trace_sel, float* trace_val, void* workspace, size_t workspace_bytes, void* stream);
 
+/* teacher forcing (nn/decoding/forcing.py:12-71 as called by CoNeTTEPLM.decode_audio(..., "forcing",
+ * caps_in=...), pl_modules/conette.py:392-417, after the projection of conette.py:457): the logits of every position of
+ * given input captions under the causal mask, padded caption positions masked as keys
+ * (tensor_to_pad_mask(caps_in, pad_value=pad_id)).
+ *   caps_in : dev (B, cap_len) int32, column 0 = the task token that replaced <bos>, right-padded with pad_id
+ *   logits  : dev (B, cap_len, vocab) fp32 -- the reference returns the same values permuted to (B, vocab, cap_len)
+ * Runs the KV-cached step kernels of conette_decode with the next token taken from caps_in instead of the search. */
+size_t conette_forcing_workspace_bytes(const conette_ctx* ctx, int32_t batch, int32_t t_audio, int32_t cap_len);
+int conette_forcing(conette_ctx* ctx, const float* frame_embs, const int32_t* frame_lens, const int32_t* caps_in,
+                    int32_t batch, int32_t t_audio, int32_t cap_len, float* logits, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
 /* a1: torchaudio.functional.resample (preprocessor.py:134-141), sinc_interpolation width 6,
  * rolloff 0.99.  in: dev (rows, n_in) fp32; out: dev (rows, n_out), n_out = ceil(n_in*new/orig). */
 int conette_resample(const float* in, int32_t rows, int32_t n_in, int32_t orig_sr, int32_t new_sr, float* out,

@@ -247,8 +247,8 @@ def _mha(x_q: Tensor, x_kv: Tensor, w_in: Tensor, b_in: Tensor, w_out: Tensor, b
 
 
 def decoder_forward(w: Weights, memory: Tensor, mem_pad_mask: Optional[Tensor], caps_in: Tensor,
-                    nhead: int = 8, n_layers: int = 6) -> Tensor:
-    """memory (T, R, d), mask (R, T) bool, caps_in (t, R) ids -> logits (t, R, V)."""
+                    nhead: int = 8, n_layers: int = 6, caps_pad_mask: Optional[Tensor] = None) -> Tensor:
+    """memory (T, R, d), mask (R, T) bool, caps_in (t, R) ids [, caps_pad_mask (R, t) bool] -> logits (t, R, V)."""
     D = "model.decoder."
     d = w[D + "emb_layer.weight"].shape[1]
     t = caps_in.shape[0]
@@ -258,7 +258,7 @@ def decoder_forward(w: Weights, memory: Tensor, mem_pad_mask: Optional[Tensor], 
     for l in range(n_layers):
         p = D + f"layers.{l}."
         sa = _mha(x, x, w[p + "self_attn.in_proj_weight"], w[p + "self_attn.in_proj_bias"],
-                  w[p + "self_attn.out_proj.weight"], w[p + "self_attn.out_proj.bias"], nhead, sq_mask, None)
+                  w[p + "self_attn.out_proj.weight"], w[p + "self_attn.out_proj.bias"], nhead, sq_mask, caps_pad_mask)
         x = F.layer_norm(x + sa, (d,), w[p + "norm1.weight"], w[p + "norm1.bias"], 1e-5)
         ca = _mha(x, memory, w[p + "multihead_attn.in_proj_weight"], w[p + "multihead_attn.in_proj_bias"],
                   w[p + "multihead_attn.out_proj.weight"], w[p + "multihead_attn.out_proj.bias"], nhead, None,
@@ -268,6 +268,27 @@ def decoder_forward(w: Weights, memory: Tensor, mem_pad_mask: Optional[Tensor], 
                       w[p + "linear2.weight"], w[p + "linear2.bias"])
         x = F.layer_norm(x + ff, (d,), w[p + "norm3.weight"], w[p + "norm3.bias"], 1e-5)
     return F.linear(x, w[D + "classifier.weight"], w[D + "classifier.bias"])
+
+
+# ----------------------------------------------------------------------------------------
+# 8(f)3  teacher forcing -- nn/decoding/forcing.py:12-71 via pl_modules/conette.py:392-417
+# ----------------------------------------------------------------------------------------
+@torch.no_grad()
+def teacher_forcing(w: Weights, audio: Tensor, audio_shape: Tensor, caps_in: Tensor, *, pad_id: int = 0,
+                    bos_id: int = 1, nhead: int = 8, n_layers: int = 6) -> Tensor:
+    """frame embeddings (B, T, 768) + input captions (B, t) -> logits (B, V, t).
+
+    encode_audio (conette.py:452-470: projection + frame pad mask), then ONE causal decoder pass over caps_in with
+    caps_in_pad_mask = tensor_to_pad_mask(caps_in, pad_value=pad_id) (forcing.py:44-49) and the square subsequent
+    mask (:51-55); the result is permuted (caps, B, V) -> (B, V, caps) (:68-70).  conette.py:399-404 rejects captions
+    whose first token is still <bos> (the task token must have replaced it)."""
+    if bool(caps_in[:, 0].eq(bos_id).any()):
+        raise ValueError("BOS was not replaced in input captions for decode_method='forcing'.")
+    memory_bdt, mask = encode_audio(w, audio, audio_shape)
+    caps_pad_mask = caps_in.eq(pad_id)
+    logits = decoder_forward(w, memory_bdt.permute(2, 0, 1), mask, caps_in.permute(1, 0), nhead, n_layers,
+                             caps_pad_mask=caps_pad_mask)
+    return logits.permute(1, 2, 0)
 
 
 # ----------------------------------------------------------------------------------------

@@ -257,3 +257,24 @@ def test_decode_at_256_clips(model_bf16):
     for q in range(4):
         assert torch.equal(o256["best_preds"][64 * q:64 * (q + 1), :w], o64["best_preds"][:, :w]), q
         assert torch.equal(o256["best_lprobs"][64 * q:64 * (q + 1)], o64["best_lprobs"]), q
+
+
+def test_model_teacher_forcing_api(model_fp32):
+    """CoNeTTEModel.teacher_forcing mirrors CoNeTTEPLM.decode_audio(..., "forcing", caps_in=...): waveform input,
+    (B, vocab, cap_len) output, the reference's BOS check."""
+    from conette_amd import synth
+    g = np.load(os.path.join(G.GOLDEN, "forcing", "forcing_ragged.npz"))
+    n = [int(v) for v in g["lengths"]]
+    wav = synth.synth_waveforms(len(n), max(n), int(g["seed0"]), lengths=n)
+    x = [torch.from_numpy(wav[i, : n[i]].copy())[None, :] for i in range(len(n))]
+    caps = torch.from_numpy(g["caps_in"])
+    logits = model_fp32.teacher_forcing(x, caps, sr=32000)
+    assert tuple(logits.shape) == tuple(g["logits"].shape)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=2e-3, atol=5e-3)
+    pre = {"audio": torch.from_numpy(g["frame_embs"]), "audio_shape": torch.from_numpy(g["audio_shape"])}
+    logits2 = model_fp32.teacher_forcing(pre, caps, preprocess=False)
+    np.testing.assert_allclose(logits2.cpu().numpy(), g["logits"], rtol=1e-3, atol=2e-3)
+    bad = caps.clone()
+    bad[0, 0] = 1
+    with pytest.raises(ValueError, match="BOS was not replaced"):
+        model_fp32.teacher_forcing(pre, bad, preprocess=False)

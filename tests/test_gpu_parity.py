@@ -157,3 +157,36 @@ def test_resample_against_oracle(engines):
         ref = tp.resample(x, o, n)
         assert got.shape == ref.shape
         np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_teacher_forcing_matches_reference_fixture(prec, engines):
+    """conette_forcing against logits produced by the reference itself (all caption positions,
+    padded ones included: padded positions are masked as keys exactly like tensor_to_pad_mask does)."""
+    g = np.load(os.path.join(G.GOLDEN, "forcing", "forcing_ragged.npz"))
+    eng = engines[prec]
+    fe = torch.from_numpy(g["frame_embs"]).cuda()
+    lens = torch.from_numpy(g["audio_shape"][:, 1].astype(np.int32))
+    caps = torch.from_numpy(g["caps_in"])
+    got = eng.forcing(fe, lens, caps).permute(0, 2, 1).cpu().numpy()  # (B, V, cap_len) like the reference
+    ref = g["logits"]
+    assert got.shape == ref.shape
+    if prec == "fp32":
+        np.testing.assert_allclose(got, ref, rtol=1e-3, atol=2e-3)
+    else:
+        # bf16 operands: logits span +-40; compare log-probabilities of the reference's top candidates
+        err = np.abs(got - ref)
+        assert err.max() < 0.6 and err.mean() < 0.06, (err.max(), err.mean())
+        lp_got = torch.log_softmax(torch.from_numpy(got), dim=1)
+        lp_ref = torch.log_softmax(torch.from_numpy(ref), dim=1)
+        top = lp_ref.argmax(dim=1, keepdim=True)
+        d = (lp_got.gather(1, top) - lp_ref.gather(1, top))[:, 0].numpy()      # (B, cap_len)
+        assert np.abs(d).max() < 0.12, np.abs(d).max()                          # per token
+        valid = g["caps_in"] != 0
+        per_cap = np.abs((d * valid).sum(axis=1) / valid.sum(axis=1))           # length-averaged, like the beam score
+        assert per_cap.max() < 0.05, per_cap                                    # north_star bf16 tolerance
+    # twice the same call: deterministic; a batch of one: row independent
+    again = eng.forcing(fe, lens, caps).permute(0, 2, 1).cpu().numpy()
+    assert np.array_equal(got, again)
+    one = eng.forcing(fe[1:2].contiguous(), lens[1:2], caps[1:2]).permute(0, 2, 1).cpu().numpy()
+    np.testing.assert_allclose(one[0], got[1], atol=1e-5 if prec == "fp32" else 1e-3)

@@ -67,3 +67,19 @@ def test_oracle_api_cases(synth_weights, synth_cfg):
     assert str(e.value) == api["bad_ntasks_error"]
     with pytest.raises(ValueError):
         f(wav[0], sr=16000, x_shapes=torch.tensor([[64000]]))
+
+
+def test_oracle_teacher_forcing_matches_reference_fixture(synth_weights):
+    """the oracle's restatement of forcing.py against logits produced by the reference itself
+    (oracle/gen_golden_forcing.py)."""
+    import os
+    g = np.load(os.path.join(G.GOLDEN, "forcing", "forcing_ragged.npz"))
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    logits = O.teacher_forcing(synth_weights, torch.from_numpy(g["frame_embs"]), torch.from_numpy(g["audio_shape"]),
+                               torch.from_numpy(g["caps_in"]))
+    assert tuple(logits.shape) == tuple(g["logits"].shape)  # (B, V, cap_len)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=1e-4, atol=2e-4)
+    bad = torch.from_numpy(g["caps_in"]).clone()
+    bad[0, 0] = 1  # <bos> left in place of the task token (conette.py:399-404)
+    with pytest.raises(ValueError, match="BOS was not replaced"):
+        O.teacher_forcing(synth_weights, torch.from_numpy(g["frame_embs"]), torch.from_numpy(g["audio_shape"]), bad)
