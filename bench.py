@@ -39,7 +39,39 @@ PEAK_BF16_TFLOPS = 2500.0                    # dense MFMA bf16 (MI355X_MICROARCH
 PEAK_HBM_GBS = 8000.0                        # HBM3E spec (MI355X_MICROARCH.md)
 
 
-FUSED_STAGES = (0, 1)  # C = 96 / 192: pw1 + GELU + pw2 run as ONE kernel (mlp_fused.h), timed under "pw1_gemm"
+# C = 96 / 192 / 384: pw1 + GELU + pw2 run as ONE kernel (mlp_fused.h), timed under "pw1_gemm"
+FUSED_STAGES = (0, 1) if os.environ.get("CN_MLP384") == "0" else (0, 1, 2)
+# kernel-name fragments of each profiling class in the committed PMC table (profiles/*_pmc_hbm_traffic.csv)
+PMC_KERNELS = {
+    "pw1_gemm": ("cn_mlp_fused_kernel", "EpiBiasActIDF16bLi4"),
+    "pw2_gemm": ("EpiResid",),
+    "dwconv_ln": ("cn_dwconv_ln_kernel",),
+}
+
+
+def pmc_traffic(cls: str, batch: int, launches_per_step: float):
+    """HBM bytes per launch of a kernel class from the newest committed rocprofv3 PMC table (separate FETCH_SIZE and
+    WRITE_SIZE passes of this benchmark at B = 64, bf16; FETCH_SIZE doubled: gfx950 tallies wide streaming reads at
+    half their size, MI355X_MICROARCH.md).  None when no table matches the configuration."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.csv")))
+    if not files or batch != 64:
+        return None, None
+    tot = 0.0
+    n_disp = {}
+    for r in csv.DictReader(open(files[-1])):
+        keys = list(r.keys())
+        name, disp, kb = r[keys[1]], int(r[keys[3]]), float(r[keys[4]])
+        if not any(f in name for f in PMC_KERNELS.get(cls, ())):
+            continue
+        n_disp.setdefault(r[keys[0]], 0)
+        n_disp[r[keys[0]]] += disp
+        tot += (2.0 if r[keys[0]] == "FETCH_SIZE" else 1.0) * kb * 1024.0 * disp
+    if not n_disp:
+        return None, None
+    passes = max(n_disp.values()) / max(launches_per_step, 1.0)  # profiled batches in the table
+    return tot / passes / launches_per_step, os.path.basename(files[-1])
 
 
 def algorithmic_work(cls: str, batch: int):
@@ -199,6 +231,13 @@ def main() -> None:
                 "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None}
     roof["avg_launch_us"] = round(avg_launch_s * 1e6, 2)
     roof["launches_per_step"] = launches_per_step
+    if args.precision == "bf16":
+        tr, src = pmc_traffic(dominant, B, launches_per_step)
+        if tr is not None:
+            roof["traffic"] = round(tr)            # HBM bytes per launch (class average), PMC
+            roof["traffic_unit"] = "bytes/launch"
+            roof["traffic_source"] = "profiles/" + src
+            roof["algorithmic_bytes_per_launch"] = round(by / launches_per_step)
 
     result = None
     if rank == 0:
