@@ -306,6 +306,148 @@ static int launch_dwconv(const float* x, int B, int H, int W, const CnBlockW& bw
 }
 
 // ---------------------------------------------------------------------------------------------
+// Full-width variant for the deep stages (W = 14 at C = 384, W = 7 at C = 768: the frequency axis, a constant
+// of the architecture whatever the clip length).  With 4-wide tiles almost no tile of such a narrow map is
+// "interior", so every load went through the clamped / masked slow path and each input element was fetched
+// ~6x (10 x 10 halo per 4 x 4 outputs): rocprof 113 us per launch at 1.1 TB/s of HBM traffic, 4x the VALU
+// floor.  Here a block owns TH rows x the WHOLE width for all channels: a thread (= channel) keeps TH x WW
+// accumulators, every input row is loaded once (WW coalesced loads), the left / right zero padding is resolved
+// at compile time (taps that fall outside simply do not exist) and rows above / below the map are skipped by a
+// block-uniform branch.  LayerNorm: conv results through an LDS tile [pos][C], one wave per position with DPP
+// sums, two positions in flight; 16-byte bf16 stores as in the tiled kernel.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int C, int WW, int TH>
+__global__ __launch_bounds__(384) void cn_dwconv_ln_fw_kernel(const float* __restrict__ x, int H, int tiles_h,
+                                                              const float* __restrict__ dw_w /*[49][C]*/,
+                                                              const float* __restrict__ dw_b,
+                                                              const float* __restrict__ ln_w,
+                                                              const float* __restrict__ ln_b, T* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* s_v = (float*)smem_raw;  // [TH*WW][C + 1]
+  constexpr int CT = 384, NPOS = TH * WW, PITCH = C + 1, NW = CT / 64;
+  float* s_mean = s_v + NPOS * PITCH;
+  float* s_rstd = s_mean + NPOS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int bid = cn_xcd_remap(blockIdx.x, gridDim.x);
+  const int th = bid % tiles_h;
+  const int b = bid / tiles_h;
+  const int h0 = th * TH;
+
+#pragma unroll 1
+  for (int c = tid; c < C; c += CT) {
+    float k[49];
+#pragma unroll
+    for (int i = 0; i < 49; ++i) k[i] = dw_w[i * C + c];
+    float acc[TH][WW];
+    const float bias = dw_b[c];
+#pragma unroll
+    for (int a = 0; a < TH; ++a)
+#pragma unroll
+      for (int e = 0; e < WW; ++e) acc[a][e] = bias;
+    const float* xb = x + (size_t)b * H * WW * C + c;
+    auto load_row = [&](int r, float (&v)[WW]) {
+      const int hh = h0 - 3 + r;
+      if (hh >= 0 && hh < H) {  // block-uniform
+        const float* xr = xb + (size_t)hh * WW * C;
+#pragma unroll
+        for (int q = 0; q < WW; ++q) v[q] = xr[q * C];
+      } else {
+#pragma unroll
+        for (int q = 0; q < WW; ++q) v[q] = 0.f;
+      }
+    };
+    auto fma_row = [&](int r, const float (&v)[WW]) {
+#pragma unroll
+      for (int oh = 0; oh < TH; ++oh) {
+        const int i = r - oh;
+        if (i < 0 || i > 6) continue;
+#pragma unroll
+        for (int ow = 0; ow < WW; ++ow)
+#pragma unroll
+          for (int j = 0; j < 7; ++j) {
+            const int q = ow + j - 3;
+            if (q < 0 || q >= WW) continue;  // zero padding left / right of the map: the tap does not exist
+            acc[oh][ow] = fmaf(v[q], k[i * 7 + j], acc[oh][ow]);
+          }
+      }
+    };
+    float va[WW], vb[WW];
+    load_row(0, va);
+#pragma unroll
+    for (int r = 0; r < TH + 6; r += 2) {
+      if (r + 1 < TH + 6) load_row(r + 1, vb);
+      fma_row(r, va);
+      if (r + 2 < TH + 6) load_row(r + 2, va);
+      if (r + 1 < TH + 6) fma_row(r + 1, vb);
+    }
+#pragma unroll
+    for (int oh = 0; oh < TH; ++oh)
+#pragma unroll
+      for (int ow = 0; ow < WW; ++ow) s_v[(oh * WW + ow) * PITCH + c] = acc[oh][ow];
+  }
+  __syncthreads();
+  // LayerNorm statistics: wave per position, C / 64 values per lane, two positions per iteration
+  constexpr int VPL = C / 64;
+  for (int p0 = wave * 2; p0 < NPOS; p0 += NW * 2) {
+    const int p1 = min(p0 + 1, NPOS - 1);
+    float a0[VPL], a1[VPL], s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      a0[i] = s_v[p0 * PITCH + i * 64 + lane];
+      a1[i] = s_v[p1 * PITCH + i * 64 + lane];
+      s0 += a0[i];
+      s1 += a1[i];
+    }
+    const float m0 = cn_wave_sum_dpp(s0) * (1.0f / C), m1 = cn_wave_sum_dpp(s1) * (1.0f / C);
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      q0 = fmaf(a0[i] - m0, a0[i] - m0, q0);
+      q1 = fmaf(a1[i] - m1, a1[i] - m1, q1);
+    }
+    q0 = cn_wave_sum_dpp(q0);
+    q1 = cn_wave_sum_dpp(q1);
+    if (lane == 0) {
+      s_mean[p0] = m0;
+      s_rstd[p0] = 1.0f / sqrtf(q0 * (1.0f / C) + 1e-6f);
+      s_mean[p1] = m1;
+      s_rstd[p1] = 1.0f / sqrtf(q1 * (1.0f / C) + 1e-6f);
+    }
+  }
+  __syncthreads();
+  constexpr int C8 = C / 8;
+  for (int item = tid; item < NPOS * C8; item += CT) {
+    const int pos = item / C8, c8 = (item % C8) * 8;
+    const int h = h0 + pos / WW, w = pos % WW;
+    if (h >= H) continue;
+    const float mean = s_mean[pos], rstd = s_rstd[pos];
+    const float* src = s_v + pos * PITCH + c8;
+    T* dst = y + (((size_t)b * H + h) * WW + w) * C + c8;
+    float o[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (src[i] - mean) * rstd * ln_w[c8 + i] + ln_b[c8 + i];
+    cn_store4(dst, o[0], o[1], o[2], o[3]);
+    cn_store4(dst + 4, o[4], o[5], o[6], o[7]);
+  }
+}
+
+template <typename T, int C, int WW, int TH>
+static int launch_dwconv_fw(const float* x, int B, int H, const CnBlockW& bw, T* y, hipStream_t s) {
+  const int tiles_h = cn_cdiv(H, TH);
+  const size_t smem = ((size_t)TH * WW * (C + 1) + 2 * TH * WW) * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    CN_HIP(hipFuncSetAttribute((const void*)cn_dwconv_ln_fw_kernel<T, C, WW, TH>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    configured = true;
+  }
+  hipLaunchKernelGGL((cn_dwconv_ln_fw_kernel<T, C, WW, TH>), dim3((unsigned)(B * tiles_h)), dim3(384), smem, s, x, H,
+                     tiles_h, bw.dw_w, bw.dw_b, bw.ln_w, bw.ln_b, y);
+  CN_LAUNCH_CHECK();
+  return CN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // downsample input: LayerNorm(channels_first == per-position over C, eps 1e-6) + 2x2/2 patchify
 // x fp32 (B,H,W,C) -> p T (B, H/2, W/2, (kh, kw, C)); rows/cols beyond 2*floor() are dropped.
 // One wave per input position.
@@ -479,13 +621,22 @@ extern "C" size_t conette_encode_workspace_bytes(const conette_ctx* ctx, int32_t
   return enc_ws(ctx, batch, n_samples, nullptr).total;
 }
 
+static inline int dw_fullwidth() {
+  static const int v = getenv("CN_DW_FULLWIDTH") ? atoi(getenv("CN_DW_FULLWIDTH")) : 1;
+  return v;
+}
+
 template <typename T>
 static int dwconv_dispatch(int C, const float* x, int B, int H, int W, const CnBlockW& bw, T* y, hipStream_t s) {
   switch (C) {
     case 96: return launch_dwconv<T, 96, 2, 8>(x, B, H, W, bw, y, s);
     case 192: return launch_dwconv<T, 192, 1, 8>(x, B, H, W, bw, y, s);
-    case 384: return launch_dwconv<T, 384, 1, 4>(x, B, H, W, bw, y, s);
-    case 768: return launch_dwconv<T, 768, 1, 4>(x, B, H, W, bw, y, s);
+    case 384:
+      if (W == 14 && dw_fullwidth()) return launch_dwconv_fw<T, 384, 14, 4>(x, B, H, bw, y, s);
+      return launch_dwconv<T, 384, 1, 4>(x, B, H, W, bw, y, s);
+    case 768:
+      if (W == 7 && dw_fullwidth()) return launch_dwconv_fw<T, 768, 7, 4>(x, B, H, bw, y, s);
+      return launch_dwconv<T, 768, 1, 4>(x, B, H, W, bw, y, s);
   }
   cn_set_error("dwconv: unsupported C=%d", C);
   return CN_ERR_ARG;
