@@ -872,6 +872,36 @@ __global__ void cn_force_store_kernel(const float* __restrict__ logits, int ldv,
     out[((size_t)r * cap_len + step) * V + v] = logits[(size_t)r * ldv + v];
 }
 
+// ---- greedy_search's full-logit output (nn/decoding/greedy.py:17-131): the step's logits of every unfinished clip
+// with the EOS floor (:96-97) and the forbid-repeat mask (:99-105) applied, (-inf, pad_id -> 0) for finished clips (:64-69)
+__global__ __launch_bounds__(256) void cn_greedy_logits_kernel(const float* __restrict__ logits, int ldv, int V, int maxp,
+                                                               int step, int min_pred, int eos_id, int pad_id,
+                                                               const uint8_t* __restrict__ forbid,
+                                                               const int* __restrict__ n_active,
+                                                               const int* __restrict__ prefix, float* __restrict__ out) {
+  __shared__ int s_tok[CN_MAX_PRED + 1];
+  const int b = blockIdx.y;
+  const bool active = n_active[b] > 0;
+  for (int j = threadIdx.x; j <= step; j += 256) s_tok[j] = prefix[(size_t)b * (maxp + 1) + j];
+  __syncthreads();
+  float* o = out + ((size_t)b * maxp + step) * V;
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < V; v += gridDim.x * 256) {
+    float x;
+    if (!active) {
+      x = v == pad_id ? 0.f : -INFINITY;
+    } else {
+      x = logits[(size_t)b * ldv + v];
+      if (step < min_pred && v == eos_id) x = -INFINITY;
+      if (forbid != nullptr && forbid[v]) {
+        bool seen = false;
+        for (int j = 0; j <= step; ++j) seen |= s_tok[j] == v;
+        if (seen) x = -INFINITY;
+      }
+    }
+    o[v] = x;
+  }
+}
+
 struct DecWs {
   void *fe_t, *mem, *kvc, *xt, *attn_t, *ffh, *kc, *vc;
   float *x, *x2, *qkv, *q, *tmp, *logits, *slabs;
@@ -931,7 +961,8 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
                        const uint8_t* forbid, int B, int Ta, int beam, int min_pred, int maxp, int32_t* best_preds,
                        float* best_lprobs, int32_t* mult_preds, float* mult_lprobs, int32_t* out_sizes,
                        float* step0_logits, int32_t* trace_sel, float* trace_val, char* wsp, hipStream_t s,
-                       const int32_t* force_caps = nullptr, float* force_logits = nullptr) {
+                       const int32_t* force_caps = nullptr, float* force_logits = nullptr,
+                       float* greedy_logits = nullptr) {
   const conette_config& cfg = ctx->cfg;
   const int d = cfg.d_model, NL = cfg.n_layers, R = B * beam, V = cfg.vocab_size, dff = cfg.d_ff;
   DecWs w = dec_ws(ctx, B, Ta, beam, maxp, wsp);
@@ -1220,6 +1251,11 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
       CN_LAUNCH_CHECK();
       continue;
     }
+    if (greedy_logits) {  // beam == 1: rows == clips; before the search step updates prefix / n_active
+      hipLaunchKernelGGL(cn_greedy_logits_kernel, dim3(cn_cdiv(V, 1024), B), dim3(256), 0, s, w.logits, w.ldv, V, maxp, step,
+                         min_pred, cfg.eos_id, cfg.pad_id, forbid, w.n_active, w.prefix, greedy_logits);
+      CN_LAUNCH_CHECK();
+    }
     CnProfScope ps_search(ctx, CONETTE_PROF_SEARCH, s);
     const size_t search_smem = (size_t)beam * V * sizeof(float);
     static const int search_mode = getenv("CN_SEARCH_MODE") ? atoi(getenv("CN_SEARCH_MODE")) : 3;
@@ -1482,6 +1518,49 @@ extern "C" int conette_forcing(conette_ctx* ctx, const float* frame_embs, const 
   return decode_impl<float>(ctx, frame_embs, frame_lens, caps_in, nullptr, batch, t_audio, 1, 0, cap_len, mult_preds,
                             mult_lprobs, mult_preds, mult_lprobs, sizes, nullptr, nullptr, nullptr, (char*)workspace, s,
                             caps_in, logits);
+}
+
+extern "C" int conette_greedy(conette_ctx* ctx, const float* frame_embs, const int32_t* frame_lens, const int32_t* bos_ids,
+                              const uint8_t* forbid_mask, int32_t batch, int32_t t_audio, int32_t min_pred,
+                              int32_t max_pred, float* logits, int32_t* preds, int32_t* out_sizes, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  if (!ctx || !frame_embs || !frame_lens || !bos_ids || !logits || !preds || !out_sizes || !workspace || batch <= 0 ||
+      t_audio <= 0) {
+    cn_set_error("greedy: bad argument");
+    return CN_ERR_ARG;
+  }
+  if (max_pred < 1 || max_pred > CN_MAX_PRED || max_pred > ctx->pe_len || min_pred < 0) {
+    cn_set_error("greedy: max_pred=%d (1..%d) min_pred=%d unsupported", max_pred, CN_MAX_PRED, min_pred);
+    return CN_ERR_ARG;
+  }
+  if (ctx->cfg.d_model != 256 || ctx->cfg.nhead != 8) {
+    cn_set_error("greedy: kernels are specialised for d_model=256, nhead=8");
+    return CN_ERR_ARG;
+  }
+  const size_t base = conette_decode_workspace_bytes(ctx, batch, t_audio, 1, max_pred);
+  const size_t need = base + cn_align((size_t)batch * max_pred * 4) + 2 * cn_align((size_t)batch * 4);
+  if (workspace_bytes < need) {
+    cn_set_error("greedy: workspace %zu < %zu", workspace_bytes, need);
+    return CN_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  char* tail = (char*)workspace + base;
+  int32_t* mult_preds = (int32_t*)tail;  // beam 1: the single hypothesis of every clip
+  float* mult_lprobs = (float*)(tail + cn_align((size_t)batch * max_pred * 4));
+  float* best_lprobs = (float*)(tail + cn_align((size_t)batch * max_pred * 4) + cn_align((size_t)batch * 4));
+  if (ctx->cfg.precision == CONETTE_PREC_BF16)
+    return decode_impl<bf16_t>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, 1, min_pred, max_pred, preds,
+                               best_lprobs, mult_preds, mult_lprobs, out_sizes, nullptr, nullptr, nullptr, (char*)workspace,
+                               s, nullptr, nullptr, logits);
+  return decode_impl<float>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, 1, min_pred, max_pred, preds,
+                            best_lprobs, mult_preds, mult_lprobs, out_sizes, nullptr, nullptr, nullptr, (char*)workspace, s,
+                            nullptr, nullptr, logits);
+}
+
+extern "C" size_t conette_greedy_workspace_bytes(const conette_ctx* ctx, int32_t batch, int32_t t_audio, int32_t max_pred) {
+  if (!ctx || batch <= 0 || t_audio <= 0 || max_pred <= 0) return 0;
+  return conette_decode_workspace_bytes(ctx, batch, t_audio, 1, max_pred) + cn_align((size_t)batch * max_pred * 4) +
+         2 * cn_align((size_t)batch * 4);
 }
 
 extern "C" int conette_debug_dbprof(unsigned long long* out16, int reset) {

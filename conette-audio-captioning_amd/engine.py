@@ -27,6 +27,7 @@ EXPORTS = (
     "conette_frontend_logmel", "conette_encode", "conette_decode", "conette_resample", "conette_resample_len",
     "conette_set_option", "conette_profile_enable", "conette_profile_read", "conette_stream_create_masked",
     "conette_stream_destroy", "conette_forcing_workspace_bytes", "conette_forcing",
+    "conette_greedy_workspace_bytes", "conette_greedy",
 )
 OPT_DECODE_GRAPH = 1
 OPT_DECODE_FUSION = 2
@@ -86,6 +87,12 @@ def load_library() -> C.CDLL:
     lib.conette_forcing.restype = C.c_int
     lib.conette_forcing.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.conette_greedy_workspace_bytes.restype = C.c_size_t
+    lib.conette_greedy_workspace_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    lib.conette_greedy.restype = C.c_int
+    lib.conette_greedy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                   C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                   C.c_void_p]
     lib.conette_set_option.restype = C.c_int
     lib.conette_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.conette_profile_enable.restype = C.c_int
@@ -331,6 +338,25 @@ class Engine:
                                       wsb.numel(), _stream())
         _check(st, "conette_forcing")
         return out
+
+    def greedy(self, frame_embs: torch.Tensor, frame_lens: torch.Tensor, bos_ids: torch.Tensor,
+               forbid_mask: Optional[torch.Tensor], min_pred: int, max_pred: int) -> Dict[str, torch.Tensor]:
+        """greedy_search (greedy.py:17-131): {"logits": (B, pred_size, vocab) masked step logits, "preds": (B, pred_size)}."""
+        b, t, _ = frame_embs.shape
+        fe = frame_embs.to(self.device, torch.float32).contiguous()
+        lens = frame_lens.to(self.device, torch.int32).contiguous()
+        bos = bos_ids.to(self.device, torch.int32).contiguous()
+        fm = None if forbid_mask is None else forbid_mask.to(self.device, torch.uint8).contiguous()
+        logits = torch.empty((b, max_pred, self.vocab_size), dtype=torch.float32, device=self.device)
+        preds = torch.empty((b, max_pred), dtype=torch.int32, device=self.device)
+        sizes = torch.zeros((2,), dtype=torch.int32, device=self.device)
+        need = self.lib.conette_greedy_workspace_bytes(self._ctx, b, t, max_pred)
+        wsb = self._workspace("dec", need)
+        st = self.lib.conette_greedy(self._ctx, _ptr(fe), _ptr(lens), _ptr(bos), _ptr(fm), b, t, int(min_pred), int(max_pred),
+                                     _ptr(logits), _ptr(preds), _ptr(sizes), _ptr(wsb), wsb.numel(), _stream())
+        _check(st, "conette_greedy")
+        ps = int(sizes[0].item())
+        return {"logits": logits[:, :ps].contiguous(), "preds": preds[:, :ps].contiguous()}
 
     def decode_input_buffer(self, b: int, t: int, beam: int, max_pred: int, slot: int = 0) -> torch.Tensor:
         """The persistent (B, T, 768) input of decode(): encode straight into it to skip a copy."""

@@ -278,6 +278,30 @@ class CoNeTTEModel:
         logits = self.engine.forcing(audio, lens, caps_in)  # (B, cap_len, V)
         return logits.permute(0, 2, 1)
 
+    def greedy_search(self, x, sr=None, x_shapes=None, preprocess: bool = True, bos_id: Optional[int] = None,
+                      min_pred_size: Optional[int] = None, max_pred_size: Optional[int] = None,
+                      forbid_rep_mode: Optional[str] = None) -> Tensor:
+        """nn/decoding/greedy.py:17-131 (the decoder of BaselinePLM, baseline.py:339-401): the arg-max chain, returned
+        as the masked logits of every step, (B, vocab, pred_size).  ``bos_id`` defaults to the plain <bos> token
+        (BaselinePLM has no task token); pass a task token id for CoNeTTE-style prompting."""
+        if preprocess:
+            batch = self.preprocessor(x, sr, x_shapes)
+            audio, audio_shape = batch["audio"], batch["audio_shape"]
+        elif isinstance(x, dict):
+            audio, audio_shape = x["audio"], x["audio_shape"]
+        else:
+            audio = x
+            audio_shape = x_shapes if x_shapes is not None else torch.as_tensor([list(a.shape) for a in x])
+        if audio.ndim == 4:
+            audio = audio.squeeze(dim=1)
+        cfg = self.config
+        min_pred = cfg.min_pred_size if min_pred_size is None else int(min_pred_size)
+        max_pred = cfg.max_pred_size if max_pred_size is None else int(max_pred_size)
+        bos = torch.full((audio.shape[0],), self.tokenizer.bos_token_id if bos_id is None else int(bos_id), dtype=torch.int32)
+        lens = torch.as_tensor(audio_shape)[:, 1].to(torch.int32)
+        res = self.engine.greedy(audio, lens, bos, self.get_forbid_rep_mask(forbid_rep_mode), min_pred, max_pred)
+        return res["logits"].permute(0, 2, 1)
+
     def _generate(self, audio: Tensor, audio_shape: Tensor, datasets: List[str], sources: List[Optional[str]], *,
                   beam_size=None, min_pred_size=None, max_pred_size=None, forbid_rep_mode=None) -> Dict[str, Any]:
         """CoNeTTEPLM.forward("generate") = encode_audio + decode_audio + decode_text (conette.py:352-450)."""

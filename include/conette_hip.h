@@ -123,6 +123,19 @@ int conette_forcing(conette_ctx* ctx, const float* frame_embs, const int32_t* fr
                     int32_t batch, int32_t t_audio, int32_t cap_len, float* logits, void* workspace,
                     size_t workspace_bytes, void* stream);
 
+/* greedy_search (nn/decoding/greedy.py:17-131; BaselinePLM's decoder, not reachable from
+ * CoNeTTEPLM): the arg-max chain with the full masked logits of every step as output.
+ *   logits : dev (B, max_pred, vocab) fp32 -- per step the logits of every unfinished clip with the EOS floor
+ *            (greedy.py:96-97) and the forbid-repeat mask (:99-105) applied; finished clips hold (-inf, pad_id -> 0)
+ *            (:64-69).  The reference returns the same values permuted to (B, vocab, pred_size).
+ *   preds  : dev (B, max_pred) int32 arg-max tokens, pad_id after <eos>
+ *   out_sizes[0] = pred_size (steps until every clip had finished), out_sizes[1] = longest caption incl. <eos> */
+size_t conette_greedy_workspace_bytes(const conette_ctx* ctx, int32_t batch, int32_t t_audio, int32_t max_pred);
+int conette_greedy(conette_ctx* ctx, const float* frame_embs, const int32_t* frame_lens, const int32_t* bos_ids,
+                   const uint8_t* forbid_mask, int32_t batch, int32_t t_audio, int32_t min_pred, int32_t max_pred,
+                   float* logits, int32_t* preds, int32_t* out_sizes, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
 /* a1: torchaudio.functional.resample (preprocessor.py:134-141), sinc_interpolation width 6,
  * rolloff 0.99.  in: dev (rows, n_in) fp32; out: dev (rows, n_out), n_out = ceil(n_in*new/orig). */
 int conette_resample(const float* in, int32_t rows, int32_t n_in, int32_t orig_sr, int32_t new_sr, float* out,

@@ -292,6 +292,46 @@ def teacher_forcing(w: Weights, audio: Tensor, audio_shape: Tensor, caps_in: Ten
 
 
 # ----------------------------------------------------------------------------------------
+# a15 / 8(f)4  greedy search with full-logit output -- nn/decoding/greedy.py:17-131
+# ----------------------------------------------------------------------------------------
+@torch.no_grad()
+def greedy_search(w: Weights, memory_bdt: Tensor, mem_pad_mask: Tensor, bos_id: int, *, pad_id: int = 0, eos_id: int = 2,
+                  vocab_size: int, min_pred_size: int = 0, max_pred_size: int = 20,
+                  forbid_rep_mask: Optional[Tensor] = None, nhead: int = 8, n_layers: int = 6) -> Tensor:
+    """memory (B, d, T), pad mask (B, T) -> logits (B, V, pred_size): per step the last-position logits of every
+    unfinished clip (whole prefix re-decoded, :82-93) with the EOS floor (:96-97) and the forbid-repeat mask (:99-105)
+    applied in place; arg-max continues the prefix (:107-109); a clip leaves the batch after <eos> or at the last
+    step (:111-123); untouched entries keep the initial fill: -inf, row pad_id = 0 (:64-69)."""
+    bsize = memory_bdt.shape[0]
+    memory = memory_bdt.permute(2, 0, 1)
+    batch_idxs = torch.arange(bsize)
+    preds = torch.full((bsize, max_pred_size + 1), pad_id, dtype=torch.long)
+    preds[:, 0] = bos_id
+    out = torch.full((bsize, vocab_size, max_pred_size), -math.inf, dtype=memory_bdt.dtype)
+    out[:, pad_id, :] = 0
+    use_forbid = forbid_rep_mask is not None and bool(forbid_rep_mask.any())
+    pred_size = max_pred_size
+    mask = mem_pad_mask
+    for i in range(max_pred_size):
+        logits_i = decoder_forward(w, memory.contiguous(), mask, preds[:, : i + 1].transpose(0, 1), nhead, n_layers)[-1]
+        if i < min_pred_size:
+            logits_i[:, eos_id] = -math.inf
+        if use_forbid:
+            seen = torch.zeros((preds.shape[0], vocab_size), dtype=torch.bool)
+            seen.scatter_(1, preds[:, : i + 1], True)
+            logits_i[seen & forbid_rep_mask[None]] = -math.inf
+        nxt = logits_i.argmax(dim=-1)
+        preds[:, i + 1] = nxt
+        unfinished = (nxt != eos_id) if i < max_pred_size - 1 else torch.zeros_like(nxt, dtype=torch.bool)
+        out[batch_idxs, :, i] = logits_i
+        preds, batch_idxs, memory, mask = preds[unfinished], batch_idxs[unfinished], memory[:, unfinished], mask[unfinished]
+        if preds.nelement() <= 0:
+            pred_size = i + 1
+            break
+    return out[:, :, :pred_size].contiguous() if pred_size < max_pred_size else out
+
+
+# ----------------------------------------------------------------------------------------
 # a12/a13  beam search -- nn/decoding/beam.py:22-269 (SURVEY.md A.4)
 # ----------------------------------------------------------------------------------------
 @torch.no_grad()

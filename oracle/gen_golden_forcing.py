@@ -65,6 +65,23 @@ def main() -> None:
     np.savez_compressed(os.path.join(GOLD, "forcing_ragged.npz"), **rec)
     print("caps_in", caps_in.tolist(), "logits", tuple(logits.shape), float(logits.abs().max()))
 
+    # ---- greedy_search (nn/decoding/greedy.py:17-131): full masked logits of the arg-max chain
+    from conette.nn.decoding.greedy import greedy_search
+    with torch.no_grad():
+        # plain <bos> (BaselinePLM has no task token; the synthetic decoder then never stops: all 12 steps), and the
+        # audiocaps task token as first token (one caption stops early: the finished-clip fill pattern)
+        for name, bos_tok, fmask, maxp in (("greedy_bos", plm.bos_id, plm.forbid_rep_mask, 12),
+                                           ("greedy_task", int(bos[1]), plm.forbid_rep_mask, 12)):
+            glog = greedy_search(plm.decoder, plm.pad_id, bos_tok, plm.eos_id, plm.tokenizer.get_vocab_size(),
+                                 enc["frame_embs"], enc["frame_embs_pad_mask"], min_pred_size=3, max_pred_size=maxp,
+                                 forbid_rep_mask=fmask)
+            grec = dict(lengths=np.asarray(lengths, dtype=np.int64), seed0=np.int64(seed0),
+                        frame_embs=pre["audio"].numpy(), audio_shape=pre["audio_shape"].numpy(),
+                        bos_id=np.int64(bos_tok), min_pred=np.int64(3), max_pred=np.int64(maxp),
+                        use_forbid=np.int64(fmask is not None), logits=glog.numpy().astype(np.float32))
+            np.savez_compressed(os.path.join(GOLD, name + ".npz"), **grec)
+            print(name, tuple(glog.shape), glog.argmax(dim=1).tolist())
+
 
 if __name__ == "__main__":
     main()

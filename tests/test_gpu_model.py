@@ -278,3 +278,16 @@ def test_model_teacher_forcing_api(model_fp32):
     bad[0, 0] = 1
     with pytest.raises(ValueError, match="BOS was not replaced"):
         model_fp32.teacher_forcing(pre, bad, preprocess=False)
+
+
+def test_model_greedy_search_api(model_fp32):
+    """CoNeTTEModel.greedy_search mirrors nn/decoding/greedy.py: (B, vocab, pred_size) masked logits."""
+    g = np.load(os.path.join(G.GOLDEN, "forcing", "greedy_task.npz"))
+    pre = {"audio": torch.from_numpy(g["frame_embs"]), "audio_shape": torch.from_numpy(g["audio_shape"])}
+    lg = model_fp32.greedy_search(pre, preprocess=False, bos_id=int(g["bos_id"]), min_pred_size=int(g["min_pred"]),
+                                  max_pred_size=int(g["max_pred"])).cpu()
+    ref = torch.from_numpy(g["logits"])
+    assert tuple(lg.shape) == tuple(ref.shape)
+    fin = torch.isfinite(ref)
+    assert torch.equal(torch.isfinite(lg), fin)
+    np.testing.assert_allclose(lg[fin].numpy(), ref[fin].numpy(), rtol=1e-3, atol=2e-3)

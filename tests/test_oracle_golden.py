@@ -83,3 +83,21 @@ def test_oracle_teacher_forcing_matches_reference_fixture(synth_weights):
     bad[0, 0] = 1  # <bos> left in place of the task token (conette.py:399-404)
     with pytest.raises(ValueError, match="BOS was not replaced"):
         O.teacher_forcing(synth_weights, torch.from_numpy(g["frame_embs"]), torch.from_numpy(g["audio_shape"]), bad)
+
+
+@pytest.mark.parametrize("name", ["greedy_bos", "greedy_task"])
+def test_oracle_greedy_search_matches_reference_fixture(name, synth_weights):
+    """the oracle's restatement of greedy.py against masked logits produced by the reference."""
+    import os
+    g = np.load(os.path.join(G.GOLDEN, "forcing", name + ".npz"))
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    mem, mask = O.encode_audio(synth_weights, torch.from_numpy(g["frame_embs"]), torch.from_numpy(g["audio_shape"]))
+    fm = synth_weights["model.forbid_rep_mask"] if int(g["use_forbid"]) else None
+    lg = O.greedy_search(synth_weights, mem, mask, int(g["bos_id"]), vocab_size=synth_weights["model.decoder.classifier.weight"].shape[0],
+                         min_pred_size=int(g["min_pred"]), max_pred_size=int(g["max_pred"]), forbid_rep_mask=fm)
+    ref = torch.from_numpy(g["logits"])
+    assert tuple(lg.shape) == tuple(ref.shape)
+    fin = torch.isfinite(ref)
+    assert torch.equal(torch.isfinite(lg), fin)                    # EOS floor, forbid-repeat, finished-clip fill
+    np.testing.assert_allclose(lg[fin].numpy(), ref[fin].numpy(), rtol=1e-4, atol=2e-4)
+    assert torch.equal(lg.argmax(dim=1), ref.argmax(dim=1))
