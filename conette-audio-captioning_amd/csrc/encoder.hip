@@ -701,7 +701,16 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
         if (bw.mlp_stream != nullptr && (C == 96 || C == 192 || (C == 384 && mlp384))) {
           CnProfScope ps(ctx, CONETTE_PROF_PW1_GEMM, s);
           const bf16_t* wsm = (const bf16_t*)bw.mlp_stream;
-          if (C == 96) CN_TRY((cn_launch_mlp_fused<96, 4, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
+          // Row tiles of 256 (C = 96) / 128 (C = 192) positions per block: the kernels are bound by the per-chunk latency
+          // chain, so fewer, fatter chunk iterations win; alone the kernels take the same time as with half the rows and
+          // twice the occupancy, but the pipelined step (decode of the previous batch running beside them) is 5 % shorter.
+          // At 256 clips the decode is a small share of the step and the smaller tiles' slightly faster encode wins
+          // (8.97 k vs 8.54 k clips/s), hence the switch on the batch.  CN_MLP_TILES=0 / 1 forces small / big (A/B).
+          static const int tiles_env = getenv("CN_MLP_TILES") ? atoi(getenv("CN_MLP_TILES")) : -1;
+          const int big = tiles_env >= 0 ? tiles_env : (B <= 128);
+          if (C == 96 && big) CN_TRY((cn_launch_mlp_fused<96, 8, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
+          else if (C == 96) CN_TRY((cn_launch_mlp_fused<96, 4, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
+          else if (C == 192 && big) CN_TRY((cn_launch_mlp_fused<192, 4, 2, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
           else if (C == 192) CN_TRY((cn_launch_mlp_fused<192, 2, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
           else CN_TRY((cn_launch_mlp_fused<384, 2, 4>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
           fused = true;

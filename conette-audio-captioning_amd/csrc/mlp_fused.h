@@ -40,7 +40,7 @@ __device__ unsigned long long g_mlp_prof[8];
 // of the channels.  C = 384 runs 8 waves (2 per SIMD, 250 registers each): with 4 waves of TM = 4 every LDS
 // fragment read in front of its MFMAs was exposed (one wave per SIMD, no registers left to prefetch into) and the
 // kernel was no faster than the two GEMMs it replaces.
-template <int C, int TM, int NWM>
+template <int C, int TM, int NWM, int NST = 3>
 __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* __restrict__ Y,
                                                            const bf16_t* __restrict__ WS /* packed ring image */,
                                                            const float* __restrict__ b1,
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* _
   constexpr int DPW = N_DMA / NW;
   static_assert(N_DMA % NW == 0, "DMA pieces must split evenly over the waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NST = 3;                // weight-chunk ring: chunks j+1, j+2 in flight during chunk j
+  // NST = weight-chunk ring depth: chunks j+1 .. j+NST-1 in flight during chunk j
   char* sH = smem + NST * BUF;          // [BM][64 B]
   float* sB1 = (float*)(sH + BM * 64);  // [4C] pwconv1 bias (no ordinary global load may sit inside the loop:
                                         // with LDS-DMA in flight hipcc would wait vmcnt(0) for it every chunk)
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* _
 
   for (int i = tid; i < 4 * C; i += NT) sB1[i] = b1[i];
   stage(0, 0);
-  stage(1, 1);
+  if (NST >= 3) stage(1, 1);
   // retire the ordinary loads (y fragments, bias) HERE, once: touching the registers makes the compiler
   // place its vmcnt wait before the loop instead of a vmcnt(0) in front of the first MFMA of every chunk
 #pragma unroll
@@ -133,11 +133,11 @@ __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* _
     // chunk j landed for this wave when at most the newer chunk's DPW pieces are outstanding; the raw
     // barrier (no vmcnt drain) then publishes every wave's pieces and proves chunk j-1 (buffers + H) is
     // no longer read, so its ring slot is refilled with chunk j+2
-    if (j + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+    if (NST >= 3 && j + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     MLP_STAMP(1)
-    if (j + 2 < NCH) stage((j + 2) % NST, j + 2);
+    if (j + NST - 1 < NCH) stage((j + NST - 1) % NST, j + NST - 1);
     const char* sW1 = smem + buf * BUF;
     const char* sW2 = sW1 + W1C_BYTES;
 
@@ -237,17 +237,17 @@ __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* _
 #endif
 }
 
-template <int C, int TM, int NWM>
+template <int C, int TM, int NWM, int NST = 3>
 static int cn_launch_mlp_fused(const bf16_t* Y, const bf16_t* WS, const float* b1, const float* b2,
                                const float* scale, float* X, int M, hipStream_t s) {
-  constexpr int SMEM = 3 * (32 * C * 2 + C * 64) + NWM * 16 * TM * 64 + 4 * C * 4;
+  constexpr int SMEM = NST * (32 * C * 2 + C * 64) + NWM * 16 * TM * 64 + 4 * C * 4;
   static bool configured = false;
   if (!configured) {
-    CN_HIP(hipFuncSetAttribute((const void*)cn_mlp_fused_kernel<C, TM, NWM>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    CN_HIP(hipFuncSetAttribute((const void*)cn_mlp_fused_kernel<C, TM, NWM, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                SMEM));
     configured = true;
   }
-  hipLaunchKernelGGL((cn_mlp_fused_kernel<C, TM, NWM>), dim3((unsigned)cn_cdiv(M, NWM * 16 * TM)), dim3(NWM * 128), SMEM, s, Y, WS, b1,
+  hipLaunchKernelGGL((cn_mlp_fused_kernel<C, TM, NWM, NST>), dim3((unsigned)cn_cdiv(M, NWM * 16 * TM)), dim3(NWM * 128), SMEM, s, Y, WS, b1,
                      b2, scale, X, M, getenv("CN_MLP_DEBUG") && atoi(getenv("CN_MLP_DEBUG")) == C ? 1 : 0);
   CN_LAUNCH_CHECK();
   return CN_OK;
