@@ -227,3 +227,30 @@ def test_greedy_search_matches_reference_fixture(name, prec, engines, synth_weig
                 if ga[b, i] != ra[b, i]:
                     break
         assert n_cmp >= ga.shape[0]  # at least the first step of every clip
+
+
+def test_fused_decoder_kernels_repeatable_under_load(engines, synth_weights):
+    """The fused decoder kernels count their outstanding loads by hand (dec_block.h, dec_ffn.h): a wrong count would
+    show up as run-to-run differences once timing changes.  Eager (non-graph) decodes while another stream runs encoder
+    work of varying shape must reproduce the first result bit for bit."""
+    from conette_amd import synth
+    eng = engines["bf16"]
+    B = 48
+    wave = torch.from_numpy(synth.synth_waveforms(B, 160000, 77)).cuda()
+    fe, _ = eng.encode(wave)
+    lens = torch.full((B,), fe.shape[1], dtype=torch.int32)
+    bos = synth_weights["model.task_id_to_token_id"][torch.zeros(B, dtype=torch.long)]
+    forbid = synth_weights["model.forbid_rep_mask"]
+    eng.set_decode_graph(False)
+    try:
+        ref = eng.decode(fe, lens, bos, forbid, 3, 3, 20, want_trace=True)
+        s2 = torch.cuda.Stream()
+        for it in range(40):
+            with torch.cuda.stream(s2):
+                eng.encode(wave[: 8 + (it % 5) * 8].contiguous())
+            out = eng.decode(fe, lens, bos, forbid, 3, 3, 20, want_trace=True)
+            for k in ("best_preds", "best_lprobs", "mult_preds", "mult_lprobs", "trace_val"):
+                assert torch.equal(out[k], ref[k]), (it, k)
+        torch.cuda.synchronize()
+    finally:
+        eng.set_decode_graph(True)
