@@ -708,7 +708,10 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
           // (8.97 k vs 8.54 k clips/s), hence the switch on the batch.  CN_MLP_TILES=0 / 1 forces small / big (A/B).
           static const int tiles_env = getenv("CN_MLP_TILES") ? atoi(getenv("CN_MLP_TILES")) : -1;
           const int big = tiles_env >= 0 ? tiles_env : (B <= 128);
-          if (C == 96 && big) CN_TRY((cn_launch_mlp_fused<96, 8, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
+          static const int pipe = getenv("CN_MLP_PIPE") ? atoi(getenv("CN_MLP_PIPE")) : 1;
+          if (C == 96 && big && pipe) CN_TRY((cn_launch_mlp_fused<96, 8, 2, 4, true>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
+          else if (C == 192 && big && pipe) CN_TRY((cn_launch_mlp_fused<192, 4, 2, 4, true>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
+          else if (C == 96 && big) CN_TRY((cn_launch_mlp_fused<96, 8, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
           else if (C == 96) CN_TRY((cn_launch_mlp_fused<96, 4, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
           else if (C == 192 && big) CN_TRY((cn_launch_mlp_fused<192, 4, 2, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
           else if (C == 192) CN_TRY((cn_launch_mlp_fused<192, 2, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));

@@ -40,7 +40,7 @@ __device__ unsigned long long g_mlp_prof[8];
 // of the channels.  C = 384 runs 8 waves (2 per SIMD, 250 registers each): with 4 waves of TM = 4 every LDS
 // fragment read in front of its MFMAs was exposed (one wave per SIMD, no registers left to prefetch into) and the
 // kernel was no faster than the two GEMMs it replaces.
-template <int C, int TM, int NWM, int NST = 3>
+template <int C, int TM, int NWM, int NST = 3, bool PIPE = false>
 __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* __restrict__ Y,
                                                            const bf16_t* __restrict__ WS /* packed ring image */,
                                                            const float* __restrict__ b1,
@@ -65,8 +65,9 @@ __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* _
   static_assert(N_DMA % NW == 0, "DMA pieces must split evenly over the waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // NST = weight-chunk ring depth: chunks j+1 .. j+NST-1 in flight during chunk j
-  char* sH = smem + NST * BUF;          // [BM][64 B]
-  float* sB1 = (float*)(sH + BM * 64);  // [4C] pwconv1 bias (no ordinary global load may sit inside the loop:
+  static_assert(!PIPE || NST >= 4, "the pipelined schedule reads two ring slots per iteration");
+  char* sH = smem + NST * BUF;          // [BM][64 B] (x 2 when PIPE)
+  float* sB1 = (float*)(sH + (PIPE ? 2 : 1) * BM * 64);  // [4C] pwconv1 bias (no ordinary global load may sit inside the loop:
                                         // with LDS-DMA in flight hipcc would wait vmcnt(0) for it every chunk)
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -115,6 +116,10 @@ __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* _
   for (int i = tid; i < 4 * C; i += NT) sB1[i] = b1[i];
   stage(0, 0);
   if (NST >= 3) stage(1, 1);
+  if (PIPE) {
+    stage(2, 2);
+    stage(3, 3);
+  }
   // retire the ordinary loads (y fragments, bias) HERE, once: touching the registers makes the compiler
   // place its vmcnt wait before the loop instead of a vmcnt(0) in front of the first MFMA of every chunk
 #pragma unroll
@@ -128,6 +133,66 @@ __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* _
       for (int b = 0; b < TM; ++b) asm volatile("" : "+v"(res[a][b]));
   }
   MLP_STAMP(0)
+  if constexpr (PIPE) {
+    // Software-pipelined schedule: iteration j runs GEMM 1 of chunk j+1, GEMM 2 of chunk j and the GELU epilogue of
+    // chunk j+1 between ONE pair of barriers (double-buffered hidden tile).  The epilogue's VALU work is independent
+    // of GEMM 2's MFMAs, so hipcc interleaves them: at one wave per SIMD (256-row tiles, chosen so that decode kernels
+    // fit beside this one) nothing else would hide the 32 GELUs per lane and chunk.
+    auto gemm1 = [&](int slot, f32x4 (&acc1)[TM]) {
+      const char* sW1 = smem + slot * BUF;
+#pragma unroll
+      for (int b = 0; b < TM; ++b) acc1[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks) {
+        const bf16x8 fw = *(const bf16x8*)(sW1 + ks * 2048 + (wn * 16 + lr) * 64 + ((lq ^ sw) * 16));
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc1[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, fa[b][ks], acc1[b], 0, 0, 0);
+      }
+    };
+    auto epi1 = [&](int jj, const f32x4 (&acc1)[TM], char* sHb) {
+      const f32x4 bb = *(const f32x4*)(sB1 + jj * 32 + wn * 16 + 4 * lq);
+      const int chunk = wn * 2 + (lq >> 1);
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const int ml = wm * (16 * TM) + b * 16 + lr;
+        bf16_t* dst = (bf16_t*)(sHb + ml * 64 + ((chunk ^ sw) * 16) + (lq & 1) * 8);
+        const f32x4 g = cn_gelu_fast4(f32x4{acc1[b][0] + bb[0], acc1[b][1] + bb[1], acc1[b][2] + bb[2], acc1[b][3] + bb[3]});
+        cn_store4(dst, g[0], g[1], g[2], g[3]);
+      }
+    };
+    auto gemm2 = [&](int slot, const char* sHb) {
+      const char* sW2 = smem + slot * BUF + W1C_BYTES;
+      bf16x8 fh[TM];
+#pragma unroll
+      for (int b = 0; b < TM; ++b) fh[b] = *(const bf16x8*)(sHb + (wm * (16 * TM) + b * 16 + lr) * 64 + ((lq ^ sw) * 16));
+#pragma unroll
+      for (int a = 0; a < TN2; ++a) {
+        const bf16x8 fw2 = *(const bf16x8*)(sW2 + (wn * (C / 2) + a * 16 + lr) * 64 + ((lq ^ sw) * 16));
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc2[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2, fh[b], acc2[a][b], 0, 0, 0);
+      }
+    };
+    f32x4 acc1[TM];
+    // chunk 0: GEMM 1 + epilogue (chunks 1..3 stay in flight)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * DPW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    gemm1(0, acc1);
+    epi1(0, acc1, sH);
+    for (int j = 0; j < NCH; ++j) {
+      // chunk j+1 landed (chunks j+2 [, j+3 at j = 0] may stay in flight); the barrier publishes H(j) and every wave's
+      // DMA pieces, and proves chunk j-1's slot and H(j-1)'s buffer are no longer read
+      if (j == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * DPW) : "memory");
+      else if (j + 2 < NCH) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (j >= 1 && j + 3 < NCH) stage((j + 3) % NST, j + 3);
+      char* sHj = sH + (j & 1) * (BM * 64);
+      char* sHn = sH + ((j + 1) & 1) * (BM * 64);
+      if (j + 1 < NCH) gemm1((j + 1) % NST, acc1);
+      gemm2(j % NST, sHj);
+      if (j + 1 < NCH) epi1(j + 1, acc1, sHn);
+    }
+  } else
   for (int j = 0; j < NCH; ++j) {
     const int buf = j % NST;
     // chunk j landed for this wave when at most the newer chunk's DPW pieces are outstanding; the raw
@@ -237,17 +302,17 @@ __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* _
 #endif
 }
 
-template <int C, int TM, int NWM, int NST = 3>
+template <int C, int TM, int NWM, int NST = 3, bool PIPE = false>
 static int cn_launch_mlp_fused(const bf16_t* Y, const bf16_t* WS, const float* b1, const float* b2,
                                const float* scale, float* X, int M, hipStream_t s) {
-  constexpr int SMEM = NST * (32 * C * 2 + C * 64) + NWM * 16 * TM * 64 + 4 * C * 4;
+  constexpr int SMEM = NST * (32 * C * 2 + C * 64) + (PIPE ? 2 : 1) * NWM * 16 * TM * 64 + 4 * C * 4;
   static bool configured = false;
   if (!configured) {
-    CN_HIP(hipFuncSetAttribute((const void*)cn_mlp_fused_kernel<C, TM, NWM, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    CN_HIP(hipFuncSetAttribute((const void*)cn_mlp_fused_kernel<C, TM, NWM, NST, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                SMEM));
     configured = true;
   }
-  hipLaunchKernelGGL((cn_mlp_fused_kernel<C, TM, NWM, NST>), dim3((unsigned)cn_cdiv(M, NWM * 16 * TM)), dim3(NWM * 128), SMEM, s, Y, WS, b1,
+  hipLaunchKernelGGL((cn_mlp_fused_kernel<C, TM, NWM, NST, PIPE>), dim3((unsigned)cn_cdiv(M, NWM * 16 * TM)), dim3(NWM * 128), SMEM, s, Y, WS, b1,
                      b2, scale, X, M, getenv("CN_MLP_DEBUG") && atoi(getenv("CN_MLP_DEBUG")) == C ? 1 : 0);
   CN_LAUNCH_CHECK();
   return CN_OK;
