@@ -254,3 +254,33 @@ def test_fused_decoder_kernels_repeatable_under_load(engines, synth_weights):
         torch.cuda.synchronize()
     finally:
         eng.set_decode_graph(True)
+
+
+def test_c_abi_error_behaviour(engines):
+    """Status codes + conette_last_error instead of exceptions / aborts: bad arguments, unsupported sizes and short
+    workspaces are refused before anything is launched (header: 0 ok, 1 argument, 4 workspace)."""
+    import ctypes as C
+    eng = engines["fp32"]
+    lib, ctx = eng.lib, eng._ctx
+    b, t = 2, 7
+    fe = torch.zeros((b, t, 768), device="cuda")
+    lens = torch.full((b,), t, dtype=torch.int32, device="cuda")
+    bos = torch.full((b,), 5624, dtype=torch.int32, device="cuda")
+    out_i = torch.zeros((b * 3 * 64,), dtype=torch.int32, device="cuda")
+    out_f = torch.zeros((b * 3 * 64,), dtype=torch.float32, device="cuda")
+    sizes = torch.zeros((2,), dtype=torch.int32, device="cuda")
+    need = lib.conette_decode_workspace_bytes(ctx, b, t, 3, 20)
+    ws = torch.empty((need,), dtype=torch.uint8, device="cuda")
+    p = lambda x: C.c_void_p(x.data_ptr())
+
+    def dec(beam, max_pred, ws_bytes, fe_ptr=p(fe)):
+        return lib.conette_decode(ctx, fe_ptr, p(lens), p(bos), None, b, t, beam, 3, max_pred, p(out_i), p(out_f), p(out_i),
+                                  p(out_f), p(sizes), None, None, None, p(ws), ws_bytes, None)
+
+    assert dec(3, 20, need) == 0
+    assert dec(9, 20, need) == 1 and b"beam" in lib.conette_last_error()          # CN_MAX_BEAM = 8
+    assert dec(3, 65, need) == 1                                                     # CN_MAX_PRED = 64
+    assert dec(3, 20, need - 1) == 4 and b"workspace" in lib.conette_last_error()
+    assert dec(3, 20, need, fe_ptr=None) == 1
+    assert lib.conette_forcing(ctx, p(fe), p(lens), p(bos), b, t, 0, p(out_f), p(ws), need, None) == 1
+    torch.cuda.synchronize()
