@@ -302,6 +302,47 @@ class CoNeTTEModel:
         res = self.engine.greedy(audio, lens, bos, self.get_forbid_rep_mask(forbid_rep_mode), min_pred, max_pred)
         return res["logits"].permute(0, 2, 1)
 
+    def decode_audio(self, encoder_outs: Dict[str, Tensor], decode_method: str, **kwargs) -> Any:
+        """The decode_audio surface shared by CoNeTTEPLM (pl_modules/conette.py:386-450) and BaselinePLM
+        (pl_modules/baseline.py:339-401): ``encoder_outs`` = the preprocessor's output ({"audio": (B, T, 768),
+        "audio_shape": (B, 2)}; the projection of conette.py:457 / baseline.py:409 runs inside the engine),
+        ``decode_method`` in ("forcing", "greedy", "generate").
+
+        * "forcing": ``caps_in`` required -> logits (B, vocab, cap_len)
+        * "greedy": kwargs bos_id (default <bos>: BaselinePLM has no task token), min_pred_size, max_pred_size,
+          forbid_rep_mode -> logits (B, vocab, pred_size)
+        * "generate": kwargs bos_id (int or (B,) tensor; REQUIRED for CoNeTTE-style task prompting, default <bos>),
+          beam_size, min_pred_size, max_pred_size, forbid_rep_mode -> (preds, lprobs, mult_preds, mult_lprobs)"""
+        if decode_method == "forcing":
+            if "caps_in" not in kwargs:
+                raise ValueError(f"Please provide a 'caps_in' keyword argument with {decode_method=}. "
+                                 f"(found {tuple(kwargs.keys())})")
+            return self.teacher_forcing(encoder_outs, kwargs["caps_in"], preprocess=False)
+        if decode_method == "greedy":
+            return self.greedy_search(encoder_outs, preprocess=False, bos_id=kwargs.get("bos_id"),
+                                      min_pred_size=kwargs.get("min_pred_size"), max_pred_size=kwargs.get("max_pred_size"),
+                                      forbid_rep_mode=kwargs.get("forbid_rep_mode"))
+        if decode_method == "generate":
+            audio, audio_shape = encoder_outs["audio"], torch.as_tensor(encoder_outs["audio_shape"])
+            if audio.ndim == 4:
+                audio = audio.squeeze(dim=1)
+            cfg = self.config
+            bos = kwargs.get("bos_id")
+            if bos is None:
+                bos = self.tokenizer.bos_token_id
+            bos = torch.as_tensor(bos, dtype=torch.int32).reshape(-1)
+            if bos.numel() == 1:
+                bos = bos.expand(audio.shape[0])
+            beam = cfg.beam_size if kwargs.get("beam_size") is None else int(kwargs["beam_size"])
+            min_pred = cfg.min_pred_size if kwargs.get("min_pred_size") is None else int(kwargs["min_pred_size"])
+            max_pred = cfg.max_pred_size if kwargs.get("max_pred_size") is None else int(kwargs["max_pred_size"])
+            res = self.engine.decode(audio, audio_shape[:, 1].to(torch.int32), bos.contiguous(),
+                                     self.get_forbid_rep_mask(kwargs.get("forbid_rep_mode")), beam, min_pred, max_pred)
+            pred_size, best_maxlen = (int(v) for v in res["sizes"].tolist())
+            return (res["best_preds"][:, :best_maxlen].to(torch.long).contiguous(), res["best_lprobs"],
+                    res["mult_preds"][:, :, :pred_size].to(torch.long).contiguous(), res["mult_lprobs"])
+        raise ValueError(f"Unknown argument {decode_method=}. (expected one of ('forcing', 'greedy', 'generate'))")
+
     def _generate(self, audio: Tensor, audio_shape: Tensor, datasets: List[str], sources: List[Optional[str]], *,
                   beam_size=None, min_pred_size=None, max_pred_size=None, forbid_rep_mode=None) -> Dict[str, Any]:
         """CoNeTTEPLM.forward("generate") = encode_audio + decode_audio + decode_text (conette.py:352-450)."""

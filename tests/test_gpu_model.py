@@ -321,3 +321,32 @@ def test_mixed_length_1s_to_30s_against_oracle(model_fp32, model_bf16):
     same = [b for b in range(len(lengths)) if torch.equal(p16[b, :w_], p32[b, :w_])]
     np.testing.assert_allclose(out16["lprobs"].cpu().numpy()[same], out["lprobs"].cpu().numpy()[same], atol=0.05)
     assert all(len(c) > 0 for c in out16["cands"])
+
+
+def test_decode_audio_surface_baseline_style(model_fp32):
+    """decode_audio(encoder_outs, method): the surface shared by CoNeTTEPLM and BaselinePLM.  "generate" with the plain
+    <bos> first token (BaselinePLM: no task token) against the CPU oracle's beam search; "forcing" / "greedy" route
+    to the paths pinned by the reference fixtures; unknown methods raise like the reference."""
+    from conette_amd import synth
+    from oracle import cpu_ref as O
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    g = np.load(os.path.join(G.GOLDEN, "forcing", "greedy_bos.npz"))
+    pre = {"audio": torch.from_numpy(g["frame_embs"]), "audio_shape": torch.from_numpy(g["audio_shape"])}
+    w = O.to_torch(synth.synth_state_dict())
+    mem, mask = O.encode_audio(w, pre["audio"], pre["audio_shape"])
+    bos = torch.full((mem.shape[0],), int(g["bos_id"]), dtype=torch.long)
+    trace = []
+    ref = O.generate(w, mem, mask, bos, vocab_size=w["model.decoder.classifier.weight"].shape[0], beam_size=2,
+                     min_pred_size=3, max_pred_size=10, forbid_rep_mask=w["model.forbid_rep_mask"], trace=trace)
+    preds, lprobs, mult_preds, mult_lprobs = model_fp32.decode_audio(pre, "generate", beam_size=2, min_pred_size=3,
+                                                                    max_pred_size=10)
+    if min(d["margin"] for step in trace for d in step) > 1e-3:
+        assert preds.cpu().tolist() == ref[0].tolist() and mult_preds.cpu().tolist() == ref[2].tolist()
+    np.testing.assert_allclose(lprobs.cpu().numpy(), ref[1].numpy(), atol=1e-3)
+    lg = model_fp32.decode_audio(pre, "greedy", min_pred_size=int(g["min_pred"]), max_pred_size=int(g["max_pred"])).cpu()
+    fin = torch.isfinite(torch.from_numpy(g["logits"]))
+    np.testing.assert_allclose(lg[fin].numpy(), g["logits"][fin.numpy()], rtol=1e-3, atol=2e-3)
+    with pytest.raises(ValueError, match="caps_in"):
+        model_fp32.decode_audio(pre, "forcing")
+    with pytest.raises(ValueError, match="Unknown argument"):
+        model_fp32.decode_audio(pre, "sampling")
