@@ -709,12 +709,14 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
           static const int tiles_env = getenv("CN_MLP_TILES") ? atoi(getenv("CN_MLP_TILES")) : -1;
           const int big = tiles_env >= 0 ? tiles_env : (B <= 128);
           static const int pipe = getenv("CN_MLP_PIPE") ? atoi(getenv("CN_MLP_PIPE")) : 1;
-          if (C == 96 && big && pipe) CN_TRY((cn_launch_mlp_fused<96, 8, 2, 4, true>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
-          else if (C == 192 && big && pipe) CN_TRY((cn_launch_mlp_fused<192, 4, 2, 4, true>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
+          if (C == 96 && big && pipe) CN_TRY((cn_launch_mlp_fused<96, 8, 2, 4, 1>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
+          else if (C == 192 && big && pipe) CN_TRY((cn_launch_mlp_fused<192, 4, 2, 4, 1>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
           else if (C == 96 && big) CN_TRY((cn_launch_mlp_fused<96, 8, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
           else if (C == 96) CN_TRY((cn_launch_mlp_fused<96, 4, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
           else if (C == 192 && big) CN_TRY((cn_launch_mlp_fused<192, 4, 2, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
           else if (C == 192) CN_TRY((cn_launch_mlp_fused<192, 2, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
+          // (C = 384: the split-ring pipelined loop, CN_MLP_PIPE=2, measured 229 us against 213-223 us: not the default)
+          else if (pipe == 2) CN_TRY((cn_launch_mlp_fused<384, 2, 4, 2, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
           else CN_TRY((cn_launch_mlp_fused<384, 2, 4>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
           fused = true;
         }

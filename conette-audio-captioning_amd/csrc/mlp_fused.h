@@ -40,7 +40,7 @@ __device__ unsigned long long g_mlp_prof[8];
 // of the channels.  C = 384 runs 8 waves (2 per SIMD, 250 registers each): with 4 waves of TM = 4 every LDS
 // fragment read in front of its MFMAs was exposed (one wave per SIMD, no registers left to prefetch into) and the
 // kernel was no faster than the two GEMMs it replaces.
-template <int C, int TM, int NWM, int NST = 3, bool PIPE = false>
+template <int C, int TM, int NWM, int NST = 3, int PIPE = 0>
 __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* __restrict__ Y,
                                                            const bf16_t* __restrict__ WS /* packed ring image */,
                                                            const float* __restrict__ b1,
@@ -65,8 +65,9 @@ __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* _
   static_assert(N_DMA % NW == 0, "DMA pieces must split evenly over the waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // NST = weight-chunk ring depth: chunks j+1 .. j+NST-1 in flight during chunk j
-  static_assert(!PIPE || NST >= 4, "the pipelined schedule reads two ring slots per iteration");
-  char* sH = smem + NST * BUF;          // [BM][64 B] (x 2 when PIPE)
+  static_assert(PIPE != 1 || NST >= 4, "the pipelined schedule reads two ring slots per iteration");
+  constexpr int RING_BYTES = PIPE == 2 ? 2 * BUF : NST * BUF;  // PIPE 2: separate two-slot rings for W1 and W2 chunks
+  char* sH = smem + RING_BYTES;         // [BM][64 B] (x 2 when PIPE)
   float* sB1 = (float*)(sH + (PIPE ? 2 : 1) * BM * 64);  // [4C] pwconv1 bias (no ordinary global load may sit inside the loop:
                                         // with LDS-DMA in flight hipcc would wait vmcnt(0) for it every chunk)
 
@@ -114,11 +115,39 @@ __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* _
     }
 
   for (int i = tid; i < 4 * C; i += NT) sB1[i] = b1[i];
-  stage(0, 0);
-  if (NST >= 3) stage(1, 1);
-  if (PIPE) {
-    stage(2, 2);
-    stage(3, 3);
+  // PIPE 2 (C = 384, where a four-slot ring of whole chunks does not fit): the W1 and W2 halves of a chunk live in
+  // separate two-slot rings, because the pipelined loop needs W1 of chunk j+1 together with W2 of chunk j
+  constexpr int W1P = W1C_BYTES / 1024, W2P = W2C_BYTES / 1024;
+  auto stage_w1 = [&](int slot, int j) {
+#pragma unroll
+    for (int i = 0; i < W1P / NW; ++i) {
+      const int inst = wave * (W1P / NW) + i;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)((const char*)WS + (size_t)j * BUF + inst * 1024 + lane * 16),
+          (__attribute__((address_space(3))) void*)(smem + slot * W1C_BYTES + inst * 1024), 16, 0, 0);
+    }
+  };
+  auto stage_w2 = [&](int slot, int j) {
+#pragma unroll
+    for (int i = 0; i < W2P / NW; ++i) {
+      const int inst = wave * (W2P / NW) + i;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)((const char*)WS + (size_t)j * BUF + W1C_BYTES + inst * 1024 + lane * 16),
+          (__attribute__((address_space(3))) void*)(smem + 2 * W1C_BYTES + slot * W2C_BYTES + inst * 1024), 16, 0, 0);
+    }
+  };
+  if constexpr (PIPE == 2) {
+    static_assert(W1P % NW == 0 && W2P % NW == 0, "split rings: pieces must divide over the waves");
+    stage_w1(0, 0);
+    stage_w2(0, 0);
+    stage_w1(1, 1);
+  } else {
+    stage(0, 0);
+    if (NST >= 3) stage(1, 1);
+    if (PIPE == 1) {
+      stage(2, 2);
+      stage(3, 3);
+    }
   }
   // retire the ordinary loads (y fragments, bias) HERE, once: touching the registers makes the compiler
   // place its vmcnt wait before the loop instead of a vmcnt(0) in front of the first MFMA of every chunk
@@ -133,13 +162,12 @@ __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* _
       for (int b = 0; b < TM; ++b) asm volatile("" : "+v"(res[a][b]));
   }
   MLP_STAMP(0)
-  if constexpr (PIPE) {
+  if constexpr (PIPE != 0) {
     // Software-pipelined schedule: iteration j runs GEMM 1 of chunk j+1, GEMM 2 of chunk j and the GELU epilogue of
     // chunk j+1 between ONE pair of barriers (double-buffered hidden tile).  The epilogue's VALU work is independent
     // of GEMM 2's MFMAs, so hipcc interleaves them: at one wave per SIMD (256-row tiles, chosen so that decode kernels
     // fit beside this one) nothing else would hide the 32 GELUs per lane and chunk.
-    auto gemm1 = [&](int slot, f32x4 (&acc1)[TM]) {
-      const char* sW1 = smem + slot * BUF;
+    auto gemm1 = [&](const char* sW1, f32x4 (&acc1)[TM]) {
 #pragma unroll
       for (int b = 0; b < TM; ++b) acc1[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -160,8 +188,7 @@ __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* _
         cn_store4(dst, g[0], g[1], g[2], g[3]);
       }
     };
-    auto gemm2 = [&](int slot, const char* sHb) {
-      const char* sW2 = smem + slot * BUF + W1C_BYTES;
+    auto gemm2 = [&](const char* sW2, const char* sHb) {
       bf16x8 fh[TM];
 #pragma unroll
       for (int b = 0; b < TM; ++b) fh[b] = *(const bf16x8*)(sHb + (wm * (16 * TM) + b * 16 + lr) * 64 + ((lq ^ sw) * 16));
@@ -173,24 +200,44 @@ __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* _
       }
     };
     f32x4 acc1[TM];
-    // chunk 0: GEMM 1 + epilogue (chunks 1..3 stay in flight)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * DPW) : "memory");
-    __builtin_amdgcn_s_barrier();
-    gemm1(0, acc1);
-    epi1(0, acc1, sH);
-    for (int j = 0; j < NCH; ++j) {
-      // chunk j+1 landed (chunks j+2 [, j+3 at j = 0] may stay in flight); the barrier publishes H(j) and every wave's
-      // DMA pieces, and proves chunk j-1's slot and H(j-1)'s buffer are no longer read
-      if (j == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * DPW) : "memory");
-      else if (j + 2 < NCH) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DPW) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if constexpr (PIPE == 1) {
+      // chunk 0: GEMM 1 + epilogue (chunks 1..3 stay in flight)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * DPW) : "memory");
       __builtin_amdgcn_s_barrier();
-      if (j >= 1 && j + 3 < NCH) stage((j + 3) % NST, j + 3);
-      char* sHj = sH + (j & 1) * (BM * 64);
-      char* sHn = sH + ((j + 1) & 1) * (BM * 64);
-      if (j + 1 < NCH) gemm1((j + 1) % NST, acc1);
-      gemm2(j % NST, sHj);
-      if (j + 1 < NCH) epi1(j + 1, acc1, sHn);
+      gemm1(smem, acc1);
+      epi1(0, acc1, sH);
+      for (int j = 0; j < NCH; ++j) {
+        // chunk j+1 landed (chunks j+2 [, j+3 at j = 0] may stay in flight); the barrier publishes H(j) and every wave's
+        // DMA pieces, and proves chunk j-1's slot and H(j-1)'s buffer are no longer read
+        if (j == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * DPW) : "memory");
+        else if (j + 2 < NCH) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(DPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (j >= 1 && j + 3 < NCH) stage((j + 3) % NST, j + 3);
+        char* sHj = sH + (j & 1) * (BM * 64);
+        char* sHn = sH + ((j + 1) & 1) * (BM * 64);
+        if (j + 1 < NCH) gemm1(smem + ((j + 1) % NST) * BUF, acc1);
+        gemm2(smem + (j % NST) * BUF + W1C_BYTES, sHj);
+        if (j + 1 < NCH) epi1(j + 1, acc1, sHn);
+      }
+    } else {
+      // split rings: W1 of chunk j+1 and W2 of chunk j are resident in iteration j; the loads issued in iteration j
+      // (W1 of chunk j+2, W2 of chunk j+1) have one whole iteration to land
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      gemm1(smem, acc1);
+      epi1(0, acc1, sH);
+      for (int j = 0; j < NCH; ++j) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (j + 2 < NCH) stage_w1(j & 1, j + 2);         // slot of W1(j): consumed in iteration j-1
+        if (j + 1 < NCH) stage_w2((j + 1) & 1, j + 1);   // slot of W2(j-1): consumed in iteration j-1
+        char* sHj = sH + (j & 1) * (BM * 64);
+        char* sHn = sH + ((j + 1) & 1) * (BM * 64);
+        if (j + 1 < NCH) gemm1(smem + ((j + 1) & 1) * W1C_BYTES, acc1);
+        gemm2(smem + 2 * W1C_BYTES + (j & 1) * W2C_BYTES, sHj);
+        if (j + 1 < NCH) epi1(j + 1, acc1, sHn);
+      }
     }
   } else
   for (int j = 0; j < NCH; ++j) {
@@ -302,10 +349,10 @@ __global__ __launch_bounds__(NWM * 128) void cn_mlp_fused_kernel(const bf16_t* _
 #endif
 }
 
-template <int C, int TM, int NWM, int NST = 3, bool PIPE = false>
+template <int C, int TM, int NWM, int NST = 3, int PIPE = 0>
 static int cn_launch_mlp_fused(const bf16_t* Y, const bf16_t* WS, const float* b1, const float* b2,
                                const float* scale, float* X, int M, hipStream_t s) {
-  constexpr int SMEM = NST * (32 * C * 2 + C * 64) + (PIPE ? 2 : 1) * NWM * 16 * TM * 64 + 4 * C * 4;
+  constexpr int SMEM = (PIPE == 2 ? 2 : NST) * (32 * C * 2 + C * 64) + (PIPE ? 2 : 1) * NWM * 16 * TM * 64 + 4 * C * 4;
   static bool configured = false;
   if (!configured) {
     CN_HIP(hipFuncSetAttribute((const void*)cn_mlp_fused_kernel<C, TM, NWM, NST, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize,
