@@ -769,12 +769,13 @@ extern "C" int conette_frontend_logmel(conette_ctx* ctx, const float* wave, int3
 extern "C" int conette_encode(conette_ctx* ctx, const float* wave, int32_t batch, int32_t n_samples,
                               float* frame_embs, float* clip_probs, const conette_encode_taps* taps, void* workspace,
                               size_t workspace_bytes, void* stream) {
-  if (!ctx || !wave || !frame_embs || !workspace || batch <= 0) {
-    cn_set_error("encode: bad argument");
+  if (conette_num_audio_frames(n_samples) < 1) {  // (checked first: the caller's (B, 0, 768) output has no storage)
+    cn_set_error("encode: n_samples=%d is too short: the encoder's three 2x downsamplings need >= 7680 samples "
+                 "(0.24 s at 32 kHz) to leave one audio frame", n_samples);
     return CN_ERR_ARG;
   }
-  if (conette_num_audio_frames(n_samples) < 1) {
-    cn_set_error("encode: n_samples=%d too short", n_samples);
+  if (!ctx || !wave || !frame_embs || !workspace || batch <= 0) {
+    cn_set_error("encode: bad argument");
     return CN_ERR_ARG;
   }
   const size_t need = conette_encode_workspace_bytes(ctx, batch, n_samples);

@@ -284,3 +284,19 @@ def test_c_abi_error_behaviour(engines):
     assert dec(3, 20, need, fe_ptr=None) == 1
     assert lib.conette_forcing(ctx, p(fe), p(lens), p(bos), b, t, 0, p(out_f), p(ws), need, None) == 1
     torch.cuda.synchronize()
+
+
+def test_encode_short_and_odd_lengths(engines):
+    """Edge geometry: very short clips (a single frame row in the last stage) and lengths that leave partial tiles in
+    every stage; bf16 must track fp32 and everything stays finite."""
+    from conette_amd import synth
+    with pytest.raises(RuntimeError, match="too short"):          # 0.2 s: no audio frame survives the downsamplings
+        engines["fp32"].encode(torch.zeros((1, 6400)).cuda())
+    for L in (7680, 9600, 16000, 20481, 33333, 47999):
+        wave = torch.from_numpy(synth.synth_waveforms(3, L, 31 + L, lengths=[L, max(L // 2, 3200), max(L - 777, 3200)])).cuda()
+        f32, c32 = engines["fp32"].encode(wave)
+        f16, c16 = engines["bf16"].encode(wave)
+        assert f32.shape == f16.shape and f32.shape[1] == engines["fp32"].lib.conette_num_audio_frames(L)
+        assert torch.isfinite(f32).all() and torch.isfinite(f16).all()
+        np.testing.assert_allclose(f16.float().cpu().numpy(), f32.cpu().numpy(), atol=0.1, rtol=0.1)
+        np.testing.assert_allclose(c16.cpu().numpy(), c32.cpu().numpy(), atol=0.05)
