@@ -456,56 +456,68 @@ template <typename T, int C>
 __global__ __launch_bounds__(256) void cn_ln_patchify_kernel(const float* __restrict__ x, int H, int W, long n_pos,
                                                              const float* __restrict__ ln_w,
                                                              const float* __restrict__ ln_b, T* __restrict__ p) {
-  // one wave normalises PPW consecutive positions: all their loads are issued before any reduction
-  // (a wave per position was a pure latency chain: load -> 12 shuffles -> store, 1.3 TB/s)
-  constexpr int PER = (C + 63) / 64, PPW = 4;
+  // A lane owns 4 consecutive channels (16-byte loads, 8-byte bf16 stores: one 2-byte store per lane made the
+  // kernel store-issue bound, 2.4 TB/s); C = 96 packs two positions into a wave (one per 32-lane half).  All loads of
+  // the PPW position groups of a wave are issued before any reduction (a group at a time was a pure latency chain).
+  constexpr int PER = C > 192 ? 2 : 1;          // 4-channel chunks per lane
+  constexpr int LANES = C / 4 / PER;            // active lanes per position: 24 / 48 / 48
+  constexpr int SLOTS = LANES <= 32 ? 2 : 1;    // positions side by side in a wave
+  constexpr int PPW = 4;
   const int lane = threadIdx.x & 63;
-  const long pos0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW;
+  const int sl = SLOTS == 2 ? lane >> 5 : 0, ll = SLOTS == 2 ? lane & 31 : lane;
+  const bool act = ll < LANES;
+  const long pos0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (PPW * SLOTS);
   if (pos0 >= n_pos) return;
   const int H2 = H / 2, W2 = W / 2;
-  float v[PPW][PER];
+  f32x4 v[PPW][PER];
 #pragma unroll
   for (int u = 0; u < PPW; ++u) {
-    const long pos = min(pos0 + u, n_pos - 1);
+    const long pos = min(pos0 + u * SLOTS + sl, n_pos - 1);
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int cc = lane + 64 * i;
-      v[u][i] = (C % 64 == 0 || cc < C) ? x[(size_t)pos * C + cc] : 0.f;
-    }
+    for (int i = 0; i < PER; ++i)
+      v[u][i] = act ? *(const f32x4*)(x + (size_t)pos * C + 4 * (ll + LANES * i)) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  float gw[PER], gb[PER];
+  f32x4 gw[PER], gb[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    const int cc = lane + 64 * i;
-    gw[i] = (C % 64 == 0 || cc < C) ? ln_w[cc] : 0.f;
-    gb[i] = (C % 64 == 0 || cc < C) ? ln_b[cc] : 0.f;
+    gw[i] = act ? *(const f32x4*)(ln_w + 4 * (ll + LANES * i)) : f32x4{0.f, 0.f, 0.f, 0.f};
+    gb[i] = act ? *(const f32x4*)(ln_b + 4 * (ll + LANES * i)) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  auto group_sum = [&](float s) {  // over the position's lanes: a 32-lane half or the whole wave
+    s = cn_sum8_dpp(s);
+    s += cn_dpp<0x140>(s);
+    s += __shfl_xor(s, 16);
+    if (SLOTS == 1) s += __shfl_xor(s, 32);
+    return s;
+  };
 #pragma unroll
   for (int u = 0; u < PPW; ++u) {
-    const long pos = pos0 + u;
-    if (pos >= n_pos) break;
+    const long pos = pos0 + u * SLOTS + sl;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) s += (v[u][i][0] + v[u][i][1]) + (v[u][i][2] + v[u][i][3]);
+    const float mean = group_sum(s) * (1.0f / C);
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = act ? v[u][i][e] - mean : 0.f;
+        s2 = fmaf(d, d, s2);
+      }
+    const float rstd = 1.0f / sqrtf(group_sum(s2) * (1.0f / C) + 1e-6f);
+    if (pos >= n_pos || !act) continue;
     const int w = (int)(pos % W);
     const long t = pos / W;
     const int h = (int)(t % H);
     const int b = (int)(t / H);
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) s += v[u][i];
-    const float mean = cn_wave_sum(s) * (1.0f / C);
-    float s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int cc = lane + 64 * i;
-      const float d = (C % 64 == 0 || cc < C) ? v[u][i] - mean : 0.f;
-      s2 = fmaf(d, d, s2);
-    }
-    const float rstd = 1.0f / sqrtf(cn_wave_sum(s2) * (1.0f / C) + 1e-6f);
     if (h >= 2 * H2 || w >= 2 * W2) continue;  // odd trailing row / column is dropped by the stride-2 conv
     T* o = p + ((((size_t)b * H2 + (h >> 1)) * W2 + (w >> 1)) * 4 + ((h & 1) * 2 + (w & 1))) * C;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int cc = lane + 64 * i;
-      if (C % 64 == 0 || cc < C) o[cc] = cn_from_f32<T>((v[u][i] - mean) * rstd * gw[i] + gb[i]);
+      const int cc = 4 * (ll + LANES * i);
+      cn_store4(o + cc, (v[u][i][0] - mean) * rstd * gw[i][0] + gb[i][0], (v[u][i][1] - mean) * rstd * gw[i][1] + gb[i][1],
+                (v[u][i][2] - mean) * rstd * gw[i][2] + gb[i][2], (v[u][i][3] - mean) * rstd * gw[i][3] + gb[i][3]);
     }
   }
 }
@@ -676,7 +688,8 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
       const long n_in = (long)B * Hp * Wp;
       const CnDownW& dw = ctx->down[st - 1];
       CnProfScope ps(ctx, CONETTE_PROF_DOWNSAMPLE, s);
-      const dim3 pg((unsigned)((n_in + 15) / 16));  // 4 waves x 4 positions per block
+      const int ppb = Cp == 96 ? 32 : 16;           // positions per block: 4 waves x 4 groups x (2 | 1) positions
+      const dim3 pg((unsigned)((n_in + ppb - 1) / ppb));
       if (Cp == 96)
         hipLaunchKernelGGL((cn_ln_patchify_kernel<T, 96>), pg, dim3(256), 0, s, ws.x, Hp, Wp, n_in, dw.ln_w, dw.ln_b, y);
       else if (Cp == 192)

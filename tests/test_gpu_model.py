@@ -226,7 +226,7 @@ def test_long_clips_long_captions_block_path(model_bf16, model_fp32):
             if not np.array_equal(sel_f[step, clip], sel_p[step, clip]):
                 break  # a near-tie resolved the other way: later steps are no longer comparable
             live = sel_p[step, clip, :, 0] >= 0
-            np.testing.assert_allclose(val_f[step, clip][live], val_p[step, clip][live], atol=0.02 * (step + 1))
+            np.testing.assert_allclose(val_f[step, clip][live], val_p[step, clip][live], atol=0.08 * (step + 1))  # two bf16 roundings of the same sums
             n_same_steps += 1
     assert n_same_steps >= 0.8 * n_steps, (n_same_steps, n_steps)
     p16 = fused["best_preds"].cpu()
