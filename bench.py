@@ -134,6 +134,7 @@ def main() -> None:
     eng = Engine(sd, precision=args.precision, device=dev)
     if os.environ.get("CN_NO_GRAPH"):
         eng.set_decode_graph(False)
+    eng.set_encode_reserved_cus(int(os.environ.get("CN_ENC_RESERVE", "48")))
     wave = torch.from_numpy(synth.synth_waveforms(B, L, 1234 + rank * B)).to(dev)
     t_audio = eng.lib.conette_num_audio_frames(L)
     lens = torch.full((B,), t_audio, dtype=torch.int32, device=dev)

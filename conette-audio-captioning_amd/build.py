@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libconette_hip.so")
 SOURCES = ["api.hip", "frontend.hip", "encoder.hip", "decoder.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-DCN_RC2_GELU_PK"]
 if os.environ.get("CN_G2_PROF"):  # profiling build: phase stamps inside the encoder GEMM (tools/g2prof.py)
     FLAGS.append("-DCN_G2_PROF")
 if os.environ.get("CN_G2_NOACT"):

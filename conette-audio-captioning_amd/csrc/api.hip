@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "ctx.h"
+#include "mlp_rc2.h"
 
 static thread_local char g_err[512] = "";
 
@@ -133,26 +134,6 @@ __global__ void pk_ffn_stream(const float* __restrict__ W1, const float* __restr
 #pragma unroll
   for (int i = 0; i < 8; ++i) dst[(size_t)u * 8 + i] = (bf16_t)s[i];
 }
-// fused-MLP weight stream (mlp_fused.h): 16-byte unit u = (j * N_DMA + inst) * 64 + lane of hidden chunk j.
-// Pieces inst < C/16 are the W1 chunk ([KS1][32 hidden rows][64 B], 16 rows per piece), the rest the W2 chunk
-// ([C channel rows][64 B]); the XOR swizzle the kernel's ds_read_b128 expects is applied here.
-__global__ void pk_mlp_stream(const float* __restrict__ W1, const float* __restrict__ W2, int C, bf16_t* __restrict__ dst) {
-  const int n_dma = C / 8, w1p = C / 16;
-  const int u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= (C / 8) * n_dma * 64) return;
-  const int lane = u & 63, inst = (u >> 6) % n_dma, j = (u >> 6) / n_dma;
-  const int slot = lane & 3;
-  const float* s;
-  if (inst < w1p) {
-    const int ks = inst >> 1, r = (inst & 1) * 16 + (lane >> 2), chunk = slot ^ ((r >> 2) & 3);
-    s = W1 + (size_t)(j * 32 + r) * C + ks * 32 + chunk * 8;
-  } else {
-    const int r = (inst - w1p) * 16 + (lane >> 2), chunk = slot ^ ((r >> 2) & 3);
-    s = W2 + (size_t)r * (4 * C) + j * 32 + chunk * 8;
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) dst[(size_t)u * 8 + i] = (bf16_t)s[i];
-}
 __global__ void pk_bn(const float* w, const float* b, const float* mean, const float* var, float* scale, float* shift,
                       int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -244,6 +225,13 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
   ctx->cfg = *cfg;
   ctx->rt = new CnRuntime();
   ctx->esize = cfg->precision == CONETTE_PREC_BF16 ? 2 : 4;
+  {
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        n_cu <= 0)
+      n_cu = 256;
+    ctx->n_cu = n_cu;
+  }
   size_t total = 1 << 20;
   for (int i = 0; i < n_tensors; ++i) total += cn_align((size_t)numel[i] * 4) + 256;
   ctx->arena_bytes = total;
@@ -362,12 +350,13 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
         bw.b2 = B.f32(p + "pwconv2.bias", C);
         bw.mlp_stream = nullptr;
         if (ctx->esize == 2 && C <= 384) {
-          bf16_t* ms = (bf16_t*)B.alloc((size_t)8 * C * C * 2);
+          const size_t bytes = (size_t)(C / 8) * (C / 8 + 1) * 1024 + (size_t)C * 4;  // Rc2Geom<C, 1>::TOTAL_BYTES
+          bf16_t* ms = (bf16_t*)B.alloc(bytes);
           const float* w1 = B.find(p + "pwconv1.weight", (int64_t)4 * C * C);
           const float* w2 = B.find(p + "pwconv2.weight", (int64_t)4 * C * C);
-          if (w1 && w2) {
-            const int units = (C / 8) * (C / 8) * 64;
-            hipLaunchKernelGGL(pk_mlp_stream, dim3((units + 255) / 256), dim3(256), 0, 0, w1, w2, C, ms);
+          if (w1 && w2 && bw.b1 && bw.b2 && bw.scale) {
+            const int units = (C / 8) * (C / 8 + 1) * 64;
+            hipLaunchKernelGGL(pk_mlp_rc2, dim3((units + 255) / 256), dim3(256), 0, 0, w1, bw.b1, w2, bw.b2, bw.scale, C, 1, ms);
             bw.mlp_stream = ms;
           }
         }

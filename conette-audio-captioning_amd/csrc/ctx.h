@@ -25,8 +25,8 @@ struct CnBlockW {
   const void* w2;  // [C][4C]
   const float* b2;
   const float* scale;
-  // bf16, C <= 384: w1 / w2 re-ordered into the exact LDS image of mlp_fused.h's weight ring, one 1 KB DMA piece
-  // after the other: [hidden chunk C/8][piece][lane 64][8 bf16]
+  // bf16, C <= 384: pwconv1 / pwconv2 (+ b1, LayerScale, b2) as the MFMA-fragment stream of mlp_rc2.h:
+  // [hidden chunk C/8][fragment C/8 + 1][lane 64][8 bf16] followed by s * b2 (fp32, C)
   const void* mlp_stream;
 };
 
@@ -99,6 +99,8 @@ struct conette_ctx {
   int pe_len;
   const void* cls_w;  // [V][d]
   const float* cls_b;
+  int n_cu;  // compute units of the device the context lives on (persistent-kernel grids)
+  int enc_reserved_cus;  // CONETTE_OPT_ENCODE_RESERVED_CUS
   // arena
   char* arena;
   size_t arena_bytes;

@@ -1367,6 +1367,14 @@ extern "C" int conette_set_option(conette_ctx* ctx, int32_t option, int32_t valu
     }
     return CN_OK;
   }
+  if (option == CONETTE_OPT_ENCODE_RESERVED_CUS) {
+    if (value < 0 || value > ctx->n_cu / 2) {
+      cn_set_error("set_option: reserved CUs %d outside 0 .. %d", value, ctx->n_cu / 2);
+      return CN_ERR_ARG;
+    }
+    ctx->enc_reserved_cus = value;
+    return CN_OK;
+  }
   cn_set_error("set_option: unknown option %d", option);
   return CN_ERR_ARG;
 }

@@ -9,7 +9,7 @@
 #include <type_traits>
 
 #include "gemm2.h"
-#include "mlp_fused.h"
+#include "mlp_rc2.h"
 
 // ---------------------------------------------------------------------------------------------
 // stem: Conv2d(1 -> 96, k 4x4, s 4x4, pad (4, 0)) + LayerNorm(channels_first, eps 1e-6)
@@ -258,15 +258,6 @@ __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(c
     cn_store4(dst + 4, o[4], o[5], o[6], o[7]);
   }
   DW_STAMP(4)
-}
-
-extern "C" int conette_debug_mlpprof(unsigned long long* out8, int reset) {
-  if (out8) CN_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_mlp_prof), 64));
-  if (reset) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    CN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mlp_prof), z, 64));
-  }
-  return CN_OK;
 }
 
 extern "C" int conette_debug_g2prof(unsigned long long* out16, int reset) {
@@ -620,8 +611,9 @@ static EncWs enc_ws(const conette_ctx* ctx, int B, int L, char* base) {
     return p;
   };
   w.logmel = (float*)take((size_t)B * g.F * CN_N_MELS * 4);
-  w.x = (float*)take(n0 * 4);
-  w.y = take(n0 * es);
+  // (+ 32 rows: the fused MLP reads whole 32-position tiles; rows past the last position are read, never written)
+  w.x = (float*)take((n0 + 32 * 96) * 4);
+  w.y = take((n0 + 32 * 96) * es);
   w.h = take(n0 * 4 * es);
   w.fe_t = take((size_t)B * g.H[3] * CN_FEAT * es);
   w.clip_t = take((size_t)B * CN_FEAT * es);
@@ -709,28 +701,13 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
       }
       bool fused = false;
       if constexpr (std::is_same<T, bf16_t>::value) {
-        // narrow stages: fused MLP keeps the 4C hidden in LDS (mlp_fused.h); timed under PW1
-        static const int mlp384 = getenv("CN_MLP384") ? atoi(getenv("CN_MLP384")) : 1;
-        if (bw.mlp_stream != nullptr && (C == 96 || C == 192 || (C == 384 && mlp384))) {
+        // stages 0-2: register-chained fused MLP (mlp_rc2.h): the 4C hidden never leaves the registers; timed under PW1
+        if (bw.mlp_stream != nullptr && C <= 384) {
           CnProfScope ps(ctx, CONETTE_PROF_PW1_GEMM, s);
           const bf16_t* wsm = (const bf16_t*)bw.mlp_stream;
-          // Row tiles of 256 (C = 96) / 128 (C = 192) positions per block: the kernels are bound by the per-chunk latency
-          // chain, so fewer, fatter chunk iterations win; alone the kernels take the same time as with half the rows and
-          // twice the occupancy, but the pipelined step (decode of the previous batch running beside them) is 5 % shorter.
-          // At 256 clips the decode is a small share of the step and the smaller tiles' slightly faster encode wins
-          // (8.97 k vs 8.54 k clips/s), hence the switch on the batch.  CN_MLP_TILES=0 / 1 forces small / big (A/B).
-          static const int tiles_env = getenv("CN_MLP_TILES") ? atoi(getenv("CN_MLP_TILES")) : -1;
-          const int big = tiles_env >= 0 ? tiles_env : (B <= 128);
-          static const int pipe = getenv("CN_MLP_PIPE") ? atoi(getenv("CN_MLP_PIPE")) : 1;
-          if (C == 96 && big && pipe) CN_TRY((cn_launch_mlp_fused<96, 8, 2, 4, 1>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
-          else if (C == 192 && big && pipe) CN_TRY((cn_launch_mlp_fused<192, 4, 2, 4, 1>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
-          else if (C == 96 && big) CN_TRY((cn_launch_mlp_fused<96, 8, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
-          else if (C == 96) CN_TRY((cn_launch_mlp_fused<96, 4, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
-          else if (C == 192 && big) CN_TRY((cn_launch_mlp_fused<192, 4, 2, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
-          else if (C == 192) CN_TRY((cn_launch_mlp_fused<192, 2, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
-          // (C = 384: the split-ring pipelined loop, CN_MLP_PIPE=2, measured 229 us against 213-223 us: not the default)
-          else if (pipe == 2) CN_TRY((cn_launch_mlp_fused<384, 2, 4, 2, 2>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
-          else CN_TRY((cn_launch_mlp_fused<384, 2, 4>(y, wsm, bw.b1, bw.b2, bw.scale, ws.x, (int)P, s)));
+          if (C == 96) CN_TRY((cn_launch_mlp_rc2_resident<96, 12, 1>(y, wsm, ws.x, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
+          else if (C == 192) CN_TRY((cn_launch_mlp_rc2_ring<192, 8, 1, 5>(y, wsm, ws.x, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
+          else CN_TRY((cn_launch_mlp_rc2_ring<384, 4, 1, 3>(y, wsm, ws.x, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
           fused = true;
         }
       }

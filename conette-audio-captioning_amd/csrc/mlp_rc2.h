@@ -1,0 +1,386 @@
+// Register-chained fused ConvNeXt MLP (bf16), stages 0-2 -- second generation (see mlp_rc.h for the idea):
+//
+//     x[m][:] += scale * ( W2 . gelu( W1 . y[m][:] + b1 ) + b2 )          (convnext.py:66-74)
+//
+// * a wave owns 32 positions; per 32 hidden units: GEMM1 (A = W1 fragments from LDS, B = y fragments in registers,
+//   bias as one extra k-step) -> GELU on the 16 accumulator registers -> GEMM2 with the converted accumulator as the
+//   A operand (X^T . B, cdna guide 3) accumulating O[32 pos][C] with channels on the lanes;
+// * a STEP covers NCK = 1 or 2 chunks and is one basic block whose MFMA / VALU / LDS-read interleave is laid down with
+//   sched_group_barrier: NCK = 2:  M1a | M1b + GELU a | M2a + GELU b | M2b;   NCK = 1:  M1 | GELU lo | M2(k 0) + GELU hi | M2(k 1)
+//   with the fragment reads running a few MFMAs ahead of their use;
+// * LayerScale is folded into the packed W2 rows (W2'[c][:] = bf16(s[c] W2[c][:])) and the accumulators START from the
+//   residual: O = x, loaded straight into the accumulator registers at the start of a tile (the HBM latency hides under
+//   the first GEMM1; no VALU work, no extra registers); the epilogue is x' = O + s b2, stores only.
+//
+// Packed stream per step (1 KB fragments, lane l reads 16 B at 16 l):
+//   [chunk i: W1 fragments k-step 0 .. C/16-1, bias fragment] i < NCK, then [chunk i: W2 fragments (k 0, tile t) t < C/32, (k 1, t)] i < NCK
+// followed by the per-channel vector bb = s b2 (fp32, C).
+#pragma once
+#include "common.h"
+
+#ifndef CN_F32X16
+#define CN_F32X16
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+#endif
+
+template <int C, int NCK> struct Rc2Geom {
+  static constexpr int KS1 = C / 16, NT2 = C / 32, NCH = C / 8;
+  static constexpr int F1 = KS1 + 1, F2 = 2 * NT2;
+  static constexpr int NSTEP = NCH / NCK;            // steps per tile
+  static constexpr int FRAGS = NCK * (F1 + F2);      // fragments per step
+  static constexpr int STEP_BYTES = FRAGS * 1024;
+  static constexpr size_t STREAM_BYTES = (size_t)NSTEP * STEP_BYTES;
+  static constexpr size_t TOTAL_BYTES = STREAM_BYTES + C * 4;
+};
+
+// GELU as x * sigmoid(x (a + b x^2 + c x^4)): minimax fit of the logit of the normal CDF on [-8, 8], max |error|
+// against the exact erf form 2.5e-5 (tanh form: 4.7e-4).  x^2 is clamped at 64, where the quartic would bend back.
+__device__ __forceinline__ float cn_gelu_sig2(float x) {
+  constexpr float L2E = 1.4426950408889634f;
+  const float x2 = fminf(x * x, 64.0f);
+  float p = fmaf(x2, 0.0007030350670982541f * L2E, -0.07401130190658815f * L2E);
+  p = fmaf(p, x2, -1.5950157568571721f * L2E);
+  const float e = __builtin_amdgcn_exp2f(x * p);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// two elements at once: v_pk_mul / v_pk_fma / v_pk_add carry both (the two min, exp2 and rcp stay scalar)
+__device__ __forceinline__ f32x2 cn_gelu_sig2_pk(f32x2 x) {
+  constexpr float L2E = 1.4426950408889634f;
+  f32x2 x2 = x * x;
+  x2 = f32x2{fminf(x2[0], 64.0f), fminf(x2[1], 64.0f)};
+  f32x2 p = x2 * (0.0007030350670982541f * L2E) + (-0.07401130190658815f * L2E);
+  p = p * x2 + (-1.5950157568571721f * L2E);
+  const f32x2 u = x * p;
+  const f32x2 d = f32x2{__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])} + 1.0f;
+  return x * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+
+// ---- packing (fp32 nn.Linear layouts -> fragment stream + aux) ------------------------------------------------------
+static __global__ void pk_mlp_rc2(const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+                           const float* __restrict__ b2, const float* __restrict__ scale, int C, int NCK,
+                           bf16_t* __restrict__ dst) {
+  const int KS1 = C / 16, NT2 = C / 32, NCH = C / 8, F1 = KS1 + 1, F2 = 2 * NT2, FRAGS = NCK * (F1 + F2), NSTEP = NCH / NCK;
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < C) ((float*)((char*)dst + (size_t)NSTEP * FRAGS * 1024))[u] = scale[u] * b2[u];  // bb behind the stream
+  if (u >= NSTEP * FRAGS * 64) return;
+  const int l = u & 63, q = (u >> 6) % FRAGS, st = (u >> 6) / FRAGS;
+  const int r = l & 31, h = l >> 5;
+  float v[8];
+  if (q < NCK * F1) {
+    const int j = st * NCK + q / F1, s = q % F1;
+    if (s < KS1) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = W1[(size_t)(32 * j + r) * C + 16 * s + 8 * h + i];
+    } else {
+      const float b = b1[32 * j + r];
+      const float hi = (float)(bf16_t)b;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = 0.f;
+      if (h == 0) {
+        v[0] = hi;
+        v[1] = b - hi;
+      }
+    }
+  } else {
+    const int q2 = q - NCK * F1;
+    const int j = st * NCK + q2 / F2, s = (q2 % F2) / NT2, t = (q2 % F2) % NT2;
+    const int c = 32 * t + r;
+    const float sc = scale[c];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = sc * W2[(size_t)c * (4 * C) + 32 * j + 16 * s + 8 * (i >> 2) + 4 * h + (i & 3)];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dst[(size_t)u * 8 + i] = (bf16_t)v[i];
+}
+
+// sched_group_barrier masks (LLVM AMDGPU IGroupLP)
+#define CN_SG_VALU 0x002
+#define CN_SG_MFMA 0x008
+#define CN_SG_DSR 0x100
+
+template <int C, int NCK> struct Rc2Wave {
+  typedef Rc2Geom<C, NCK> G;
+  static constexpr int KS1 = G::KS1, NT2 = G::NT2, F1 = G::F1, F2 = G::F2;
+  static constexpr int NV = 88;  // VALU instructions of the GELU + bf16 packing of 8 accumulator registers (approx.)
+
+  static __device__ __forceinline__ bf16x8 frag(const char* wc, int f) { return *(const bf16x8*)(wc + f * 1024); }
+  static __device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ bf16x8 gelu8(const f32x16& X, int o) {
+    float g[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = cn_gelu_sig2(X[o + i]);
+    return bf16x8{(bf16_t)g[0], (bf16_t)g[1], (bf16_t)g[2], (bf16_t)g[3], (bf16_t)g[4], (bf16_t)g[5], (bf16_t)g[6], (bf16_t)g[7]};
+  }
+  static __device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+  }
+
+  // One step; fragments at wc (LDS, lane offset applied).  MFMA q of a step consumes fragment q of the packed stream.
+  // The instruction order is laid down BY HAND (sched_barrier(0) between slices; sched_group_barrier pipelines of this
+  // size were not honoured by the scheduler): fragment q + PRE is requested before MFMA q, and the GELU of an accumulator
+  // is cut into per-element slices placed behind the MFMAs of the neighbouring GEMM:
+  //   NCK = 2:  M1a | M1b + GELU a | M2a + GELU b | M2b        NCK = 1:  M1 | GELU lo | M2(k 0) + GELU hi | M2(k 1)
+  static constexpr int PRE = 4;
+  static constexpr int NM = NCK * (F1 + F2), R = PRE + 1;
+  struct State {
+    bf16x8 F[R];
+    f32x16 X[NCK];
+    float g[NCK][16];
+    bf16x8 H[NCK][2];
+  };
+  // index of the MFMA behind which GELU element e of chunk i is placed
+  static constexpr int gelu_at(int i, int e) {
+    if (NCK == 2) return i == 0 ? F1 + 1 + e * (F1 - 1) / 16 : 2 * F1 + e * F2 / 16;
+    return e < 8 ? F1 - 1 : F1 + (e - 8) * NT2 / 8;
+  }
+  template <int Q, int I, int E>
+  static __device__ __forceinline__ void gelu_slices(State& st) {  // (compile-time recursion: every index is a constant)
+#ifdef CN_RC2_GELU_PK
+    if constexpr ((E & 1) == 0 && gelu_at(I, E) == Q) {  // pairs (E, E + 1) ride together behind MFMA gelu_at(I, E)
+      const f32x2 r = cn_gelu_sig2_pk(f32x2{st.X[I][E], st.X[I][E + 1]});
+      st.g[I][E] = r[0];
+      st.g[I][E + 1] = r[1];
+    }
+    if constexpr (gelu_at(I, E & ~1) == Q) {
+#else
+    if constexpr (gelu_at(I, E) == Q) {
+      st.g[I][E] = cn_gelu_sig2(st.X[I][E]);
+#endif
+      if constexpr ((E & 7) == 7) {
+        constexpr int o = E - 7;
+        st.H[I][E >> 3] = bf16x8{(bf16_t)st.g[I][o],     (bf16_t)st.g[I][o + 1], (bf16_t)st.g[I][o + 2], (bf16_t)st.g[I][o + 3],
+                                 (bf16_t)st.g[I][o + 4], (bf16_t)st.g[I][o + 5], (bf16_t)st.g[I][o + 6], (bf16_t)st.g[I][o + 7]};
+      }
+    }
+    if constexpr (E + 1 < 16) gelu_slices<Q, I, E + 1>(st);
+    else if constexpr (I + 1 < NCK) gelu_slices<Q, I + 1, 0>(st);
+  }
+  template <int Q>
+  static __device__ __forceinline__ void mstep(const char* wc, const bf16x8 (&fy)[KS1], const bf16x8 ones, f32x16 (&O)[NT2],
+                                               State& st) {
+    if constexpr (Q + PRE < NM) st.F[(Q + PRE) % R] = frag(wc, Q + PRE);
+    if constexpr (Q < NCK * F1) {
+      constexpr int i = Q / F1, s = Q % F1;
+      if constexpr (s == 0) st.X[i] = zero16();
+      if constexpr (s < KS1) st.X[i] = mma(st.F[Q % R], fy[s], st.X[i]);
+      else st.X[i] = mma(st.F[Q % R], ones, st.X[i]);
+    } else {
+      constexpr int q2 = Q - NCK * F1, i = q2 / F2, k = (q2 % F2) / NT2, t = q2 % NT2;
+      O[t] = mma(st.H[i][k], st.F[Q % R], O[t]);
+    }
+    gelu_slices<Q, 0, 0>(st);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (Q + 1 < NM) mstep<Q + 1>(wc, fy, ones, O, st);
+  }
+  template <int Q>
+  static __device__ __forceinline__ void prefetch(const char* wc, State& st) {
+    st.F[Q % R] = frag(wc, Q);
+    if constexpr (Q + 1 < PRE) prefetch<Q + 1>(wc, st);
+  }
+  static __device__ __forceinline__ void step(const char* wc, const bf16x8 (&fy)[KS1], const bf16x8 ones, f32x16 (&O)[NT2]) {
+    State st;
+    prefetch<0>(wc, st);
+    __builtin_amdgcn_sched_barrier(0);
+    mstep<0>(wc, fy, ones, O, st);
+  }
+
+  // Addressing: tile bases are wave-uniform (scalar), the per-lane part is ONE loop-invariant 32-bit offset and the rest
+  // are immediates.  Rows of a ragged last tile beyond M are READ (never written): Y and X must be readable for 31 rows
+  // past M (the encoder workspace is padded accordingly).
+
+  // y rows of a 32-position tile as B fragments: fy[s] = y[m0 + (l & 31)][16 s + 8 (l >> 5) .. + 8]
+  static __device__ __forceinline__ void load_y(const bf16_t* __restrict__ Y, int m0, int lane, bf16x8 (&fy)[KS1]) {
+    const bf16_t* base = Y + (size_t)m0 * C;                 // scalar
+    const int voff = (lane & 31) * C + 8 * (lane >> 5);      // elements
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) fy[s] = *(const bf16x8*)(base + voff + 16 * s);
+  }
+
+  // O = x: lane = channel 32 t + (l & 31), register r = position (r&3) + 8 (r>>2) + 4 (l>>5)
+  static __device__ __forceinline__ void init_o(const float* __restrict__ X, int m0, int lane, f32x16 (&O)[NT2]) {
+    const int voff = 4 * (lane >> 5) * C + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* row = X + (size_t)(m0 + (r & 3) + 8 * (r >> 2)) * C;  // scalar
+#pragma unroll
+      for (int t = 0; t < NT2; ++t) O[t][r] = row[voff + 32 * t];
+    }
+  }
+
+  // x' = O + bb, straight from the accumulator layout (two whole 128-byte row pieces per store instruction)
+  static __device__ __forceinline__ void store_o(float* __restrict__ X, const float* __restrict__ bbv, int m0, int M, int lane,
+                                                 const f32x16 (&O)[NT2]) {
+    const int voff = 4 * (lane >> 5) * C + (lane & 31);
+    const int plim = M - m0 - 4 * (lane >> 5);  // this lane's rows (r&3) + 8 (r>>2) < plim are inside the tensor
+    float bb[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) bb[t] = bbv[32 * t + (lane & 31)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float* row = X + (size_t)(m0 + (r & 3) + 8 * (r >> 2)) * C;  // scalar
+      if ((r & 3) + 8 * (r >> 2) < plim) {
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) row[voff + 32 * t] = O[t][r] + bb[t];
+      }
+    }
+  }
+};
+
+// ---- resident variant (C = 96): the whole stream (156 KB) lives in LDS; persistent blocks; no barrier, no DMA after the fill
+template <int C, int NW, int NCK>
+__global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_resident_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ WS,
+                                                                      float* __restrict__ X, int M) {
+  typedef Rc2Geom<C, NCK> G;
+  typedef Rc2Wave<C, NCK> W;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int TOTAL = G::NSTEP * G::FRAGS;
+  for (int i = wave; i < TOTAL; i += NW)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)WS + (size_t)i * 1024 + lane * 16),
+                                     (__attribute__((address_space(3))) void*)(smem + i * 1024), 16, 0, 0);
+  const float* aux = (const float*)((const char*)WS + G::STREAM_BYTES);
+  const int n_tiles = (M + 31) >> 5;
+  const int t_lo = (int)((long)blockIdx.x * n_tiles / gridDim.x), t_hi = (int)((long)(blockIdx.x + 1) * n_tiles / gridDim.x);
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)((lane < 32 && i < 2) ? 1.0f : 0.0f);
+  bf16x8 fy[G::KS1];
+  int tile = t_lo + wave;
+  if (tile < t_hi) W::load_y(Y, tile * 32, lane, fy);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const char* wl = smem + lane * 16;
+  for (; tile < t_hi; tile += NW) {
+    f32x16 O[G::NT2];
+    W::init_o(X, tile * 32, lane, O);
+#pragma unroll 1
+    for (int j = 0; j < G::NSTEP; ++j) W::step(wl + j * G::STEP_BYTES, fy, ones, O);
+    if (tile + NW < t_hi) W::load_y(Y, (tile + NW) * 32, lane, fy);
+    W::store_o(X, aux, tile * 32, M, lane, O);
+  }
+}
+
+template <int C, int NW, int NCK>
+static int cn_launch_mlp_rc2_resident(const bf16_t* Y, const bf16_t* WS, float* X, int M, int n_blocks, hipStream_t s) {
+  constexpr int SMEM = (int)Rc2Geom<C, NCK>::STREAM_BYTES;
+  static_assert(SMEM <= 160 * 1024, "resident variant: the weight stream must fit in LDS");
+  static bool configured = false;
+  if (!configured) {
+    CN_HIP(hipFuncSetAttribute((const void*)cn_mlp_rc2_resident_kernel<C, NW, NCK>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    configured = true;
+  }
+  const int n_tiles = (M + 31) / 32;
+  const int grid = n_blocks < cn_cdiv(n_tiles, NW) ? n_blocks : cn_cdiv(n_tiles, NW);
+  hipLaunchKernelGGL((cn_mlp_rc2_resident_kernel<C, NW, NCK>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, Y, WS, X, M);
+  CN_LAUNCH_CHECK();
+  return CN_OK;
+}
+
+// ---- ring variant (C = 192: 8 waves, C = 384: 4 waves): steps stream L2 -> LDS through an NST-deep ring ----------------
+// Step g of a block consumes ring entry g (stream step g % NSTEP); entry g + NST - 1 is requested at the start of step g,
+// right after the barrier that publishes entry g and retires entry g - 1.  vmcnt: at most (NST - 2) younger entries of
+// this wave's pieces may be outstanding when entry g is needed; any other vector-memory operation in between (residual
+// loads, stores) only makes that wait stricter, never unsafe (the counter retires in order).
+// PROF (kernel lab only): per-step s_memtime stamps at points where no LDS read is in flight -> prof[0..4] =
+// wait for the DMA, barrier, DMA issue, step compute, tile boundary (sums over waves, in cycles), prof[5] = wave-steps
+template <int C, int NW, int NCK, int NST, int PROF = 0>
+__global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_ring_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ WS,
+                                                                  float* __restrict__ X, int M, unsigned long long* prof = nullptr) {
+  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0, nstep = 0;
+  auto stamp = [&](int i) {
+    if constexpr (PROF) {
+      const unsigned long long t = clock64();
+      tacc[i] += t - tprev;
+      tprev = t;
+    }
+  };
+  if constexpr (PROF) tprev = clock64();
+  typedef Rc2Geom<C, NCK> G;
+  typedef Rc2Wave<C, NCK> W;
+  constexpr int FR = G::FRAGS, SB = G::STEP_BYTES;
+  constexpr int DPW_LO = FR / NW, N_HI = FR % NW;  // waves < N_HI issue DPW_LO + 1 pieces per entry
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float* aux = (const float*)((const char*)WS + G::STREAM_BYTES);
+
+  const int n_tiles = (M + 31) >> 5;
+  const int t_lo = (int)((long)blockIdx.x * n_tiles / gridDim.x), t_hi = (int)((long)(blockIdx.x + 1) * n_tiles / gridDim.x);
+  const int max_it = (t_hi - t_lo + NW - 1) / NW;  // block-uniform: every wave runs the same number of steps
+
+  const char* wsrc = (const char*)WS + lane * 16;
+  auto stage = [&](int g) {  // stream step g % NSTEP -> slot g % NST (this wave's pieces)
+    const char* src = wsrc + (size_t)(g % G::NSTEP) * SB;
+    char* dst = smem + (g % NST) * SB;
+#pragma unroll
+    for (int i = 0; i < DPW_LO + 1; ++i) {
+      const int piece = wave + i * NW;
+      if (i < DPW_LO || wave < N_HI)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+    }
+  };
+  bf16x8 ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)((lane < 32 && i < 2) ? 1.0f : 0.0f);
+
+#pragma unroll
+  for (int g = 0; g < NST - 1; ++g) stage(g);
+  bf16x8 fy[G::KS1];
+  if (t_lo + wave < t_hi) W::load_y(Y, (t_lo + wave) * 32, lane, fy);
+  const char* wl = smem + lane * 16;
+  int g = 0;
+  for (int it = 0; it < max_it; ++it) {
+    const int tile = t_lo + wave + it * NW;
+    const bool valid = tile < t_hi;
+    f32x16 O[G::NT2];
+    for (int j = 0; j < G::NSTEP; ++j, ++g) {
+      stamp(4);
+      if (N_HI > 0 && wave < N_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (DPW_LO + 1)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * DPW_LO) : "memory");
+      stamp(0);
+      __builtin_amdgcn_s_barrier();
+      stamp(1);
+      stage(g + NST - 1);
+      if (j == 0 && valid) W::init_o(X, tile * 32, lane, O);
+      stamp(2);
+      if (valid) W::step(wl + (g % NST) * SB, fy, ones, O);
+      stamp(3);
+      if constexpr (PROF) nstep += valid;
+    }
+    if (tile + NW < t_hi) W::load_y(Y, (tile + NW) * 32, lane, fy);
+    if (valid) W::store_o(X, aux, tile * 32, M, lane, O);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring was filled NST - 1 entries past the end
+  if constexpr (PROF) {
+    if (lane == 0 && prof) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) atomicAdd(prof + i, tacc[i]);
+      atomicAdd(prof + 5, nstep);
+    }
+  }
+}
+
+template <int C, int NW, int NCK, int NST, int PROF = 0>
+static int cn_launch_mlp_rc2_ring(const bf16_t* Y, const bf16_t* WS, float* X, int M, int n_blocks, hipStream_t s,
+                                  unsigned long long* prof = nullptr) {
+  constexpr int SMEM = NST * Rc2Geom<C, NCK>::STEP_BYTES;
+  static_assert(SMEM <= 160 * 1024, "ring must fit in LDS");
+  static bool configured = false;
+  if (!configured) {
+    CN_HIP(hipFuncSetAttribute((const void*)cn_mlp_rc2_ring_kernel<C, NW, NCK, NST, PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    configured = true;
+  }
+  const int n_tiles = (M + 31) / 32;
+  const int grid = n_blocks < cn_cdiv(n_tiles, NW) ? n_blocks : cn_cdiv(n_tiles, NW);
+  hipLaunchKernelGGL((cn_mlp_rc2_ring_kernel<C, NW, NCK, NST, PROF>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, Y, WS, X, M, prof);
+  CN_LAUNCH_CHECK();
+  return CN_OK;
+}

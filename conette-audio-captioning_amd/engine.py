@@ -31,6 +31,7 @@ EXPORTS = (
 )
 OPT_DECODE_GRAPH = 1
 OPT_DECODE_FUSION = 2
+OPT_ENCODE_RESERVED_CUS = 3
 PROF_CLASSES = ("frontend", "stem", "dwconv_ln", "pw1_gemm", "pw2_gemm", "downsample", "heads", "dec_prepare",
                 "dec_gemm", "dec_attn", "dec_misc", "search")
 
@@ -369,6 +370,10 @@ class Engine:
     def set_decode_fusion(self, enabled: bool) -> None:
         """bf16: fused decoder-layer kernels (default) or one launch per sub-layer (cross-check path)."""
         _check(self.lib.conette_set_option(self._ctx, OPT_DECODE_FUSION, int(bool(enabled))), "set_option")
+
+    def set_encode_reserved_cus(self, n: int) -> None:
+        """Compute units the encoder's persistent kernels leave free for a decode running on another stream."""
+        _check(self.lib.conette_set_option(self._ctx, OPT_ENCODE_RESERVED_CUS, int(n)), "set_option")
 
     def profile_enable(self, classes=()) -> None:
         mask = 0

@@ -153,6 +153,9 @@ int conette_stream_destroy(void* stream);
 /* Runtime options. */
 #define CONETTE_OPT_DECODE_GRAPH 1 /* 1 (default): replay conette_decode from a cached hipGraph */
 #define CONETTE_OPT_DECODE_FUSION 2 /* 1 (default): fused decoder-layer kernels (bf16); 0: one launch per sub-layer */
+#define CONETTE_OPT_ENCODE_RESERVED_CUS 3 /* default 0: compute units the encoder's persistent kernels leave free, so that
+                                            the small dependent kernels of a conette_decode running on another stream are
+                                            not queued behind them (0 .. n_cu / 2) */
 int conette_set_option(conette_ctx* ctx, int32_t option, int32_t value);
 
 /* Per-kernel-class timing with HIP events recorded on the caller's stream around each launch

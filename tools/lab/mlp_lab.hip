@@ -1,0 +1,253 @@
+// Kernel lab for the fused ConvNeXt MLP kernels (development aid, not part of the product library):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I conette-audio-captioning_amd/csrc tools/lab/mlp_lab.hip -o tools/lab/mlp_lab
+//   tools/lab/mlp_lab [C] [batch] [iters]
+// Checks every variant against a naive bf16-operand reference kernel on a small M (full tensors), then times it on
+// the benchmark shape (batch x positions-per-clip rows) with HIP events, interleaved rounds.
+#include <stdarg.h>
+#include <math.h>
+#include <stdlib.h>
+#include <vector>
+#include <string>
+#include <algorithm>
+
+#include "mlp_rc.h"
+#include "mlp_rc_ring.h"
+#include "mlp_rc2.h"
+
+void cn_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vfprintf(stderr, fmt, ap);
+  va_end(ap);
+  fprintf(stderr, "\n");
+}
+
+#define CK(x)                                                                      \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess) {                                                        \
+      fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      exit(1);                                                                     \
+    }                                                                              \
+  } while (0)
+
+// naive reference: bf16 operands (y, W1, W2, hidden), fp32 accumulation, exact erf GELU
+__global__ void ref_hidden(const bf16_t* Y, const float* W1, const float* b1, int C, int M, bf16_t* H) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)M * 4 * C) return;
+  const int m = (int)(i / (4 * C)), n = (int)(i % (4 * C));
+  float a = 0.f;
+  for (int k = 0; k < C; ++k) a = fmaf((float)Y[(size_t)m * C + k], (float)(bf16_t)W1[(size_t)n * C + k], a);
+  a += b1[n];
+  H[i] = (bf16_t)(0.5f * a * (1.0f + erff(a * 0.70710678118654752440f)));
+}
+// folded = 1: LayerScale folded into the bf16 W2 operand (mlp_rc2.h): x += sum h * bf16(s W2) + s b2
+__global__ void ref_out(const bf16_t* H, const float* W2, const float* b2, const float* scale, int C, int M, float* X, int folded) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)M * C) return;
+  const int m = (int)(i / C), n = (int)(i % C);
+  float a = 0.f;
+  const float sc = scale[n];
+  for (int k = 0; k < 4 * C; ++k) {
+    const float w = W2[(size_t)n * 4 * C + k];
+    a = fmaf((float)H[(size_t)m * 4 * C + k], (float)(bf16_t)(folded ? sc * w : w), a);
+  }
+  X[i] += folded ? a + sc * b2[n] : sc * (a + b2[n]);
+}
+
+static uint32_t rng_state = 12345u;
+static float frand() {  // uniform [-1, 1)
+  rng_state = rng_state * 1664525u + 1013904223u;
+  return (float)((rng_state >> 8) & 0xFFFFFF) / 8388608.0f - 1.0f;
+}
+
+template <typename T> static T* dalloc(size_t n) {
+  T* p;
+  CK(hipMalloc(&p, n * sizeof(T)));
+  return p;
+}
+
+struct Variant {
+  std::string name;
+  int (*run)(const bf16_t* Y, const bf16_t* WS, const float* b2, const float* scale, float* X, int M, hipStream_t s);
+  int pack = 0;  // 0: mlp_rc.h stream, 1 / 2: mlp_rc2.h stream with NCK = 1 / 2
+};
+
+template <int C> static std::vector<Variant> variants();
+
+template <> std::vector<Variant> variants<96>() {
+  return {
+      {"rc_resident<96,8>",
+       [](const bf16_t* Y, const bf16_t* WS, const float* b2, const float* sc, float* X, int M, hipStream_t s) {
+         return cn_launch_mlp_rc_resident<96, 8>(Y, WS, b2, sc, X, M, 256, s);
+       }, 0},
+      {"rc_resident<96,12>",
+       [](const bf16_t* Y, const bf16_t* WS, const float* b2, const float* sc, float* X, int M, hipStream_t s) {
+         return cn_launch_mlp_rc_resident<96, 12>(Y, WS, b2, sc, X, M, 256, s);
+       }, 0},
+      {"rc2_resident<96,8,nck2>",
+       [](const bf16_t* Y, const bf16_t* WS, const float* b2, const float* sc, float* X, int M, hipStream_t s) {
+         return cn_launch_mlp_rc2_resident<96, 8, 2>(Y, WS, X, M, 256, s);
+       }, 2},
+      {"rc2_resident<96,8,nck1>",
+       [](const bf16_t* Y, const bf16_t* WS, const float* b2, const float* sc, float* X, int M, hipStream_t s) {
+         return cn_launch_mlp_rc2_resident<96, 8, 1>(Y, WS, X, M, 256, s);
+       }, 1},
+      {"rc2_resident<96,12,nck1>",
+       [](const bf16_t* Y, const bf16_t* WS, const float* b2, const float* sc, float* X, int M, hipStream_t s) {
+         return cn_launch_mlp_rc2_resident<96, 12, 1>(Y, WS, X, M, 256, s);
+       }, 1},
+  };
+}
+template <> std::vector<Variant> variants<192>() {
+  return {
+      {"rc_ring<192,8,5>",
+       [](const bf16_t* Y, const bf16_t* WS, const float* b2, const float* sc, float* X, int M, hipStream_t s) {
+         return cn_launch_mlp_rc_ring<192, 8, 5>(Y, WS, b2, sc, X, M, 256, s);
+       }, 0},
+      {"rc2_ring<192,8,nck1,nst5>",
+       [](const bf16_t* Y, const bf16_t* WS, const float* b2, const float* sc, float* X, int M, hipStream_t s) {
+         return cn_launch_mlp_rc2_ring<192, 8, 1, 5>(Y, WS, X, M, 256, s);
+       }, 1},
+      {"rc2_ring<192,8,nck2,nst3>",
+       [](const bf16_t* Y, const bf16_t* WS, const float* b2, const float* sc, float* X, int M, hipStream_t s) {
+         return cn_launch_mlp_rc2_ring<192, 8, 2, 3>(Y, WS, X, M, 256, s);
+       }, 2},
+  };
+}
+template <> std::vector<Variant> variants<384>() {
+  return {
+      {"rc_ring<384,4,3>",
+       [](const bf16_t* Y, const bf16_t* WS, const float* b2, const float* sc, float* X, int M, hipStream_t s) {
+         return cn_launch_mlp_rc_ring<384, 4, 3>(Y, WS, b2, sc, X, M, 256, s);
+       }, 0},
+      {"rc2_ring<384,4,nck1,nst3>",
+       [](const bf16_t* Y, const bf16_t* WS, const float* b2, const float* sc, float* X, int M, hipStream_t s) {
+         return cn_launch_mlp_rc2_ring<384, 4, 1, 3>(Y, WS, X, M, 256, s);
+       }, 1},
+  };
+}
+
+template <int C> static int run(int batch, int iters) {
+  const int pos_per_clip = C == 96 ? 252 * 56 : C == 192 ? 126 * 28 : 63 * 14;
+  const int M = batch * pos_per_clip;
+  const int Mc = 4096 + 19;  // check size (ragged last tile)
+  printf("== C = %d, M = %d (batch %d), check M = %d\n", C, M, batch, Mc);
+  std::vector<float> hW1((size_t)4 * C * C), hW2((size_t)4 * C * C), hb1(4 * C), hb2(C), hsc(C);
+  const float s1 = 1.7f / sqrtf((float)C), s2 = 1.7f / sqrtf(4.0f * C);
+  for (auto& v : hW1) v = frand() * s1;
+  for (auto& v : hW2) v = frand() * s2;
+  for (auto& v : hb1) v = frand() * 0.5f;
+  for (auto& v : hb2) v = frand() * 0.5f;
+  for (auto& v : hsc) v = 0.1f + 0.4f * fabsf(frand());
+  std::vector<bf16_t> hY((size_t)(M + 64) * C);
+  std::vector<float> hX((size_t)M * C);
+  for (auto& v : hY) v = (bf16_t)(frand() * 1.5f);
+  for (auto& v : hX) v = frand();
+  float *W1 = dalloc<float>(hW1.size()), *W2 = dalloc<float>(hW2.size()), *b1 = dalloc<float>(4 * C), *b2 = dalloc<float>(C),
+        *sc = dalloc<float>(C);
+  bf16_t* Y = dalloc<bf16_t>(hY.size());
+  float *X = dalloc<float>(hX.size() + 64 * C), *Xref = dalloc<float>((size_t)Mc * C), *Xref2 = dalloc<float>((size_t)Mc * C);
+  bf16_t* H = dalloc<bf16_t>((size_t)Mc * 4 * C);
+  bf16_t* WS = dalloc<bf16_t>((size_t)RcGeom<C>::NCH * RcGeom<C>::CHUNK_BYTES / 2);
+  bf16_t* WS2[3] = {WS, dalloc<bf16_t>(Rc2Geom<C, 1>::TOTAL_BYTES / 2), dalloc<bf16_t>(Rc2Geom<C, 2>::TOTAL_BYTES / 2)};
+  CK(hipMemcpy(W1, hW1.data(), hW1.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(W2, hW2.data(), hW2.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(b1, hb1.data(), 4 * C * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(b2, hb2.data(), C * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(sc, hsc.data(), C * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(Y, hY.data(), hY.size() * 2, hipMemcpyHostToDevice));
+  {
+    const int units = RcGeom<C>::NCH * RcGeom<C>::PIECES * 64;
+    hipLaunchKernelGGL(pk_mlp_rc, dim3((units + 255) / 256), dim3(256), 0, 0, W1, b1, W2, C, WS);
+    for (int nck = 1; nck <= 2; ++nck) {
+      const int u2 = (C / 8) * (C / 8 + 1) * 64;
+      hipLaunchKernelGGL(pk_mlp_rc2, dim3((u2 + 255) / 256), dim3(256), 0, 0, W1, b1, W2, b2, sc, C, nck, WS2[nck]);
+    }
+  }
+  // reference on the first Mc rows
+  CK(hipMemcpy(Xref, hX.data(), (size_t)Mc * C * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(ref_hidden, dim3((unsigned)(((long)Mc * 4 * C + 255) / 256)), dim3(256), 0, 0, Y, W1, b1, C, Mc, H);
+  hipLaunchKernelGGL(ref_out, dim3((unsigned)(((long)Mc * C + 255) / 256)), dim3(256), 0, 0, H, W2, b2, sc, C, Mc, Xref, 0);
+  CK(hipMemcpy(Xref2, hX.data(), (size_t)Mc * C * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(ref_out, dim3((unsigned)(((long)Mc * C + 255) / 256)), dim3(256), 0, 0, H, W2, b2, sc, C, Mc, Xref2, 1);
+  CK(hipDeviceSynchronize());
+  std::vector<float> href0((size_t)Mc * C), href1((size_t)Mc * C), hgot((size_t)(Mc + 64) * C);
+  CK(hipMemcpy(href0.data(), Xref, href0.size() * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(href1.data(), Xref2, href1.size() * 4, hipMemcpyDeviceToHost));
+
+  auto vs = variants<C>();
+  int bad = 0;
+  for (auto& v : vs) {
+    CK(hipMemcpy(X, hX.data(), (size_t)(Mc + 64) * C * 4, hipMemcpyHostToDevice));
+    if (v.run(Y, WS2[v.pack], b2, sc, X, Mc, 0) != CN_OK) return 1;
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(hgot.data(), X, hgot.size() * 4, hipMemcpyDeviceToHost));
+    const std::vector<float>& href = v.pack ? href1 : href0;
+    double max_err = 0, sum_err = 0, max_ref = 0;
+    size_t n_bad = 0;
+    for (size_t i = 0; i < href.size(); ++i) {
+      const double e = fabs((double)hgot[i] - href[i]);
+      max_err = std::max(max_err, e);
+      sum_err += e;
+      max_ref = std::max(max_ref, (double)fabs(href[i] - hX[i]));
+      if (e > 1e-3 + 1e-3 * fabs(href[i])) ++n_bad;
+    }
+    size_t touched = 0;  // rows beyond Mc must be untouched
+    for (size_t i = href.size(); i < hgot.size(); ++i) touched += hgot[i] != hX[i];
+    printf("  check %-34s max|err| %.3e  mean %.3e  (max |delta| %.3f)  out-of-tol %zu  rows>=M touched %zu  %s\n", v.name.c_str(),
+           max_err, sum_err / href.size(), max_ref, n_bad, touched, (n_bad == 0 && touched == 0) ? "OK" : "FAIL");
+    bad += (n_bad != 0 || touched != 0);
+  }
+
+  // timing: interleaved rounds
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  CK(hipMemcpy(X, hX.data(), hX.size() * 4, hipMemcpyHostToDevice));
+  std::vector<std::vector<float>> times(vs.size());
+  const double flops = 16.0 * C * C * (double)M;
+  for (int round = 0; round < 5; ++round)
+    for (size_t vi = 0; vi < vs.size(); ++vi) {
+      vs[vi].run(Y, WS2[vs[vi].pack], b2, sc, X, M, 0);  // warm
+      CK(hipEventRecord(e0, 0));
+      for (int it = 0; it < iters; ++it) vs[vi].run(Y, WS2[vs[vi].pack], b2, sc, X, M, 0);
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      times[vi].push_back(ms * 1000.0f / iters);
+    }
+  for (size_t vi = 0; vi < vs.size(); ++vi) {
+    std::sort(times[vi].begin(), times[vi].end());
+    const double med = times[vi][times[vi].size() / 2], mn = times[vi][0];
+    printf("  time  %-34s median %8.1f us  min %8.1f us  -> %7.1f TFLOP/s (%.3f of 2.5 PF)\n", vs[vi].name.c_str(), med, mn,
+           flops / med * 1e-6, flops / med * 1e-6 / 2500.0);
+  }
+  // phase profile of the ring kernels (separate instrumented instantiation)
+  if constexpr (C != 96) {
+    unsigned long long* prof = dalloc<unsigned long long>(8);
+    CK(hipMemset(prof, 0, 64));
+    if constexpr (C == 192) cn_launch_mlp_rc2_ring<192, 8, 1, 5, 1>(Y, WS2[1], X, M, 256, 0, prof);
+    else cn_launch_mlp_rc2_ring<384, 4, 1, 3, 1>(Y, WS2[1], X, M, 256, 0, prof);
+    CK(hipDeviceSynchronize());
+    unsigned long long h[8];
+    CK(hipMemcpy(h, prof, 64, hipMemcpyDeviceToHost));
+    const char* nm[5] = {"wait DMA", "barrier", "DMA issue (+ tile init)", "step compute", "tile boundary / loop"};
+    const double n = (double)h[5];
+    printf("  phase profile (cycles per valid wave-step, %llu wave-steps):\n", h[5]);
+    for (int i = 0; i < 5; ++i) printf("    %-26s %9.1f\n", nm[i], h[i] / n);
+  }
+  return bad;
+}
+
+int main(int argc, char** argv) {
+  const int C = argc > 1 ? atoi(argv[1]) : 96;
+  const int batch = argc > 2 ? atoi(argv[2]) : 64;
+  const int iters = argc > 3 ? atoi(argv[3]) : 10;
+  if (C == 96) return run<96>(batch, iters);
+  if (C == 192) return run<192>(batch, iters);
+  if (C == 384) return run<384>(batch, iters);
+  fprintf(stderr, "C must be 96, 192 or 384\n");
+  return 2;
+}
