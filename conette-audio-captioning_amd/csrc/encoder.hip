@@ -729,6 +729,7 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
         }
       }
       if (taps && b == 0) CN_TRY(tap_copy(taps->stage_block0[st], ws.x, (size_t)P * C, s));
+      if (taps) CN_TRY(tap_copy(taps->block[blk], ws.x, (size_t)P * C, s));
     }
     if (taps) CN_TRY(tap_copy(taps->stage[st], ws.x, (size_t)P * C, s));
   }

@@ -43,7 +43,7 @@ class ConetteConfigC(C.Structure):
 
 class EncodeTapsC(C.Structure):
     _fields_ = [("logmel", C.c_void_p), ("stem", C.c_void_p), ("stage_block0", C.c_void_p * 4),
-                ("stage", C.c_void_p * 4), ("down", C.c_void_p * 4)]
+                ("stage", C.c_void_p * 4), ("down", C.c_void_p * 4), ("block", C.c_void_p * 18)]
 
 
 _lib = None
@@ -224,8 +224,9 @@ class Engine:
         return out
 
     # ---- a2-a7 -----------------------------------------------------------------------------
-    def encode(self, wave: torch.Tensor, taps: bool = False, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
-        """wave (B, L) fp32 on device -> frame_embs (B, T, 768), clip_probs (B, 527) [, taps dict]."""
+    def encode(self, wave: torch.Tensor, taps=False, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        """wave (B, L) fp32 on device -> frame_embs (B, T, 768), clip_probs (B, 527) [, taps dict].
+        ``taps="blocks"`` additionally returns the output of every ConvNeXt block ("block0" .. "block17")."""
         wave = wave.to(self.device, torch.float32).contiguous()
         b, l = wave.shape
         f, hs, ws_ = encoder_geometry(l)
@@ -254,6 +255,13 @@ class Engine:
                 tap_struct.stage_block0[i] = tap_out[f"stage{i}_block0"].data_ptr()
                 tap_struct.stage[i] = tap_out[f"stage{i}"].data_ptr()
                 tap_struct.down[i] = tap_out[f"down{i}"].data_ptr() if i > 0 else 0
+            if taps == "blocks":
+                blk = 0
+                for i, depth in enumerate((3, 3, 9, 3)):
+                    for _ in range(depth):
+                        tap_out[f"block{blk}"] = e(b, hs[i], ws_[i], dims[i])
+                        tap_struct.block[blk] = tap_out[f"block{blk}"].data_ptr()
+                        blk += 1
         st = self.lib.conette_encode(self._ctx, _ptr(wave), b, l, _ptr(frame_embs), _ptr(clip),
                                      C.byref(tap_struct) if tap_struct is not None else None, _ptr(wsb),
                                      wsb.numel(), _stream())

@@ -56,6 +56,7 @@ typedef struct conette_encode_taps {
   float* stage_block0[4]; /* output of the first block of stage i */
   float* stage[4];      /* output of stage i */
   float* down[4];       /* output of downsample_layers[i], i = 1..3 ([0] unused) */
+  float* block[18];     /* output of every ConvNeXt block in network order (stage 0 block 0 .. stage 3 block 2) */
 } conette_encode_taps;
 
 const char* conette_last_error(void);
