@@ -1,15 +1,21 @@
 #!/usr/bin/env python
 """Benchmark of the CoNeTTE hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--global-batch G] [--workload mixed]
 
 One "step" = one pass of the hot path over one batch of synthetic clips already resident in
 HBM: waveform (B, 320000) fp32 -> log-mel -> ConvNeXt -> projection -> KV-cached decoder under
 beam search -> token ids / scores on device (+ the RCCL all-gather of ids for N > 1).
-Workload = BASELINE.json configs[1]/[2] shape: B = 64 clips of 10 s @ 32 kHz per GPU, beam 3,
+Default workload = BASELINE.json configs[1]/[2] shape: B = 64 clips of 10 s @ 32 kHz per GPU, beam 3,
 bf16 operands, seeded synthetic checkpoint (random-init weights of the reference architecture;
-the published checkpoint is not reachable offline).  N > 1: one process per GPU, every rank
-processes its own 64 clips (weak scaling), no data-path collective except the final all-gather.
+the published checkpoint is not reachable offline).
+
+N > 1: one process per GPU.  Started by the driver through torch.distributed.run (RANK / LOCAL_RANK /
+WORLD_SIZE in the environment) or directly as `python bench.py --gpus N`, in which case this process
+starts the N ranks itself (a child `torch.distributed.run`, before anything here touches a GPU) and
+exits with its status.  Default N > 1 mode: weak scaling, every rank processes its own 64 clips, no
+data-path collective except the final all-gather of ids + scores.  `--global-batch G` (BASELINE config 4:
+G = 2048 over 8 GPUs): strong scaling, rank r takes the contiguous shard `shard_bounds(G, r, N)`.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings).
 """
@@ -18,17 +24,12 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import conette_amd  # noqa: E402,F401
-from conette_amd import synth  # noqa: E402
 
 SR = 32000
 CLIP_S = 10
@@ -37,16 +38,56 @@ DEPTHS = (3, 3, 9, 3)
 POS = (252 * 56, 126 * 28, 63 * 14, 31 * 7)  # positions per 10 s clip and stage
 PEAK_BF16_TFLOPS = 2500.0                    # dense MFMA bf16 (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0                        # HBM3E spec (MI355X_MICROARCH.md)
-
-
-# C = 96 / 192 / 384: pw1 + GELU + pw2 run as ONE kernel (mlp_fused.h), timed under "pw1_gemm"
-FUSED_STAGES = (0, 1) if os.environ.get("CN_MLP384") == "0" else (0, 1, 2)
-# kernel-name fragments of each profiling class in the committed PMC table (profiles/*_pmc_hbm_traffic.csv)
+FUSED_STAGES = (0, 1, 2)                     # pw1 + GELU + pw2 run as ONE kernel (mlp_rc2.h), timed under "pw1_gemm"
+# kernel-name fragments of each profiling class in the committed PMC tables (profiles/*_pmc_*.csv)
 PMC_KERNELS = {
-    "pw1_gemm": ("cn_mlp_fused_kernel", "EpiBiasActIDF16bLi4"),
+    "pw1_gemm": ("cn_mlp_rc2_", "EpiBiasActIDF16bLi4"),
     "pw2_gemm": ("EpiResid",),
-    "dwconv_ln": ("cn_dwconv_ln_kernel",),
+    "dwconv_ln": ("cn_dwconv_ln",),
 }
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="clips per GPU (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0, help="total clips, sharded over the GPUs (strong scaling)")
+    ap.add_argument("--beam", type=int, default=3)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--workload", default="fixed", choices=["fixed", "mixed"],
+                    help="fixed: 10 s clips; mixed: lengths U[1 s, 30 s] (seed 1234), length-bucketed batches")
+    ap.add_argument("--cpu-clips", type=int, default=32, help="clips in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--parity-clips", type=int, default=64, help="clips in the bf16-vs-fp32 agreement leg (0 = skip)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: CPU self-test of the launcher / sharding / gather path (no GPU work, no timing)")
+    ap.add_argument("--master-port", type=int, default=0)
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args) -> int:
+    """Start `--gpus N` ranks (one process per GPU) as a child torch.distributed.run and return its exit status.
+    Runs BEFORE this process imports torch.cuda or the HIP library: a process that has initialised the GPU must not
+    start another GPU program in its place, and children inherit nothing from it."""
+    import socket
+    port = args.master_port
+    if port == 0:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def pmc_table(suffix: str):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{suffix}.csv")))
+    return files[-1] if files else None
 
 
 def pmc_traffic(cls: str, batch: int, launches_per_step: float):
@@ -54,13 +95,12 @@ def pmc_traffic(cls: str, batch: int, launches_per_step: float):
     WRITE_SIZE passes of this benchmark at B = 64, bf16; FETCH_SIZE doubled: gfx950 tallies wide streaming reads at
     half their size, MI355X_MICROARCH.md).  None when no table matches the configuration."""
     import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.csv")))
-    if not files or batch != 64:
+    path = pmc_table("pmc_hbm_traffic")
+    if path is None or batch != 64:
         return None, None
     tot = 0.0
     n_disp = {}
-    for r in csv.DictReader(open(files[-1])):
+    for r in csv.DictReader(open(path)):
         keys = list(r.keys())
         name, disp, kb = r[keys[1]], int(r[keys[3]]), float(r[keys[4]])
         if not any(f in name for f in PMC_KERNELS.get(cls, ())):
@@ -71,14 +111,30 @@ def pmc_traffic(cls: str, batch: int, launches_per_step: float):
     if not n_disp:
         return None, None
     passes = max(n_disp.values()) / max(launches_per_step, 1.0)  # profiled batches in the table
-    return tot / passes / launches_per_step, os.path.basename(files[-1])
+    return tot / passes / launches_per_step, os.path.basename(path)
+
+
+def pmc_mfma_busy(cls: str):
+    """MFMA-busy share of the class's kernels from the newest committed profiles/*_pmc_mfma.csv
+    (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), tools/pmc_summary.py); None when absent."""
+    import csv
+    path = pmc_table("pmc_mfma")
+    if path is None:
+        return None, None
+    num = den = 0.0
+    for r in csv.DictReader(open(path)):
+        if any(f in r["kernel"] for f in PMC_KERNELS.get(cls, ())):
+            w = float(r["dispatches"]) * float(r["avg_us"]) if "avg_us" in r and r["avg_us"] else float(r["dispatches"])
+            num += w * float(r["mfma_busy"])
+            den += w
+    return (round(num / den, 4), os.path.basename(path)) if den > 0 else (None, None)
 
 
 def algorithmic_work(cls: str, batch: int):
-    """(flops, bytes) of ALL launches of a kernel class for one batch.
+    """(flops, bytes) of ALL launches of a kernel class for one batch of 10 s clips.
 
-    Classes follow the library's profiling scopes: "pw1_gemm" = the fused MLP launches of stages 0-1
-    (both GEMMs) + the pw1 GEMMs of stages 2-3; "pw2_gemm" = the pw2 GEMMs of stages 2-3."""
+    Classes follow the library's profiling scopes: "pw1_gemm" = the fused MLP launches of stages 0-2
+    (both GEMMs) + the pw1 GEMMs of stage 3; "pw2_gemm" = the pw2 GEMMs of stage 3."""
     fl = by = 0.0
     for st, (c, d, p) in enumerate(zip(DIMS, DEPTHS, POS)):
         n = batch * p
@@ -100,23 +156,72 @@ def algorithmic_work(cls: str, batch: int):
     return fl, by
 
 
+def gloo_selftest(args, rank: int, world: int) -> None:
+    """CPU check of everything around the GPU work in the N > 1 path: rendezvous, shard bounds, the all-gather of ids +
+    scores, trimming, the one JSON line on rank 0 (tests/test_bench_launcher.py)."""
+    import torch
+    import torch.distributed as dist
+    import conette_amd  # noqa: F401
+    from conette_amd.dist import gather_captions, shard_bounds, trim_captions
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total = args.global_batch if args.global_batch > 0 else world * args.batch
+    lo, hi = shard_bounds(total, rank, world) if args.global_batch > 0 else (rank * args.batch, (rank + 1) * args.batch)
+    g = torch.Generator().manual_seed(11)
+    full = torch.randint(4, 100, (total, 20), generator=g, dtype=torch.int32)
+    full[:, 7] = 2
+    full[:, 8:] = 0
+    scores = -torch.arange(total, dtype=torch.float32)
+    p, l = gather_captions(full[lo:hi].clone(), scores[lo:hi].clone(), total)
+    ok = torch.equal(p, full) and torch.equal(l, scores) and trim_captions(p).shape[1] == 8
+    flag = torch.tensor([1 if ok else 0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"metric": "clips_per_sec", "value": None, "unit": "clips/s", "n_gpus": world,
+                          "world_size_observed": dist.get_world_size(), "selftest": "gloo", "ok": bool(flag.item()),
+                          "scaling": "strong" if args.global_batch > 0 else "weak", "global_batch": total,
+                          "shard": [lo, hi]}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(3)
+
+
+def agreement(a, b, eos: int = 2):
+    """(share of identical sequences, share of identical tokens up to and including the longer <eos>) of two (B, P) id matrices."""
+    import torch
+    w = max(a.shape[1], b.shape[1])
+    pa = torch.zeros((a.shape[0], w), dtype=torch.long)
+    pb = torch.zeros((b.shape[0], w), dtype=torch.long)
+    pa[:, : a.shape[1]] = a.cpu().long()
+    pb[:, : b.shape[1]] = b.cpu().long()
+    same_seq = float((pa == pb).all(dim=1).float().mean())
+    live = (pa != 0) | (pb != 0)
+    same_tok = float(((pa == pb) & live).sum() / max(int(live.sum()), 1))
+    return round(same_seq, 4), round(same_tok, 4)
+
+
 def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="clips per GPU")
-    ap.add_argument("--beam", type=int, default=3)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--cpu-clips", type=int, default=32, help="clips in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, default=16)
-    args = ap.parse_args()
+    args = parse_args()
+    in_rank = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not in_rank:
+        raise SystemExit(launch_ranks(args))       # (nothing above has touched a GPU)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         f"(or run `python bench.py --gpus {args.gpus}` and let it start the ranks)")
+    if args.backend == "gloo":
+        return gloo_selftest(args, rank, world)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import conette_amd  # noqa: F401
+    from conette_amd import synth
+
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -124,55 +229,88 @@ def main() -> None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from conette_amd.dist import gather_captions
+    from conette_amd.dist import gather_captions, shard_bounds, trim_captions
     from conette_amd.engine import Engine
 
-    B, beam, min_pred, max_pred = args.batch, args.beam, 3, 20
-    L = CLIP_S * SR
+    beam, min_pred, max_pred = args.beam, 3, 20
+    strong = args.global_batch > 0
+    if strong:
+        lo, hi = shard_bounds(args.global_batch, rank, world)
+        B, total_clips, clip0 = hi - lo, args.global_batch, lo
+    else:
+        B, total_clips, clip0 = args.batch, world * args.batch, rank * args.batch
+    if B <= 0:
+        raise SystemExit(f"rank {rank}: empty shard of --global-batch {args.global_batch}")
     sd_np = synth.synth_state_dict()
     sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()}
     eng = Engine(sd, precision=args.precision, device=dev)
     if os.environ.get("CN_NO_GRAPH"):
         eng.set_decode_graph(False)
     eng.set_encode_reserved_cus(int(os.environ.get("CN_ENC_RESERVE", "48")))
-    wave = torch.from_numpy(synth.synth_waveforms(B, L, 1234 + rank * B)).to(dev)
-    t_audio = eng.lib.conette_num_audio_frames(L)
-    lens = torch.full((B,), t_audio, dtype=torch.int32, device=dev)
-    bos = sd["model.task_id_to_token_id"][torch.zeros(B, dtype=torch.long)].to(dev)  # task "clotho"
+    bos_all = sd["model.task_id_to_token_id"]
     forbid = sd["model.forbid_rep_mask"].to(dev)
-    # Two pipeline slots and two HIP streams: the decode of batch i (small latency-bound launches,
-    # replayed from a hipGraph) overlaps the encode of batch i+1 (big MFMA / VALU kernels).
-    share = int(os.environ.get("CN_DEC_SHARE", "0"))  # CU-masked streams measured no gain on this stack
-    if share > 0:   # CU-partitioned streams: decode owns 1/share of the CUs, encode the rest
-        from conette_amd.engine import make_partitioned_streams
-        s_enc, s_dec = make_partitioned_streams(dev, decode_share=share)
+
+    if args.workload == "mixed":
+        from conette_amd.bucketing import plan_buckets
+        rng = np.random.default_rng(1234 + clip0)
+        lengths = rng.integers(1 * SR, 30 * SR + 1, size=B)
+        buckets = plan_buckets(lengths.tolist(), max_padded_seconds=float(os.environ.get("CN_BUCKET_SECONDS", "640")), sr=SR)
+        batches = []
+        for idx in buckets:
+            ls = [int(lengths[i]) for i in idx]
+            w_ = torch.from_numpy(synth.synth_waveforms(len(idx), max(ls), 1234 + clip0 + idx[0], lengths=ls)).to(dev)
+            t_ = eng.lib.conette_num_audio_frames(max(ls))
+            lens_ = torch.tensor(ls, dtype=torch.float32).div(max(ls) // t_).round().to(torch.int32).to(dev)  # convnext.py:312-315
+            batches.append((w_, lens_, t_))
+        audio_seconds = float(lengths.sum()) / SR
     else:
-        prio = int(os.environ.get("CN_DEC_PRIO", "-1"))  # decode stream priority (negative = higher)
-        s_enc, s_dec = torch.cuda.Stream(dev), torch.cuda.Stream(dev, priority=prio)
-    fe_buf = [eng.decode_input_buffer(B, t_audio, beam, max_pred, slot=i) for i in range(2)]
-    clip_buf = [torch.empty((B, 527), dtype=torch.float32, device=dev) for _ in range(2)]
-    enc_done = [torch.cuda.Event() for _ in range(2)]
-    dec_done = [torch.cuda.Event() for _ in range(2)]
+        L = CLIP_S * SR
+        wave = torch.from_numpy(synth.synth_waveforms(B, L, 1234 + clip0)).to(dev)
+        t_audio = eng.lib.conette_num_audio_frames(L)
+        batches = [(wave, torch.full((B,), t_audio, dtype=torch.int32, device=dev), t_audio)]
+        audio_seconds = float(B * CLIP_S)
+
+    # Two pipeline slots and two HIP streams: the decode of batch i (small latency-bound launches, replayed from a
+    # hipGraph) overlaps the encode of batch i+1 (big MFMA / VALU kernels; their persistent kernels leave
+    # CN_ENC_RESERVE compute units to the decode stream).
+    prio = int(os.environ.get("CN_DEC_PRIO", "-1"))  # decode stream priority (negative = higher)
+    s_enc, s_dec = torch.cuda.Stream(dev), torch.cuda.Stream(dev, priority=prio)
+    n_slot = 2
+    slots = []
+    for k, (w_, lens_, t_) in enumerate(batches):
+        for sl in range(n_slot):
+            slots.append(dict(
+                fe=eng.decode_input_buffer(w_.shape[0], t_, beam, max_pred, slot=2 * k + sl),
+                clip=torch.empty((w_.shape[0], 527), dtype=torch.float32, device=dev),
+                enc_done=torch.cuda.Event(), dec_done=torch.cuda.Event()))
     state = {"i": 0, "last": None}
+    bos_dev = [bos_all[torch.zeros(w_.shape[0], dtype=torch.long)].to(dev) for w_, _, _ in batches]  # task "clotho"
 
     def step():
+        """one pass over this rank's clips: every (length-bucketed) batch once"""
         i = state["i"]
-        sl = i & 1
-        with torch.cuda.stream(s_enc):
-            if i >= 2:
-                s_enc.wait_event(dec_done[sl])          # slot's frame buffer is free again
-            eng.encode(wave, out=(fe_buf[sl], clip_buf[sl]))
-            enc_done[sl].record(s_enc)
+        res = []
+        for k, (w_, lens_, t_) in enumerate(batches):
+            sl = slots[n_slot * k + (i & 1)]
+            bos = bos_dev[k]
+            with torch.cuda.stream(s_enc):
+                if i >= 2:
+                    s_enc.wait_event(sl["dec_done"])          # slot's frame buffer is free again
+                eng.encode(w_, out=(sl["fe"], sl["clip"]))
+                sl["enc_done"].record(s_enc)
+            with torch.cuda.stream(s_dec):
+                s_dec.wait_event(sl["enc_done"])
+                out = eng.decode(sl["fe"], lens_, bos, forbid, beam, min_pred, max_pred, clone=False, slot=n_slot * k + (i & 1))
+                res.append((out["best_preds"], out["best_lprobs"]))
+                sl["dec_done"].record(s_dec)
         with torch.cuda.stream(s_dec):
-            s_dec.wait_event(enc_done[sl])
-            out = eng.decode(fe_buf[sl], lens, bos, forbid, beam, min_pred, max_pred, clone=False, slot=sl)
-            res = (out["best_preds"], out["best_lprobs"])
+            preds = res[0][0] if len(res) == 1 else torch.cat([r[0] for r in res])
+            lps = res[0][1] if len(res) == 1 else torch.cat([r[1] for r in res])
             if world > 1:
-                res = gather_captions(res[0], res[1], world * B)
-            dec_done[sl].record(s_dec)
+                preds, lps = gather_captions(preds, lps, total_clips)
         state["i"] = i + 1
         state["last"] = out
-        return res
+        return preds, lps
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -180,18 +318,22 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(max(args.warmup, 6)):  # >= 3 per slot: the third identical decode call replays its hipGraph
+    warm_used = max(args.warmup, 6)  # >= 3 per slot: the third identical decode call replays its hipGraph
+    for _ in range(warm_used):
         step()
     fence()
 
     # ---- pre-pass (untimed): which kernel class dominates, encode / decode split --------------------
+    w0, lens0, t0_ = batches[0]
+    B0 = w0.shape[0]
+    bos0 = bos_dev[0]
     enc_classes = ("frontend", "stem", "dwconv_ln", "pw1_gemm", "pw2_gemm", "downsample", "heads")
     eng.profile_enable(enc_classes)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     ev[0].record()
-    eng.encode(wave, out=(fe_buf[0], clip_buf[0]))
+    eng.encode(w0, out=(slots[0]["fe"], slots[0]["clip"]))
     ev[1].record()
-    out = eng.decode(fe_buf[0], lens, bos, forbid, beam, min_pred, max_pred, clone=False, slot=0)
+    out = eng.decode(slots[0]["fe"], lens0, bos0, forbid, beam, min_pred, max_pred, clone=False, slot=0)
     ev[2].record()
     torch.cuda.synchronize(dev)
     pre = eng.profile_read()
@@ -199,8 +341,10 @@ def main() -> None:
     encode_ms, decode_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
     stage_ms = {k: round(v[0], 4) for k, v in pre.items()}
     dominant = max(("pw1_gemm", "pw2_gemm", "dwconv_ln"), key=lambda k: pre.get(k, (0.0, 0))[0])
-    mult = out["mult_preds"]
-    gen_tokens = int((mult != 0).sum().item())  # generated row-steps of this batch (EOS included, pad excluded)
+    bm = int(out["sizes"][1].item())
+    best = out["best_preds"][:, :bm]
+    best_tokens = int((best != 0).sum().item())            # tokens of the returned captions (<eos> included)
+    beam_tokens = int((out["mult_preds"] != 0).sum().item())  # row-steps of every hypothesis of the search
 
     # ---- timed region: exactly K steps, events only around the dominant class --------------------------
     eng.profile_enable((dominant,))
@@ -217,44 +361,102 @@ def main() -> None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        tot_audio = torch.tensor([audio_seconds], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot_audio)
+        audio_seconds_all = float(tot_audio.item())
+    else:
+        audio_seconds_all = audio_seconds
 
     dom_ms, dom_n = prof[dominant]
-    fl, by = algorithmic_work(dominant, B)
     launches_per_step = dom_n / args.steps
     avg_launch_s = dom_ms * 1e-3 / dom_n
-    if dominant in ("pw1_gemm", "pw2_gemm"):
-        achieved = fl / launches_per_step / avg_launch_s / 1e12
-        roof = {"bound": "mfma", "kernel": dominant, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None}
-    else:
-        achieved = by / launches_per_step / avg_launch_s / 1e9
-        roof = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
-                "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None}
-    roof["avg_launch_us"] = round(avg_launch_s * 1e6, 2)
-    roof["launches_per_step"] = launches_per_step
-    if args.precision == "bf16":
-        tr, src = pmc_traffic(dominant, B, launches_per_step)
-        if tr is not None:
-            roof["traffic"] = round(tr)            # HBM bytes per launch (class average), PMC
-            roof["traffic_unit"] = "bytes/launch"
-            roof["traffic_source"] = "profiles/" + src
-            roof["algorithmic_bytes_per_launch"] = round(by / launches_per_step)
+    roof = {"kernel": dominant, "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches_per_step": launches_per_step,
+            "traffic": None}
+    if args.workload == "fixed":
+        fl, by = algorithmic_work(dominant, B)
+        if dominant in ("pw1_gemm", "pw2_gemm"):
+            achieved = fl / launches_per_step / avg_launch_s / 1e12
+            roof.update({"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4)})
+        else:
+            achieved = by / launches_per_step / avg_launch_s / 1e9
+            roof.update({"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": round(achieved / PEAK_HBM_GBS, 4)})
+        if args.precision == "bf16":
+            tr, src = pmc_traffic(dominant, B, launches_per_step)
+            if tr is not None:
+                roof["traffic"] = round(tr)            # HBM bytes per launch (class average), PMC
+                roof["traffic_unit"] = "bytes/launch"
+                roof["traffic_source"] = "profiles/" + src
+                roof["algorithmic_bytes_per_launch"] = round(by / launches_per_step)
+            mb, src = pmc_mfma_busy(dominant)
+            if mb is not None:
+                roof["mfma_busy"] = mb                 # share of SIMD cycles with the matrix pipe busy, PMC
+                roof["mfma_busy_source"] = "profiles/" + src
 
     result = None
     if rank == 0:
-        clips_per_s = world * B * args.steps / dt
+        clips_per_s = total_clips * args.steps / dt
+        if args.workload == "mixed":
+            wl = (f"{total_clips} clips of U[1 s, 30 s] @ 32 kHz (seed 1234), {len(batches)} length buckets per rank, "
+                  f"ConvNeXt encoder + beam-{beam} KV-cached decode")
+        else:
+            wl = (f"B={B}/GPU x 10 s @ 32 kHz clips, ConvNeXt encoder + beam-{beam} KV-cached decode "
+                  f"(min 3 / max 20 tokens, V=5631), synthetic seeded checkpoint")
         result = {
             "metric": "clips_per_sec", "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "steps": args.steps, "warmup": args.warmup, "warmup_run": warm_used, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "timed_region_s": round(dt, 4),
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": f"B={B}/GPU x 10 s @ 32 kHz clips, ConvNeXt encoder + beam-{beam} KV-cached decode "
-                                   f"(min 3 / max 20 tokens, V=5631), synthetic seeded checkpoint",
-                       "batch_per_gpu": B, "global_batch": world * B, "beam_size": beam, "parallelism": f"dp{world}"},
-            "decode_tokens_per_sec": round(world * gen_tokens / (decode_ms * 1e-3), 1),
+            "config": {"workload": wl, "batch_per_gpu": B, "global_batch": total_clips, "beam_size": beam,
+                       "parallelism": f"dp{world}", "world_size_observed": world},
+            "audio_seconds_per_sec": round(audio_seconds_all * args.steps / dt, 1),
+            "decode_tokens_per_sec": round(world * best_tokens / (decode_ms * 1e-3), 1),
+            "decode_beam_row_steps_per_sec": round(world * beam_tokens / (decode_ms * 1e-3), 1),
             "encode_ms": round(encode_ms, 3), "decode_ms": round(decode_ms, 3), "stage_ms": stage_ms,
             "roofline": roof,
         }
+
+    # ---- bf16 vs fp32 agreement + what exactness costs (rank 0, N = 1, untimed) ----------------------------
+    if rank == 0 and world == 1 and args.parity_clips > 0 and args.precision == "bf16" and args.workload == "fixed":
+        n = min(args.parity_clips, B0)
+        eng32 = Engine(sd, precision="fp32", device=dev)
+        wv, ln, bs = w0[:n].contiguous(), lens0[:n].contiguous(), bos0[:n].contiguous()
+        par = {}
+        outs = {}
+        for name, e in (("bf16", eng), ("fp32", eng32)):
+            fe_, _ = e.encode(wv)
+            for bm_ in (1, 3):
+                o = e.decode(fe_, ln, bs, forbid, bm_, min_pred, max_pred)
+                outs[(name, bm_)] = (o["best_preds"][:, : int(o["sizes"][1].item())].cpu(), o["best_lprobs"].cpu())
+        seq, tok = agreement(outs[("bf16", 1)][0], outs[("fp32", 1)][0])
+        par["greedy_seq_identical"], par["greedy_token_agree"] = seq, tok
+        seq3, tok3 = agreement(outs[("bf16", 3)][0], outs[("fp32", 3)][0])
+        par["beam3_best_identical"], par["beam3_token_agree"] = seq3, tok3
+        same = (outs[("bf16", 3)][0].shape == outs[("fp32", 3)][0].shape)
+        d = (outs[("bf16", 3)][1] - outs[("fp32", 3)][1]).abs()
+        par["max_abs_lprob_diff"] = round(float(d.max()), 4)
+        par["mean_abs_lprob_diff"] = round(float(d.mean()), 4)
+        par["clips"] = n
+        par["note"] = ("bf16 (the timed mode) vs the fp32 mode of the same library, whose ids equal the reference's on every golden "
+                       "fixture (tests/test_gpu_parity.py); the synthetic checkpoint's top candidates are often within 0.1")
+        # fp32-mode throughput of the same pipeline (what bit-exact ids cost)
+        fe_b = [eng32.decode_input_buffer(n, t0_, beam, max_pred, slot=i) for i in range(2)]
+        cl_b = [torch.empty((n, 527), dtype=torch.float32, device=dev) for _ in range(2)]
+        for i in range(3):
+            eng32.encode(wv, out=(fe_b[i & 1], cl_b[i & 1]))
+            eng32.decode(fe_b[i & 1], ln, bs, forbid, beam, min_pred, max_pred, clone=False, slot=i & 1)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        k32 = 4
+        for i in range(k32):
+            eng32.encode(wv, out=(fe_b[i & 1], cl_b[i & 1]))
+            eng32.decode(fe_b[i & 1], ln, bs, forbid, beam, min_pred, max_pred, clone=False, slot=i & 1)
+        torch.cuda.synchronize(dev)
+        result["parity"] = par
+        result["fp32_clips_per_sec"] = round(n * k32 / (time.perf_counter() - t1), 1)
+        del eng32
 
     # ---- CPU baseline (rank 0, N = 1 only): the oracle restatement on host cores ------------------------
     if rank == 0 and world == 1 and args.cpu_clips > 0:
@@ -263,14 +465,15 @@ def main() -> None:
         n_thr = max(1, min(args.cpu_threads, len(os.sched_getaffinity(0))))
         torch.set_num_threads(n_thr)
         cfg = synth.synth_config_dict()
-        xs = wave[: args.cpu_clips].cpu()[:, None, :]
+        nc = min(args.cpu_clips, B0)
+        xs = w0[:nc].cpu()[:, None, :]
         with torch.no_grad():
             tc = time.perf_counter()
             O.model_forward(sd, cfg, xs, sr=SR, task="clotho", beam_size=beam)
             tc = time.perf_counter() - tc
         result["cpu_baseline"] = {
-            "value": round(args.cpu_clips / tc, 4), "unit": "clips/s", "cores": n_thr, "kind": "port",
-            "sample": f"{args.cpu_clips} of the same synthetic clips, same checkpoint, beam {beam}: oracle/cpu_ref.py "
+            "value": round(nc / tc, 4), "unit": "clips/s", "cores": n_thr, "kind": "port",
+            "sample": f"{nc} of the same synthetic clips, same checkpoint, beam {beam}: oracle/cpu_ref.py "
                       f"(stock PyTorch fp32, reference algorithm incl. its no-KV-cache decode), {tc:.1f} s"}
     if rank == 0:
         print(json.dumps(result), flush=True)

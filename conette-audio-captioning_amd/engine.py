@@ -291,7 +291,7 @@ class Engine:
                 "trace_sel": e((max_pred, b, beam, 2), torch.int32) if trace else None,
                 "trace_val": e((max_pred, b, beam), torch.float32) if trace else None,
             }
-            if len(self._dec_bufs) >= 8:
+            if len(self._dec_bufs) >= 64:
                 self._dec_bufs.pop(next(iter(self._dec_bufs)))
             self._dec_bufs[key] = buf
         return buf

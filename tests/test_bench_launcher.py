@@ -1,0 +1,56 @@
+"""CPU: `python bench.py --gpus 2` from a plain shell starts its own ranks (the path the driver's scaling run takes when it
+does not wrap the command in torch.distributed.run), here on the gloo self-test leg: rendezvous on 127.0.0.1, shard
+bounds, the all-gather of ids + scores, one JSON line from rank 0 with the world size it observed."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo"] + extra, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_self_launch_two_ranks_weak():
+    d = _run(["--gpus", "2", "--batch", "5"])
+    assert d["n_gpus"] == 2 and d["world_size_observed"] == 2 and d["ok"] and d["scaling"] == "weak"
+    assert d["global_batch"] == 10 and d["shard"] == [0, 5]
+
+
+def test_self_launch_two_ranks_strong_ragged():
+    d = _run(["--gpus", "2", "--global-batch", "7"])
+    assert d["n_gpus"] == 2 and d["ok"] and d["scaling"] == "strong" and d["global_batch"] == 7 and d["shard"] == [0, 4]
+
+
+def test_wrong_world_size_is_refused():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--gpus", "2"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_bucket_plan():
+    sys.path.insert(0, ROOT)
+    import conette_amd  # noqa: F401
+    from conette_amd.bucketing import padding_waste, plan_buckets
+    import random
+    rng = random.Random(0)
+    lengths = [rng.randint(32000, 960000) for _ in range(200)]
+    buckets = plan_buckets(lengths, max_padded_seconds=640.0)
+    flat = sorted(i for b in buckets for i in b)
+    assert flat == list(range(200))                                   # a partition
+    for b in buckets:
+        assert len(b) * max(lengths[i] for i in b) <= 640 * 32000 or len(b) == 1
+    firsts = [max(lengths[i] for i in b) for b in buckets]
+    assert firsts == sorted(firsts)                                   # shortest clips first
+    assert padding_waste(lengths, buckets) < 0.15                     # one pad-to-max batch of these clips wastes ~50 %
+    assert padding_waste(lengths, [list(range(200))]) > 0.4
+    assert plan_buckets([5], 1.0) == [[0]] and plan_buckets([], 1.0) == []
