@@ -37,7 +37,9 @@ def get_offline_transform(model):
     ``get_resample_mean_convnext`` (transforms/get.py:240-310):
     ``f(waveform (C, T), sr) -> {"audio": (T', 768), "audio_shape": (2,), "clip_probs": (527,)}``,
     the columns the training HDF files store and ``model(..., preprocess=False)`` consumes."""
+    import importlib
+    offline = importlib.import_module(__name__ + ".offline")
+
     def transform(waveform, sr=32000):
-        batch = model.preprocessor(waveform, sr, None)
-        return {"audio": batch["audio"][0], "audio_shape": batch["audio_shape"][0], "clip_probs": batch["clip_probs"][0]}
+        return offline.transform_one(model, waveform, sr)
     return transform

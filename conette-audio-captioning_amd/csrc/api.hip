@@ -256,6 +256,32 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
     float* win = (float*)B.alloc(CN_N_FFT * 4);
     if (cr) hipMemcpy(win, cr, CN_N_FFT * 4, hipMemcpyDeviceToDevice);  // row k = 0: cos(0) * window
     ctx->window = win;
+    // The frontend replaces the checkpoint's DFT-as-conv1d tensors by an FFT with the window taken from row 0.  That is
+    // only the same transform if the tensors ARE the windowed DFT (torchlibrosa.stft.STFT: W[k][n] = win[n] e^{-2 pi i k n / N}):
+    // spot-check rows of both tensors against the closed form and refuse anything else instead of silently diverging.
+    const float* ci = B.find(E + "spectrogram_extractor.stft.conv_imag.weight", (int64_t)CN_N_BINS * CN_N_FFT);
+    if (cr && ci && B.err == CN_OK) {
+      const int rows[5] = {1, 7, 100, 333, 512};
+      std::vector<float> hw(CN_N_FFT), hr(CN_N_FFT), hi(CN_N_FFT);
+      hipMemcpy(hw.data(), cr, CN_N_FFT * 4, hipMemcpyDeviceToHost);
+      float wmax = 0.f;
+      for (float v : hw) wmax = fmaxf(wmax, fabsf(v));
+      double worst = 0.0;
+      for (int k : rows) {
+        hipMemcpy(hr.data(), cr + (size_t)k * CN_N_FFT, CN_N_FFT * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(hi.data(), ci + (size_t)k * CN_N_FFT, CN_N_FFT * 4, hipMemcpyDeviceToHost);
+        for (int n = 0; n < CN_N_FFT; n += 13) {
+          const double a = -2.0 * M_PI * (double)((long)k * n % CN_N_FFT) / CN_N_FFT;
+          worst = fmax(worst, fabs(hr[n] - hw[n] * cos(a)));
+          worst = fmax(worst, fabs(hi[n] - hw[n] * sin(a)));
+        }
+      }
+      if (!(wmax > 0.f) || worst > 1e-4 * wmax) {
+        cn_set_error("create: spectrogram_extractor.stft.conv_real / conv_imag are not a windowed DFT (max deviation %.3g of "
+                     "window peak %.3g): the FFT frontend cannot reproduce this checkpoint", worst, (double)wmax);
+        B.err = CN_ERR_WEIGHT;
+      }
+    }
     std::vector<float2> t512(512), t1024(513);
     for (int j = 0; j < 512; ++j) {
       const double a = -2.0 * M_PI * j / 512.0;
@@ -540,7 +566,7 @@ struct ResampleTable {
   int o, n, width, K;
   float* dev;
 };
-static std::unordered_map<long, ResampleTable> g_resample;
+static std::unordered_map<long, ResampleTable> g_resample;  // per (device, orig_sr, new_sr): the table lives in device memory
 
 extern "C" int conette_resample(const float* in, int32_t rows, int32_t n_in, int32_t orig_sr, int32_t new_sr,
                                 float* out, void* stream) {
@@ -548,7 +574,9 @@ extern "C" int conette_resample(const float* in, int32_t rows, int32_t n_in, int
     cn_set_error("resample: bad argument");
     return CN_ERR_ARG;
   }
-  const long key = (long)orig_sr * 1000003L + new_sr;
+  int dev_id = 0;
+  CN_HIP(hipGetDevice(&dev_id));
+  const long key = ((long)orig_sr * 1000003L + new_sr) * 64 + dev_id;
   auto it = g_resample.find(key);
   if (it == g_resample.end()) {
     // kernel table in fp32 arithmetic, as torchaudio 0.13.1 builds it in the waveform dtype

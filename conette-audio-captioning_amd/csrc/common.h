@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
+#include <set>
+#include <utility>
 
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -42,6 +45,20 @@ void cn_set_error(const char* fmt, ...);
     int _s = (expr);                 \
     if (_s != CN_OK) return _s;      \
   } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: remembered per (device, kernel), so a second
+// context on another GPU of the same process configures its own device (was a process-wide flag: ADVICE r01)
+static inline int cn_configure_lds(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  CN_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count(std::make_pair(dev, fn))) return CN_OK;
+  CN_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.insert(std::make_pair(dev, fn));
+  return CN_OK;
+}
 
 static inline size_t cn_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 static inline int cn_cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -66,6 +66,7 @@ struct CnRuntime;  // C++ side state: profiling events, decode graphs (api.hip)
 struct conette_ctx {
   conette_config cfg;
   CnRuntime* rt;
+  void* dec_graphs;  // DecGraphCache of decoder.hip (hipGraph replay of conette_decode), owned by the context
   uint32_t prof_mask;
   int dec_unfused;  // CONETTE_OPT_DECODE_FUSION = 0: one launch per sub-layer (the cross-check path of the tests)
   int esize;  // operand element size (2 or 4)

@@ -473,12 +473,4 @@ __global__ __launch_bounds__(512, 1) void cn_dec_block_kernel(
   if (dbg && lane == 0 && rw == 0) atomicAdd(&g_db_prof[9], 1ull);
 }
 
-static inline int cn_dec_block_setup() {
-  static bool done = false;
-  if (!done) {
-    CN_HIP(hipFuncSetAttribute((const void*)cn_dec_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               DB_LDS_BYTES));
-    done = true;
-  }
-  return CN_OK;
-}
+static inline int cn_dec_block_setup() { return cn_configure_lds((const void*)cn_dec_block_kernel, DB_LDS_BYTES); }

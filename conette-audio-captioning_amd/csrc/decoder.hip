@@ -21,10 +21,7 @@
 #define CN_MAX_BEAM 8
 #define CN_MAX_PRED 64
 #define FF2_SPLITS 8
-static int ff2_splits_env() {
-  const char* e = getenv("CN_FF2_SPLITS");
-  return e ? atoi(e) : 4;
-}
+static int ff2_splits_default() { return 4; }  // split-K slabs of the unfused FFN2 GEMM at small R
 
 // ---------------------------------------------------------------------------------------------
 template <typename T>
@@ -389,164 +386,6 @@ __global__ __launch_bounds__(256) void cn_search_step_kernel(float* __restrict__
     const int parent = flat / V, token = flat % V;
     const int np = s_newpos[c];
     if (np < 0) {  // finished: write to the slot of this row position
-      const int sl = rb + s_slot[c];
-      for (int j = tid; j <= step; j += 256) out_preds[(size_t)sl * maxp + j] = (j == step) ? token : s_prefix[parent][j + 1];
-      if (tid == 0) {
-        out_avg[sl] = s_selv[c] / (float)(step + 1);
-        out_len[sl] = step + 1;
-      }
-    } else {
-      const int dst = rb + np;
-      for (int j = tid; j <= step + 1; j += 256) prefix[(size_t)dst * (maxp + 1) + j] = (j == step + 1) ? token : s_prefix[parent][j];
-      for (int j = tid; j <= step; j += 256) anc[(size_t)dst * maxp + j] = (j == step) ? parent : s_anc[parent][j];
-      if (tid == 0) {
-        sum_lp[dst] = s_selv[c];
-        slot[dst] = s_slot[c];
-        cur_tok[dst] = token;
-      }
-    }
-  }
-}
-
-// Same step, fast path: the clip's (masked) logit rows live in LDS for all passes, every thread keeps
-// a sorted top-k of its strided candidates in registers (one scan), and k rounds of block arg-max over
-// the thread heads merge them.  Ties resolve to the lowest flat index exactly like the kernel above.
-__global__ __launch_bounds__(256) void cn_search_step2_kernel(const float* __restrict__ logits, int ldv, int V,
-                                                              int beam, int maxp, int step, int min_pred, int eos_id,
-                                                              const uint8_t* __restrict__ forbid, int* n_active,
-                                                              int* slot, float* sum_lp, int* prefix, int* anc,
-                                                              int* cur_tok, int* out_preds, float* out_avg,
-                                                              int* out_len, int* trace_sel, float* trace_val) {
-  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
-  float* s_lgt = (float*)smem_dyn;  // [nrows][V]
-  __shared__ float s_red[8];
-  __shared__ ValIdx s_vi[4];
-  __shared__ float s_mx[CN_MAX_BEAM], s_lg[CN_MAX_BEAM], s_base[CN_MAX_BEAM];
-  __shared__ float s_selv[CN_MAX_BEAM];
-  __shared__ int s_self[CN_MAX_BEAM];
-  __shared__ int s_prefix[CN_MAX_BEAM][CN_MAX_PRED + 1];
-  __shared__ int s_anc[CN_MAX_BEAM][CN_MAX_PRED];
-  __shared__ int s_slot[CN_MAX_BEAM];
-  __shared__ int s_newpos[CN_MAX_BEAM];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int k = n_active[b];
-  if (k == 0) return;
-  const int rb = b * beam;
-  const int nrows = step == 0 ? 1 : k;
-
-  for (int i = tid; i < k * (maxp + 1); i += 256) s_prefix[i / (maxp + 1)][i % (maxp + 1)] = prefix[(size_t)rb * (maxp + 1) + i];
-  for (int i = tid; i < k * maxp; i += 256) s_anc[i / maxp][i % maxp] = anc[(size_t)rb * maxp + i];
-  if (tid < k) {
-    s_slot[tid] = slot[rb + tid];
-    s_base[tid] = step == 0 ? 0.f : sum_lp[rb + tid];
-  }
-  for (int p = 0; p < nrows; ++p) {
-    const float* lg = logits + (size_t)(rb + p) * ldv;
-    for (int v = tid; v < V; v += 256) s_lgt[p * V + v] = lg[v];
-  }
-  __syncthreads();
-  // EOS floor (beam.py:129-130) + forbid-repeat (beam.py:146-156) on the LDS copy
-  for (int i = tid; i < nrows * (step + 2); i += 256) {
-    const int p = i / (step + 2), j = i % (step + 2);
-    if (j == step + 1) {
-      if (step < min_pred) s_lgt[p * V + eos_id] = -INFINITY;
-    } else if (forbid != nullptr) {
-      const int tok = s_prefix[p][j];
-      if (forbid[tok]) s_lgt[p * V + tok] = -INFINITY;
-    }
-  }
-  __syncthreads();
-  for (int p = 0; p < nrows; ++p) {
-    const float* lg = s_lgt + p * V;
-    float mx = -INFINITY;
-    for (int v = tid; v < V; v += 256) mx = fmaxf(mx, lg[v]);
-    mx = cn_wave_max(mx);
-    if (lane == 0) s_red[wv] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-    float sm = 0.f;
-    for (int v = tid; v < V; v += 256) sm += expf(lg[v] - mx);
-    sm = cn_wave_sum(sm);
-    if (lane == 0) s_red[4 + wv] = sm;
-    __syncthreads();
-    if (tid == 0) {
-      s_mx[p] = mx;
-      s_lg[p] = logf(s_red[4] + s_red[5] + s_red[6] + s_red[7]);
-    }
-    __syncthreads();
-  }
-  // per-thread sorted top-k (strict > keeps the earlier = lower flat index first on ties)
-  float bv[CN_MAX_BEAM];
-  int bi[CN_MAX_BEAM];
-#pragma unroll
-  for (int j = 0; j < CN_MAX_BEAM; ++j) {
-    bv[j] = -INFINITY;
-    bi[j] = 0x7fffffff;
-  }
-  for (int p = 0; p < nrows; ++p) {
-    const float* lg = s_lgt + p * V;
-    const float mx = s_mx[p], lgs = s_lg[p], base = s_base[p];
-    for (int v = tid; v < V; v += 256) {
-      float cand = (lg[v] - mx) - lgs;
-      if (step != 0) cand = base + cand;
-      if (cand > bv[CN_MAX_BEAM - 1]) {
-        bv[CN_MAX_BEAM - 1] = cand;
-        bi[CN_MAX_BEAM - 1] = p * V + v;
-#pragma unroll
-        for (int j = CN_MAX_BEAM - 1; j > 0; --j) {
-          if (bv[j] > bv[j - 1]) {
-            const float tv = bv[j];
-            bv[j] = bv[j - 1];
-            bv[j - 1] = tv;
-            const int ti = bi[j];
-            bi[j] = bi[j - 1];
-            bi[j - 1] = ti;
-          }
-        }
-      }
-    }
-  }
-  int head = 0;
-  for (int c = 0; c < k; ++c) {
-    ValIdx mine{-INFINITY, 0x7fffffff};
-#pragma unroll
-    for (int j = 0; j < CN_MAX_BEAM; ++j)
-      if (head == j) mine = ValIdx{bv[j], bi[j]};
-    ValIdx best = vi_wave(mine);
-    if (lane == 0) s_vi[wv] = best;
-    __syncthreads();
-    const ValIdx win = vi_better(vi_better(s_vi[0], s_vi[1]), vi_better(s_vi[2], s_vi[3]));
-    if (mine.i == win.i && mine.i != 0x7fffffff) ++head;
-    if (tid == 0) {
-      s_selv[c] = win.v;
-      s_self[c] = win.i;
-    }
-    __syncthreads();
-  }
-  // bookkeeping (beam.py:164-203)
-  if (tid < k) {
-    const size_t ti = ((size_t)step * gridDim.x + b) * beam + tid;
-    if (trace_sel) {
-      trace_sel[2 * ti] = s_self[tid] / V;
-      trace_sel[2 * ti + 1] = s_self[tid] % V;
-    }
-    if (trace_val) trace_val[ti] = s_selv[tid];
-  }
-  if (tid == 0) {
-    int cnt = 0;
-    for (int c = 0; c < k; ++c) {
-      const int token = s_self[c] % V;
-      const bool fin = (token == eos_id) || (step == maxp - 1);
-      s_newpos[c] = fin ? -1 : cnt++;
-    }
-    n_active[b] = cnt;
-  }
-  __syncthreads();
-  for (int c = 0; c < k; ++c) {
-    const int flat = s_self[c];
-    const int parent = flat / V, token = flat % V;
-    const int np = s_newpos[c];
-    if (np < 0) {
       const int sl = rb + s_slot[c];
       for (int j = tid; j <= step; j += 256) out_preds[(size_t)sl * maxp + j] = (j == step) ? token : s_prefix[parent][j + 1];
       if (tid == 0) {
@@ -1005,104 +844,27 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
       hipLaunchKernelGGL(cn_force_tok_kernel, dim3(cn_cdiv(B, 64)), dim3(64), 0, s, force_caps, B, maxp, step, w.cur_tok);
       CN_LAUNCH_CHECK();
     }
-    static const int dec_fused = getenv("CN_DEC_FUSED") ? atoi(getenv("CN_DEC_FUSED")) : 0;
-    static const int dec_block = getenv("CN_DEC_BLOCK") ? atoi(getenv("CN_DEC_BLOCK")) : 1;
-    const bool block_path = std::is_same<T, bf16_t>::value && !dec_fused && dec_block && !ctx->dec_unfused;
+    const bool block_path = std::is_same<T, bf16_t>::value && !ctx->dec_unfused;
     if (!block_path) {  // (the block path embeds in the prologue of layer 0's block kernel)
       hipLaunchKernelGGL((cn_embed_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.cur_tok, ctx->emb, ctx->pe, step, R,
                          sqrtf((float)d), w.x, xt);
       CN_LAUNCH_CHECK();
     }
-    // LN-prologue GEMMs (cn_gemm2_ln256) measured SLOWER than LN kernel + plain GEMM (decode 9.1 vs 8.2 ms at
-    // R = 192: the prologue serialises load -> reduce -> LDS write in front of the MFMAs); kept as an option.
     bool fused_done = false;
-    if constexpr (std::is_same<T, bf16_t>::value) if (dec_fused) {
-      fused_done = true;
-      // bf16 path: every LayerNorm is the prologue of the GEMM that consumes it (cn_gemm2_ln256), the
-      // fp32 stream ping-pongs between two buffers (the prologue reads the old one as residual while
-      // the n-tile-0 blocks write the new one), FFN2 is split-K into slabs summed by the next prologue.
-      float* xc = w.x;   // current residual stream
-      float* xn = w.x2;  // next
-      int splits = ff2_splits_env();
-      if (splits < 1 || splits > FF2_SPLITS || dff % (splits * 256) != 0) splits = 1;
-      const size_t slab = (size_t)R * d;
-      for (int l = 0; l < NL; ++l) {
-        const CnLayerW& lw = ctx->layers[l];
-        bf16_t* kc = (bf16_t*)w.kc + (size_t)l * maxp * R * d;
-        bf16_t* vc = (bf16_t*)w.vc + (size_t)l * maxp * R * d;
-        {
-          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-          EpiBiasAct<float, ACT_NONE> eq{lw.sa_in_b, w.qkv, 3 * d, ACT_NONE};
-          if (l == 0) {
-            CN_TRY(cn_gemm2(xt, d, (const bf16_t*)lw.sa_in_w, d, R, 3 * d, d, eq, s));
-          } else {  // x = LN3_{l-1}(x + FFN2 slabs + b2) fused in
-            const CnLayerW& pw = ctx->layers[l - 1];
-            CN_TRY(cn_gemm2_ln256(w.slabs, splits, slab, pw.ff2_b, xc, pw.n3w, pw.n3b, xn,
-                                  (const bf16_t*)lw.sa_in_w, d, R, 3 * d, eq, s));
-            float* t = xc; xc = xn; xn = t;
-          }
-        }
-        {
-          CnProfScope ps(ctx, CONETTE_PROF_DEC_ATTN, s);
-          hipLaunchKernelGGL((cn_self_attn_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.qkv, kc, vc, w.anc, step, R,
-                             beam, maxp, scale, attn_t, kvalid);
-          CN_LAUNCH_CHECK();
-        }
-        {
-          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-          EpiResid eo{lw.sa_out_b, nullptr, xc, w.tmp, d};
-          CN_TRY(cn_gemm2(attn_t, d, (const bf16_t*)lw.sa_out_w, d, R, d, d, eo, s));
-        }
-        {
-          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);  // x = LN1(tmp); q = x Wq + b
-          EpiBiasAct<float, ACT_NONE> ecq{lw.ca_q_b, w.q, d, ACT_NONE};
-          CN_TRY(cn_gemm2_ln256(w.tmp, 1, 0, nullptr, nullptr, lw.n1w, lw.n1b, xn, (const bf16_t*)lw.ca_q_w, d, R, d,
-                                ecq, s));
-          float* t = xc; xc = xn; xn = t;
-        }
-        {
-          CnProfScope ps(ctx, CONETTE_PROF_DEC_ATTN, s);
-          hipLaunchKernelGGL((cn_cross_attn_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.q, kvc, kv_ld, l * 2 * d,
-                             frame_lens, R, beam, Ta, scale, attn_t);
-          CN_LAUNCH_CHECK();
-        }
-        {
-          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-          EpiResid eco{lw.ca_out_b, nullptr, xc, w.tmp, d};
-          CN_TRY(cn_gemm2(attn_t, d, (const bf16_t*)lw.ca_out_w, d, R, d, d, eco, s));
-        }
-        {
-          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);  // x = LN2(tmp); h = gelu(x W1 + b1)
-          EpiBiasAct<bf16_t, ACT_GELU_FAST> e1{lw.ff1_b, ffh, dff, ACT_GELU_FAST};
-          CN_TRY(cn_gemm2_ln256(w.tmp, 1, 0, nullptr, nullptr, lw.n2w, lw.n2b, xn, (const bf16_t*)lw.ff1_w, d, R, dff,
-                                e1, s));
-          float* t = xc; xc = xn; xn = t;
-        }
-        {
-          CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);  // FFN2 partial slabs (bias / residual / LN3 in the consumer)
-          EpiSlab e2{w.slabs, d, slab};
-          CN_TRY(cn_gemm2(ffh, dff, (const bf16_t*)lw.ff2_w, dff, R, d, dff, e2, s, splits));
-        }
-      }
-      {
-        CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);  // x = LN3_last(...); logits = x Wc + bc
-        const CnLayerW& pw = ctx->layers[NL - 1];
-        EpiBiasAct<float, ACT_NONE> ec{ctx->cls_b, w.logits, w.ldv, ACT_NONE};
-        CN_TRY(cn_gemm2_ln256(w.slabs, splits, slab, pw.ff2_b, xc, pw.n3w, pw.n3b, xn, (const bf16_t*)ctx->cls_w, d, R,
-                              V, ec, s));
-      }
-    }
+#ifdef CN_G2_PROF  // profiling build: phase stamps of the block kernel (tools/dbprof.py)
     static const int db_debug = getenv("CN_DB_DEBUG") ? atoi(getenv("CN_DB_DEBUG")) : 0;
+#else
+    constexpr int db_debug = 0;
+#endif
     if constexpr (std::is_same<T, bf16_t>::value) if (block_path) {
       // default bf16 path: 3 launches per layer -- fused block (embedding | previous LN3, QKV, self-attention,
       // cross-attention: dec_block.h), FFN1 GEMM + GELU, FFN2 split-K slabs (summed by the next layer's block
       // prologue; the last layer's by the LN3 kernel in front of the classifier)
       fused_done = true;
-      int splits = ff2_splits_env();
+      int splits = ff2_splits_default();
       if (splits < 1 || splits > FF2_SPLITS || splits > 8 || dff % (splits * 64) != 0) splits = 1;
       // fused FFN (dec_ffn.h): one launch per layer, one slab per 256-wide hidden chunk
-      static const int ffn_env = getenv("CN_DEC_FFN") ? atoi(getenv("CN_DEC_FFN")) : 1;
-      const bool ffn_fused = ffn_env && ctx->layers[0].ffn_w != nullptr && dff / 256 <= FF2_SPLITS;
+      const bool ffn_fused = ctx->layers[0].ffn_w != nullptr && dff / 256 <= FF2_SPLITS;
       if (ffn_fused) splits = dff / 256;
       const size_t slab = (size_t)R * d;
       for (int l = 0; l < NL; ++l) {
@@ -1257,9 +1019,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
       CN_LAUNCH_CHECK();
     }
     CnProfScope ps_search(ctx, CONETTE_PROF_SEARCH, s);
-    const size_t search_smem = (size_t)beam * V * sizeof(float);
-    static const int search_mode = getenv("CN_SEARCH_MODE") ? atoi(getenv("CN_SEARCH_MODE")) : 3;
-    if (search_mode >= 3 && V <= S3_T * S3_VPT) {
+    if (V <= S3_T * S3_VPT) {  // register-resident step (one block of 1024 threads per clip)
 #define S3_LAUNCH(NR_, VPT_)                                                                                          \
   hipLaunchKernelGGL((cn_search_step3_kernel<NR_, VPT_>), dim3(B), dim3(S3_T), 0, s, w.logits, w.ldv, V, beam, maxp,  \
                      step, min_pred, cfg.eos_id, forbid, w.n_active, w.slot, w.sum_lp, w.prefix, w.anc, w.cur_tok,    \
@@ -1275,17 +1035,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
         else S3_LAUNCH(8, 8);
       }
 #undef S3_LAUNCH
-    } else if (search_mode >= 2 && search_smem <= 120 * 1024) {
-      static bool configured = false;
-      if (!configured) {
-        CN_HIP(hipFuncSetAttribute((const void*)cn_search_step2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   120 * 1024));
-        configured = true;
-      }
-      hipLaunchKernelGGL(cn_search_step2_kernel, dim3(B), dim3(256), search_smem, s, w.logits, w.ldv, V, beam, maxp,
-                         step, min_pred, cfg.eos_id, forbid, w.n_active, w.slot, w.sum_lp, w.prefix, w.anc, w.cur_tok,
-                         mult_preds, mult_lprobs, w.out_len, trace_sel, trace_val);
-    } else {
+    } else {  // vocabularies beyond 8192 entries: the generic step (masking in place, top-k over global memory)
       hipLaunchKernelGGL(cn_search_step_kernel, dim3(B), dim3(256), 0, s, w.logits, w.ldv, V, beam, maxp, step,
                          min_pred, cfg.eos_id, forbid, w.n_active, w.slot, w.sum_lp, w.prefix, w.anc, w.cur_tok,
                          mult_preds, mult_lprobs, w.out_len, trace_sel, trace_val);
@@ -1313,31 +1063,22 @@ struct DecGraph {
   hipGraph_t graph;
   int seen;
 };
-#define CN_MAX_DEC_GRAPHS 8
+#define CN_MAX_DEC_GRAPHS 32
 struct DecGraphCache {
   DecGraph g[CN_MAX_DEC_GRAPHS];
   int n;
   int enabled;
 };
 static DecGraphCache* graph_cache(conette_ctx* ctx, bool create) {
-  // one cache per context, keyed by the context pointer (contexts are few and long-lived)
-  static conette_ctx* owners[16];
-  static DecGraphCache* caches[16];
-  for (int i = 0; i < 16; ++i)
-    if (owners[i] == ctx) return caches[i];
-  if (!create) return nullptr;
-  for (int i = 0; i < 16; ++i)
-    if (owners[i] == nullptr) {
-      owners[i] = ctx;
-      caches[i] = new DecGraphCache();
-      memset(caches[i], 0, sizeof(DecGraphCache));
-      caches[i]->enabled = 1;
-      return caches[i];
-    }
-  return nullptr;
+  if (ctx->dec_graphs == nullptr && create) {
+    DecGraphCache* c = new DecGraphCache();
+    memset(c, 0, sizeof(DecGraphCache));
+    c->enabled = 1;
+    ctx->dec_graphs = c;
+  }
+  return (DecGraphCache*)ctx->dec_graphs;
 }
 void cn_decode_graphs_free(conette_ctx* ctx) {
-  static_assert(sizeof(DecGraphCache) > 0, "");
   DecGraphCache* c = graph_cache(ctx, false);
   if (!c) return;
   for (int i = 0; i < c->n; ++i)
@@ -1345,7 +1086,8 @@ void cn_decode_graphs_free(conette_ctx* ctx) {
       (void)hipGraphExecDestroy(c->g[i].exec);
       (void)hipGraphDestroy(c->g[i].graph);
     }
-  c->n = 0;
+  delete c;
+  ctx->dec_graphs = nullptr;
 }
 extern "C" int conette_set_option(conette_ctx* ctx, int32_t option, int32_t value) {
   if (!ctx) return CN_ERR_ARG;

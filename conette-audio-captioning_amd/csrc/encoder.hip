@@ -283,15 +283,14 @@ static int launch_dwconv(const float* x, int B, int H, int W, const CnBlockW& bw
   const int tiles_h = cn_cdiv(H, TH), tiles_w = cn_cdiv(W, 4 * S);
   constexpr int NPOS_ = TH * 4 * S, NT_ = (C > 384 ? 384 : C) * S;
   const size_t smem = ((size_t)NPOS_ * (C + 1) + NPOS_ * (NT_ / NPOS_) + 2 * NPOS_) * sizeof(float);
-  static bool configured = false;
-  if (!configured) {
-    CN_HIP(hipFuncSetAttribute((const void*)cn_dwconv_ln_kernel<T, C, S, TH>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    configured = true;
-  }
+  CN_TRY(cn_configure_lds((const void*)cn_dwconv_ln_kernel<T, C, S, TH>, (int)smem));
   hipLaunchKernelGGL((cn_dwconv_ln_kernel<T, C, S, TH>), dim3((unsigned)(B * tiles_h * tiles_w)),
                      dim3((C > 384 ? 384 : C) * S), smem, s, x, H, W, tiles_h, tiles_w, bw.dw_w, bw.dw_b, bw.ln_w, bw.ln_b, y,
+#ifdef CN_G2_PROF
                      getenv("CN_DW_DEBUG") ? atoi(getenv("CN_DW_DEBUG")) : 0);
+#else
+                     0);
+#endif
   CN_LAUNCH_CHECK();
   return CN_OK;
 }
@@ -426,12 +425,7 @@ template <typename T, int C, int WW, int TH>
 static int launch_dwconv_fw(const float* x, int B, int H, const CnBlockW& bw, T* y, hipStream_t s) {
   const int tiles_h = cn_cdiv(H, TH);
   const size_t smem = ((size_t)TH * WW * (C + 1) + 2 * TH * WW) * sizeof(float);
-  static bool configured = false;
-  if (!configured) {
-    CN_HIP(hipFuncSetAttribute((const void*)cn_dwconv_ln_fw_kernel<T, C, WW, TH>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    configured = true;
-  }
+  CN_TRY(cn_configure_lds((const void*)cn_dwconv_ln_fw_kernel<T, C, WW, TH>, (int)smem));
   hipLaunchKernelGGL((cn_dwconv_ln_fw_kernel<T, C, WW, TH>), dim3((unsigned)(B * tiles_h)), dim3(384), smem, s, x, H,
                      tiles_h, bw.dw_w, bw.dw_b, bw.ln_w, bw.ln_b, y);
   CN_LAUNCH_CHECK();
@@ -625,21 +619,16 @@ extern "C" size_t conette_encode_workspace_bytes(const conette_ctx* ctx, int32_t
   return enc_ws(ctx, batch, n_samples, nullptr).total;
 }
 
-static inline int dw_fullwidth() {
-  static const int v = getenv("CN_DW_FULLWIDTH") ? atoi(getenv("CN_DW_FULLWIDTH")) : 1;
-  return v;
-}
-
 template <typename T>
 static int dwconv_dispatch(int C, const float* x, int B, int H, int W, const CnBlockW& bw, T* y, hipStream_t s) {
   switch (C) {
     case 96: return launch_dwconv<T, 96, 2, 8>(x, B, H, W, bw, y, s);
     case 192: return launch_dwconv<T, 192, 1, 8>(x, B, H, W, bw, y, s);
     case 384:
-      if (W == 14 && dw_fullwidth()) return launch_dwconv_fw<T, 384, 14, 4>(x, B, H, bw, y, s);
+      if (W == 14) return launch_dwconv_fw<T, 384, 14, 4>(x, B, H, bw, y, s);
       return launch_dwconv<T, 384, 1, 4>(x, B, H, W, bw, y, s);
     case 768:
-      if (W == 7 && dw_fullwidth()) return launch_dwconv_fw<T, 768, 7, 4>(x, B, H, bw, y, s);
+      if (W == 7) return launch_dwconv_fw<T, 768, 7, 4>(x, B, H, bw, y, s);
       return launch_dwconv<T, 768, 1, 4>(x, B, H, W, bw, y, s);
   }
   cn_set_error("dwconv: unsupported C=%d", C);

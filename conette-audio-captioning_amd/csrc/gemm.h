@@ -279,12 +279,7 @@ template <typename T, int BM, int BN, class Epi>
 static int cn_launch_gemm_t(const T* A, int lda, const T* W, int ldw, int M, int N, int K, const Epi& epi,
                             hipStream_t stream) {
   constexpr int SMEM = 2 * (BM + BN) * GemmTraits<T>::ROW_BYTES;
-  static bool configured = false;
-  if (!configured) {
-    CN_HIP(hipFuncSetAttribute((const void*)cn_gemm_nt_kernel<T, BM, BN, Epi>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    configured = true;
-  }
+  CN_TRY(cn_configure_lds((const void*)cn_gemm_nt_kernel<T, BM, BN, Epi>, SMEM));
   const long blocks = (long)cn_cdiv(M, BM) * cn_cdiv(N, BN);
   hipLaunchKernelGGL((cn_gemm_nt_kernel<T, BM, BN, Epi>), dim3((unsigned)blocks), dim3(256), SMEM, stream, A, lda,
                      W, ldw, M, N, K, epi);

@@ -302,150 +302,14 @@ __global__ __launch_bounds__(256) void cn_gemm2_kernel(const bf16_t* __restrict_
 #endif
 }
 
-// ---- skinny decoder GEMM with a LayerNorm prologue (d_model = 256) ---------------------------------
-//   a[m][:] = LayerNorm_256( sum_{s < nslab} in[s][m][:] + bias + resid[m][:] ) * g + b      (eps 1e-5)
-//   C[m][n] = sum_k a[m][k] W[n][k]
-// The normalised rows are produced by the block itself (one wave per row, wave-shuffle sums) and
-// written as bf16 straight into the swizzled LDS A tile while the W tile arrives by LDS-DMA; the
-// blocks of n-tile 0 also store them as fp32 (`x_out`: the residual stream of the next sub-layer).
-// Saves one launch (~5 us of dependent latency) per LayerNorm: 18 of the 69 launches per step.
-template <class Epi>
-__global__ __launch_bounds__(256) void cn_gemm2_ln256_kernel(const float* __restrict__ in, int nslab, size_t slab_stride,
-                                                             const float* __restrict__ bias,
-                                                             const float* __restrict__ resid,
-                                                             const float* __restrict__ ln_w,
-                                                             const float* __restrict__ ln_b, float* __restrict__ x_out,
-                                                             const bf16_t* __restrict__ W, int ldw, int M, int N,
-                                                             Epi epi) {
-  constexpr int BM = 64, BN = 64, BK = 256;
-  typedef G2Geom<BK> G;
-  constexpr int A_BYTES = BM * G::RBY, W_BYTES = BN * G::RBY;
-  constexpr int DPW = W_BYTES / 1024 / 4;  // 8 DMA pieces per wave
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int n_tiles = (N + BN - 1) / BN;
-  const int m0 = (blockIdx.x / n_tiles) * BM;
-  const int n0 = (blockIdx.x % n_tiles) * BN;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  // W tile by LDS-DMA (2 rows of 512 bytes per piece)
-#pragma unroll
-  for (int i = 0; i < DPW; ++i) {
-    const int inst = wave * DPW + i;
-    const int r = inst * G::RPI + lane / G::CPR;
-    const int chunk = (lane % G::CPR) ^ (r & G::SWM);
-    const char* src = (const char*)(W + (size_t)min(n0 + r, N - 1) * ldw) + chunk * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(smem + A_BYTES + inst * 1024), 16, 0, 0);
-  }
-  // LayerNorm prologue: wave w normalises rows 16w .. 16w+15; lane owns columns 4l .. 4l+3.
-  // All 16 rows are loaded before any arithmetic (one memory latency per operand, not per row).
-  const f32x4 gw = *(const f32x4*)(ln_w + 4 * lane), gb = *(const f32x4*)(ln_b + 4 * lane);
-  f32x4 v[16];
-  size_t roff[16];
-#pragma unroll
-  for (int rr = 0; rr < 16; ++rr) {
-    roff[rr] = (size_t)min(m0 + wave * 16 + rr, M - 1) * 256 + 4 * lane;
-    v[rr] = *(const f32x4*)(in + roff[rr]);
-  }
-  for (int sl = 1; sl < nslab; ++sl) {
-    f32x4 u[16];
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) u[rr] = *(const f32x4*)(in + sl * slab_stride + roff[rr]);
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[rr][i] += u[rr][i];
-  }
-  if (resid) {
-    f32x4 u[16];
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) u[rr] = *(const f32x4*)(resid + roff[rr]);
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[rr][i] += u[rr][i];
-  }
-  if (bias) {
-    const f32x4 bv = *(const f32x4*)(bias + 4 * lane);
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[rr][i] += bv[i];
-  }
-  float mean[16], rstd[16];
-#pragma unroll
-  for (int rr = 0; rr < 16; ++rr) mean[rr] = v[rr][0] + v[rr][1] + v[rr][2] + v[rr][3];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) mean[rr] += __shfl_xor(mean[rr], o);
-#pragma unroll
-  for (int rr = 0; rr < 16; ++rr) {
-    mean[rr] *= (1.0f / 256.0f);
-    float s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s2 = fmaf(v[rr][i] - mean[rr], v[rr][i] - mean[rr], s2);
-    rstd[rr] = s2;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) rstd[rr] += __shfl_xor(rstd[rr], o);
-#pragma unroll
-  for (int rr = 0; rr < 16; ++rr) {
-    const int r = wave * 16 + rr;
-    const float rs = 1.0f / sqrtf(rstd[rr] * (1.0f / 256.0f) + 1e-5f);
-    f32x4 o;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = (v[rr][i] - mean[rr]) * rs * gw[i] + gb[i];
-    if (n0 == 0 && m0 + r < M) *(f32x4*)(x_out + (size_t)(m0 + r) * 256 + 4 * lane) = o;
-    // columns 4l..4l+3 = 16-byte chunk l/2, half l%2 of the 512-byte row r
-    cn_store4((bf16_t*)(smem + r * G::RBY + (((lane >> 1) ^ (r & G::SWM)) * 16) + (lane & 1) * 8), o[0], o[1], o[2], o[3]);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  f32x4 acc[BN / 32][BM / 32];
-#pragma unroll
-  for (int a = 0; a < BN / 32; ++a)
-#pragma unroll
-    for (int b = 0; b < BM / 32; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  cn_g2_compute<BM, BN, BK>(smem, smem + A_BYTES, lane, wm, wn, acc);
-  __syncthreads();
+// Phase-stamp / skip controls exist in the profiling build only (CN_G2_PROF=1 python build.py --force, tools/g2prof.py);
+// the product library reads no environment variable on this path.
 #ifdef CN_G2_PROF
-  {
-    const int dbg = 0;
-    unsigned long long t_prev = 0, t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    cn_g2_epilogue<BM, BN, Epi>(smem, acc, m0, n0, M, N, epi, 0, tid, wm, wn, dbg, t_prev, t_acc);
-  }
-#else
-  cn_g2_epilogue<BM, BN, Epi>(smem, acc, m0, n0, M, N, epi, 0, tid, wm, wn);
-#endif
-}
-
-template <class Epi>
-static int cn_gemm2_ln256(const float* in, int nslab, size_t slab_stride, const float* bias, const float* resid,
-                          const float* ln_w, const float* ln_b, float* x_out, const bf16_t* W, int ldw, int M, int N,
-                          const Epi& epi, hipStream_t stream) {
-  constexpr int SMEM = 2 * 64 * 512;
-  static bool configured = false;
-  if (!configured) {
-    CN_HIP(hipFuncSetAttribute((const void*)cn_gemm2_ln256_kernel<Epi>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               SMEM));
-    configured = true;
-  }
-  hipLaunchKernelGGL((cn_gemm2_ln256_kernel<Epi>), dim3((unsigned)(cn_cdiv(M, 64) * cn_cdiv(N, 64))), dim3(256), SMEM,
-                     stream, in, nslab, slab_stride, bias, resid, ln_w, ln_b, x_out, W, ldw, M, N, epi);
-  CN_LAUNCH_CHECK();
-  return CN_OK;
-}
-
 static inline int g2_debug_level() {  // CN_G2_DEBUG = BM + BN of the tile shape to instrument (256: the 128 x 128 tiles)
   static const int v = getenv("CN_G2_DEBUG") ? atoi(getenv("CN_G2_DEBUG")) : 0;
   return v;
 }
-
-static inline int g2_debug_skip() {  // profiling build only: CN_G2_SKIP bit 1 (2) = no epilogue, bit 2 (4) = no MFMA phase
+static inline int g2_debug_skip() {  // CN_G2_SKIP bit 1 (2) = no epilogue, bit 2 (4) = no MFMA phase
   static const int v = getenv("CN_G2_SKIP") ? atoi(getenv("CN_G2_SKIP")) : 0;
   return v;
 }
@@ -453,6 +317,11 @@ static inline int g2_debug_epi() {  // CN_G2_DEBUG_EPI = 2: bf16-output (staged)
   static const int v = getenv("CN_G2_DEBUG_EPI") ? atoi(getenv("CN_G2_DEBUG_EPI")) : 0;
   return v;
 }
+#else
+static inline int g2_debug_level() { return 0; }
+static inline int g2_debug_skip() { return 0; }
+static inline int g2_debug_epi() { return 0; }
+#endif
 
 template <int BM, int BN, int BK, int NST, class Epi>
 static int cn_launch_gemm2_t(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, int splits,
@@ -460,12 +329,7 @@ static int cn_launch_gemm2_t(const bf16_t* A, int lda, const bf16_t* W, int ldw,
   constexpr int EPI_BYTES = sizeof(typename Epi::stage_t) == 4 ? 0 : BM * (BN * 2 + 16);
   constexpr int PIPE_BYTES = NST * (BM + BN) * BK * 2;
   constexpr int SMEM = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
-  static bool configured = false;
-  if (!configured) {
-    CN_HIP(hipFuncSetAttribute((const void*)cn_gemm2_kernel<BM, BN, BK, NST, Epi>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    configured = true;
-  }
+  CN_TRY(cn_configure_lds((const void*)cn_gemm2_kernel<BM, BN, BK, NST, Epi>, SMEM));
   const long blocks = (long)cn_cdiv(M, BM) * cn_cdiv(N, BN);
   const int k_slice = K / splits;
   hipLaunchKernelGGL((cn_gemm2_kernel<BM, BN, BK, NST, Epi>), dim3((unsigned)blocks, (unsigned)splits), dim3(256), SMEM,
@@ -483,20 +347,13 @@ static int cn_gemm2(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, i
     return CN_ERR_ARG;
   }
   const bool k64 = (K % 64 == 0);
-  static const int cfg = getenv("CN_G2_CFG") ? atoi(getenv("CN_G2_CFG")) : 0;
   if (M >= 4096) {
     const bool n96 = (N % 96 == 0) && (N % 128 != 0);
     if (!k64) return cn_launch_gemm2_t<128, 128, 32, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
     if (n96) return cn_launch_gemm2_t<128, 96, 64, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
-    if (cfg == 1) return cn_launch_gemm2_t<128, 128, 64, 3, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
-    if (cfg == 2) return cn_launch_gemm2_t<128, 128, 32, 4, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
-    if (cfg == 3) return cn_launch_gemm2_t<128, 128, 32, 3, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
     return cn_launch_gemm2_t<128, 128, 64, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
   }
   if (!k64) return cn_launch_gemm2_t<64, 64, 32, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
-  static const int small_bk256 = getenv("CN_G2_SMALL256") ? atoi(getenv("CN_G2_SMALL256")) : 0;
-  if (small_bk256 && (K / splits) % 256 == 0)
-    return cn_launch_gemm2_t<64, 64, 256, 1, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
   return cn_launch_gemm2_t<64, 64, 64, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
 }
 

@@ -271,11 +271,7 @@ template <int C, int NW, int NCK>
 static int cn_launch_mlp_rc2_resident(const bf16_t* Y, const bf16_t* WS, float* X, int M, int n_blocks, hipStream_t s) {
   constexpr int SMEM = (int)Rc2Geom<C, NCK>::STREAM_BYTES;
   static_assert(SMEM <= 160 * 1024, "resident variant: the weight stream must fit in LDS");
-  static bool configured = false;
-  if (!configured) {
-    CN_HIP(hipFuncSetAttribute((const void*)cn_mlp_rc2_resident_kernel<C, NW, NCK>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    configured = true;
-  }
+  CN_TRY(cn_configure_lds((const void*)cn_mlp_rc2_resident_kernel<C, NW, NCK>, SMEM));
   const int n_tiles = (M + 31) / 32;
   const int grid = n_blocks < cn_cdiv(n_tiles, NW) ? n_blocks : cn_cdiv(n_tiles, NW);
   hipLaunchKernelGGL((cn_mlp_rc2_resident_kernel<C, NW, NCK>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, Y, WS, X, M);
@@ -373,11 +369,7 @@ static int cn_launch_mlp_rc2_ring(const bf16_t* Y, const bf16_t* WS, float* X, i
                                   unsigned long long* prof = nullptr) {
   constexpr int SMEM = NST * Rc2Geom<C, NCK>::STEP_BYTES;
   static_assert(SMEM <= 160 * 1024, "ring must fit in LDS");
-  static bool configured = false;
-  if (!configured) {
-    CN_HIP(hipFuncSetAttribute((const void*)cn_mlp_rc2_ring_kernel<C, NW, NCK, NST, PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    configured = true;
-  }
+  CN_TRY(cn_configure_lds((const void*)cn_mlp_rc2_ring_kernel<C, NW, NCK, NST, PROF>, SMEM));
   const int n_tiles = (M + 31) / 32;
   const int grid = n_blocks < cn_cdiv(n_tiles, NW) ? n_blocks : cn_cdiv(n_tiles, NW);
   hipLaunchKernelGGL((cn_mlp_rc2_ring_kernel<C, NW, NCK, NST, PROF>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, Y, WS, X, M, prof);

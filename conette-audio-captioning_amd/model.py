@@ -119,6 +119,10 @@ class CoNeTTEModel:
             self.task_id_to_token_id = torch.as_tensor([self.task_name_to_token_id[n] for n in config.task_names])
         frm = state_dict.get("model.forbid_rep_mask")
         self.forbid_rep_mask: Optional[Tensor] = None if frm is None else frm.to(torch.bool).to(self.device)
+        # the HIP path implements the published architecture only: fail loudly instead of silently running GELU / lin768
+        if config.acti_name != "gelu" or config.proj_name != "lin768":
+            raise ValueError(f"Unsupported config for the MI355X path: acti_name={config.acti_name!r}, "
+                             f"proj_name={config.proj_name!r} (expected 'gelu' and 'lin768').")
         self._stopwords = list(ENGLISH_STOPWORDS if stopwords is None else stopwords)
         self.audioset_idx_to_name = (load_audioset_idx_to_name(offline=offline) if audioset_idx_to_name is None
                                      else dict(audioset_idx_to_name))

@@ -3,11 +3,11 @@
 Mirrors ``CoNeTTEPreprocessor`` (reference huggingface/preprocessor.py:21-154): accepts a path,
 list of paths, Tensor (T,), (C,T), (B,C,T) or list of (C,T) tensors, resamples to 32 kHz when
 needed (HIP resampler), takes the channel mean, zero-pads to the batch maximum and runs the
-HIP encoder.  The reference's torchaudio.load is replaced by a PCM WAV reader (stdlib ``wave``).
+HIP encoder.  The reference's torchaudio.load is replaced by a RIFF/WAVE reader (PCM and float formats) with
+soundfile / torchaudio as optional back-ends for other containers.
 """
 from __future__ import annotations
 
-import wave as _wave
 from typing import Any, Dict, Iterable, List, Optional, Tuple, Union
 
 import numpy as np
@@ -20,20 +20,69 @@ TARGET_SR = 32_000
 FEAT_SIZE = 768
 
 
-def load_audio(path: str) -> Tuple[Tensor, int]:
-    """PCM WAV -> ((C, L) float32 in [-1, 1), sample rate)."""
-    with _wave.open(path, "rb") as w:
-        sr, nch, width, n = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()
-        raw = w.readframes(n)
-    if width == 2:
-        data = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
-    elif width == 4:
-        data = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
-    elif width == 1:
-        data = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+def _read_wav(path: str) -> Tuple[np.ndarray, int]:
+    """RIFF/WAVE reader: PCM 8 / 16 / 24 / 32 bit, IEEE float 32 / 64 bit, plain or WAVE_FORMAT_EXTENSIBLE headers
+    (the stdlib ``wave`` module refuses everything but 8 / 16 / 32-bit PCM).  -> ((frames, channels) float32, sr)."""
+    import struct
+    with open(path, "rb") as f:
+        blob = f.read()
+    if len(blob) < 12 or blob[:4] != b"RIFF" or blob[8:12] != b"WAVE":
+        raise ValueError(f"{path} is not a RIFF/WAVE file.")
+    pos, fmt, data = 12, None, None
+    while pos + 8 <= len(blob):
+        cid, size = blob[pos : pos + 4], struct.unpack("<I", blob[pos + 4 : pos + 8])[0]
+        body = blob[pos + 8 : pos + 8 + size]
+        if cid == b"fmt ":
+            fmt = body
+        elif cid == b"data":
+            data = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or data is None or len(fmt) < 16:
+        raise ValueError(f"{path}: missing fmt / data chunk.")
+    tag, nch, sr, _, _, bits = struct.unpack("<HHIIHH", fmt[:16])
+    if tag == 0xFFFE and len(fmt) >= 26:          # WAVE_FORMAT_EXTENSIBLE: the real tag is the first word of the sub-format GUID
+        tag = struct.unpack("<H", fmt[24:26])[0]
+    n = len(data) // (bits // 8) // max(nch, 1) * nch
+    if tag == 1 and bits == 16:
+        x = np.frombuffer(data, dtype="<i2", count=n).astype(np.float32) / 32768.0
+    elif tag == 1 and bits == 24:
+        b = np.frombuffer(data, dtype=np.uint8, count=n * 3).reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        x = (v - ((v & 0x800000) << 1)).astype(np.float32) / 8388608.0
+    elif tag == 1 and bits == 32:
+        x = np.frombuffer(data, dtype="<i4", count=n).astype(np.float32) / 2147483648.0
+    elif tag == 1 and bits == 8:
+        x = (np.frombuffer(data, dtype=np.uint8, count=n).astype(np.float32) - 128.0) / 128.0
+    elif tag == 3 and bits == 32:
+        x = np.frombuffer(data, dtype="<f4", count=n).astype(np.float32)
+    elif tag == 3 and bits == 64:
+        x = np.frombuffer(data, dtype="<f8", count=n).astype(np.float32)
     else:
-        raise ValueError(f"Unsupported PCM sample width {width} in {path}.")
-    return torch.from_numpy(np.ascontiguousarray(data.reshape(-1, nch).T)), sr
+        raise ValueError(f"Unsupported WAVE format tag {tag} with {bits} bits in {path}.")
+    return x.reshape(-1, nch), int(sr)
+
+
+def load_audio(path: str) -> Tuple[Tensor, int]:
+    """Audio file -> ((C, L) float32 in [-1, 1), sample rate); stands in for ``torchaudio.load`` (preprocessor.py:79-80).
+    WAV files (PCM 8 / 16 / 24 / 32 bit, float 32 / 64 bit) are read here; any other container (FLAC, OGG, MP3) goes
+    through ``soundfile`` or ``torchaudio`` when one of them is installed and is an explicit error otherwise."""
+    with open(path, "rb") as f:
+        head = f.read(12)
+    if head[:4] == b"RIFF" and head[8:12] == b"WAVE":
+        data, sr = _read_wav(path)
+        return torch.from_numpy(np.ascontiguousarray(data.T)), sr
+    try:
+        import soundfile
+        data, sr = soundfile.read(path, dtype="float32", always_2d=True)
+        return torch.from_numpy(np.ascontiguousarray(data.T)), int(sr)
+    except ImportError:
+        pass
+    try:
+        import torchaudio
+        wav, sr = torchaudio.load(path)
+        return wav.to(torch.float32), int(sr)
+    except ImportError:
+        raise ValueError(f"{path}: only WAV files can be read without soundfile / torchaudio installed.") from None
 
 
 def _is_iterable_str(x: Any) -> bool:

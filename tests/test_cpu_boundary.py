@@ -98,3 +98,67 @@ def test_synth_recipe_is_deterministic():
     w1 = synth.synth_waveforms(2, 4000, 5, lengths=[4000, 1000])
     assert np.array_equal(w1, synth.synth_waveforms(2, 4000, 5, lengths=[4000, 1000]))
     assert (w1[1, 1000:] == 0).all() and w1.dtype == np.float32
+
+
+def test_wav_reader_formats(tmp_path):
+    """load_audio stands in for torchaudio.load: PCM 8 / 16 / 24 / 32 bit and IEEE float WAV files, plain and
+    WAVE_FORMAT_EXTENSIBLE headers, mono and stereo; other containers are an explicit error without a back-end."""
+    import struct
+    import numpy as np
+    import pytest
+    import conette_amd  # noqa: F401
+    from conette_amd.preprocessor import load_audio
+    rng = np.random.default_rng(0)
+    x = (rng.random((1000, 2)) * 1.8 - 0.9).astype(np.float32)
+
+    def wav(path, tag, bits, payload, nch=2, sr=44100, extensible=False):
+        block = nch * bits // 8
+        if extensible:
+            fmt = struct.pack("<HHIIHH", 0xFFFE, nch, sr, sr * block, block, bits) + struct.pack("<HHI", 22, bits, 3) + \
+                struct.pack("<H", tag) + b"\x00\x00\x00\x00\x10\x00\x80\x00\x00\xaa\x00\x38\x9b\x71"
+        else:
+            fmt = struct.pack("<HHIIHH", tag, nch, sr, sr * block, block, bits)
+        body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"LIST" + struct.pack("<I", 4) + b"abcd" + \
+            b"data" + struct.pack("<I", len(payload)) + payload
+        with open(path, "wb") as f:
+            f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+    cases = {
+        "pcm16": (1, 16, np.round(x * 32767).astype("<i2").tobytes(), 2 / 32768),
+        "pcm32": (1, 32, np.round(x.astype(np.float64) * 2147483647).astype("<i4").tobytes(), 1e-6),
+        "pcm8": (1, 8, (np.round(x * 127) + 128).astype(np.uint8).tobytes(), 2 / 127),
+        "f32": (3, 32, x.astype("<f4").tobytes(), 0.0),
+        "f64": (3, 64, x.astype("<f8").tobytes(), 1e-7),
+    }
+    v24 = np.round(x.astype(np.float64) * 8388607).astype(np.int32)
+    b24 = np.stack([(v24 >> s) & 0xFF for s in (0, 8, 16)], axis=-1).astype(np.uint8).tobytes()
+    cases["pcm24"] = (1, 24, b24, 1e-6)
+    for name, (tag, bits, payload, tol) in cases.items():
+        for ext in (False, True):
+            p = str(tmp_path / f"{name}{int(ext)}.wav")
+            wav(p, tag, bits, payload, extensible=ext)
+            got, sr = load_audio(p)
+            assert sr == 44100 and tuple(got.shape) == (2, 1000) and got.dtype.is_floating_point, name
+            assert float(np.abs(got.numpy().T - x).max()) <= tol + 1e-7, (name, ext)
+    p = str(tmp_path / "x.flac")
+    with open(p, "wb") as f:
+        f.write(b"fLaC" + b"\x00" * 64)
+    try:
+        import soundfile  # noqa: F401
+    except ImportError:
+        try:
+            import torchaudio  # noqa: F401
+        except ImportError:
+            with pytest.raises(ValueError, match="only WAV"):
+                load_audio(p)
+
+
+def test_unsupported_architecture_config_is_refused():
+    import pytest
+    import conette_amd  # noqa: F401
+    from conette_amd import CoNeTTEConfig
+    from conette_amd.model import CoNeTTEModel
+    for kw in ({"acti_name": "relu"}, {"proj_name": "lin512"}):
+        with pytest.raises((ValueError, RuntimeError)) as e:
+            CoNeTTEModel(CoNeTTEConfig(**kw), state_dict={})
+        assert "Unsupported config" in str(e.value) or "GPU" in str(e.value) or "missing" in str(e.value).lower()

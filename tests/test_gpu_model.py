@@ -350,3 +350,78 @@ def test_decode_audio_surface_baseline_style(model_fp32):
         model_fp32.decode_audio(pre, "forcing")
     with pytest.raises(ValueError, match="Unknown argument"):
         model_fp32.decode_audio(pre, "sampling")
+
+
+def _write_wav(path, data, sr):
+    """data: (channels, samples) float in [-1, 1) -> 16-bit PCM WAV."""
+    import wave
+    pcm = np.clip(np.round(data.T * 32768.0), -32768, 32767).astype("<i2")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(data.shape[0]), w.setsampwidth(2), w.setframerate(sr)
+        w.writeframes(pcm.tobytes())
+
+
+def test_predict_cli_on_44k_stereo_against_oracle(model_dir, tmp_path, synth_weights, synth_cfg):
+    """SURVEY 8f-1 end to end the way the reference's smoke test runs it (tests/test_inference.py:20-27: a 44.1 kHz
+    file through the model): stereo 44.1 kHz + mono 48 kHz WAVs -> conette-predict --csv_export -> candidates equal the
+    CPU oracle's on the same files (load, 441:320 / 3:2 sinc resampling on the GPU, channel mean, pad, captions)."""
+    import csv
+    from conette_amd import synth
+    from conette_amd.predict import main_predict
+    from oracle import cpu_ref as O
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    a = synth.synth_waveforms(2, 44100 * 4, 808)
+    b = synth.synth_waveforms(1, 48000 * 3, 809)
+    pa, pb = str(tmp_path / "stereo_44k.wav"), str(tmp_path / "mono_48k.wav")
+    _write_wav(pa, np.stack([a[0], 0.5 * a[1]]), 44100)
+    _write_wav(pb, b, 48000)
+    cache = tmp_path / "audioset_mapping"
+    cache.mkdir()
+    with open(cache / "class_labels_indices.csv", "w") as f:
+        f.write("index,mid,display_name\n" + "".join(f"{i},/m/{i},tag{i}\n" for i in range(527)))
+    os.environ["CONETTE_AUDIOSET_CACHE"] = str(cache)
+    try:
+        out_csv = str(tmp_path / "out.csv")
+        res = main_predict(["--audio", pa, pb, "--task", "clotho", "--model_name", model_dir, "--precision", "fp32",
+                            "--csv_export", out_csv, "--verbose", "0"])
+    finally:
+        os.environ.pop("CONETTE_AUDIOSET_CACHE", None)
+    with torch.no_grad():
+        ref = O.model_forward(synth_weights, synth_cfg, [pa, pb], task="clotho")
+    assert [r["candidate"] for r in res] == ref["cands"]
+    with open(out_csv) as f:
+        rows = list(csv.DictReader(f))
+    assert [r["candidate"] for r in rows] == ref["cands"] and [r["audio"] for r in rows] == ["stereo_44k.wav", "mono_48k.wav"]
+    assert [r["task"] for r in rows] == ["clotho", "clotho"]
+
+
+def test_offline_feature_files_against_oracle(model_fp32, tmp_path, synth_weights, synth_cfg):
+    """per-file (batch of one) features on disk -- audio (T, 768), audio_shape, clip_probs -- equal the
+    oracle's preprocessor on each single file, and the stored rows fed back through preprocess=False decode to the
+    captions the oracle gets from the same features (transforms/get.py:240-310, conf/dm/hdf.yaml:12-14, model.py:205-212)."""
+    from conette_amd import offline, synth
+    from oracle import cpu_ref as O
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    files = []
+    for i, (sr, secs, ch) in enumerate([(44100, 3.0, 2), (32000, 5.5, 1), (16000, 2.0, 1)]):
+        w = synth.synth_waveforms(ch, int(sr * secs), 300 + i)
+        p = str(tmp_path / f"f{i}.wav")
+        _write_wav(p, w, sr)
+        files.append(p)
+    paths = offline.write_features(model_fp32, files, str(tmp_path / "feats"))
+    assert sorted(os.listdir(tmp_path / "feats")) == ["f0.npz", "f1.npz", "f2.npz", "index.json"]
+    for f, p in zip(files, paths):
+        row = np.load(p)
+        with torch.no_grad():
+            ref = O.preprocessor_forward(synth_weights, f)
+        assert row["audio"].shape == tuple(ref["audio"][0].shape) and row["audio"].shape[1] == 768
+        assert row["audio_shape"].tolist() == ref["audio_shape"][0].tolist() == [768, row["audio"].shape[0]]
+        np.testing.assert_allclose(row["audio"], ref["audio"][0].numpy(), rtol=1e-3, atol=2e-4)
+        np.testing.assert_allclose(row["clip_probs"], ref["clip_probs"][0].numpy(), rtol=1e-3, atol=1e-4)
+    audio, shapes = offline.load_features(paths)
+    assert audio.shape[0] == 3 and audio.shape[2] == 768 and shapes.shape == (3, 2)
+    out = model_fp32(audio, x_shapes=shapes, preprocess=False, task="clotho")
+    with torch.no_grad():
+        ref = O.model_forward(synth_weights, synth_cfg, audio, x_shapes=shapes, preprocess=False, task="clotho")
+    assert out["preds"].cpu().tolist() == ref["preds"].tolist() and out["cands"] == ref["cands"]
+    np.testing.assert_allclose(out["lprobs"].cpu().numpy(), ref["lprobs"].numpy(), atol=2e-4)

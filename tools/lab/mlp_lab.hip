@@ -10,8 +10,6 @@
 #include <string>
 #include <algorithm>
 
-#include "mlp_rc.h"
-#include "mlp_rc_ring.h"
 #include "mlp_rc2.h"
 
 void cn_set_error(const char* fmt, ...) {
@@ -69,62 +67,34 @@ template <typename T> static T* dalloc(size_t n) {
 
 struct Variant {
   std::string name;
-  int (*run)(const bf16_t* Y, const bf16_t* WS, const float* b2, const float* scale, float* X, int M, hipStream_t s);
-  int pack = 0;  // 0: mlp_rc.h stream, 1 / 2: mlp_rc2.h stream with NCK = 1 / 2
+  int (*run)(const bf16_t* Y, const bf16_t* WS, float* X, int M, hipStream_t s);
+  int pack = 1;  // mlp_rc2.h stream with NCK = 1 / 2
 };
 
 template <int C> static std::vector<Variant> variants();
 
 template <> std::vector<Variant> variants<96>() {
   return {
-      {"rc_resident<96,8>",
-       [](const bf16_t* Y, const bf16_t* WS, const float* b2, const float* sc, float* X, int M, hipStream_t s) {
-         return cn_launch_mlp_rc_resident<96, 8>(Y, WS, b2, sc, X, M, 256, s);
-       }, 0},
-      {"rc_resident<96,12>",
-       [](const bf16_t* Y, const bf16_t* WS, const float* b2, const float* sc, float* X, int M, hipStream_t s) {
-         return cn_launch_mlp_rc_resident<96, 12>(Y, WS, b2, sc, X, M, 256, s);
-       }, 0},
       {"rc2_resident<96,8,nck2>",
-       [](const bf16_t* Y, const bf16_t* WS, const float* b2, const float* sc, float* X, int M, hipStream_t s) {
-         return cn_launch_mlp_rc2_resident<96, 8, 2>(Y, WS, X, M, 256, s);
-       }, 2},
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 8, 2>(Y, WS, X, M, 256, s); }, 2},
       {"rc2_resident<96,8,nck1>",
-       [](const bf16_t* Y, const bf16_t* WS, const float* b2, const float* sc, float* X, int M, hipStream_t s) {
-         return cn_launch_mlp_rc2_resident<96, 8, 1>(Y, WS, X, M, 256, s);
-       }, 1},
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 8, 1>(Y, WS, X, M, 256, s); }, 1},
       {"rc2_resident<96,12,nck1>",
-       [](const bf16_t* Y, const bf16_t* WS, const float* b2, const float* sc, float* X, int M, hipStream_t s) {
-         return cn_launch_mlp_rc2_resident<96, 12, 1>(Y, WS, X, M, 256, s);
-       }, 1},
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 12, 1>(Y, WS, X, M, 256, s); }, 1},
   };
 }
 template <> std::vector<Variant> variants<192>() {
   return {
-      {"rc_ring<192,8,5>",
-       [](const bf16_t* Y, const bf16_t* WS, const float* b2, const float* sc, float* X, int M, hipStream_t s) {
-         return cn_launch_mlp_rc_ring<192, 8, 5>(Y, WS, b2, sc, X, M, 256, s);
-       }, 0},
       {"rc2_ring<192,8,nck1,nst5>",
-       [](const bf16_t* Y, const bf16_t* WS, const float* b2, const float* sc, float* X, int M, hipStream_t s) {
-         return cn_launch_mlp_rc2_ring<192, 8, 1, 5>(Y, WS, X, M, 256, s);
-       }, 1},
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, hipStream_t s) { return cn_launch_mlp_rc2_ring<192, 8, 1, 5>(Y, WS, X, M, 256, s); }, 1},
       {"rc2_ring<192,8,nck2,nst3>",
-       [](const bf16_t* Y, const bf16_t* WS, const float* b2, const float* sc, float* X, int M, hipStream_t s) {
-         return cn_launch_mlp_rc2_ring<192, 8, 2, 3>(Y, WS, X, M, 256, s);
-       }, 2},
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, hipStream_t s) { return cn_launch_mlp_rc2_ring<192, 8, 2, 3>(Y, WS, X, M, 256, s); }, 2},
   };
 }
 template <> std::vector<Variant> variants<384>() {
   return {
-      {"rc_ring<384,4,3>",
-       [](const bf16_t* Y, const bf16_t* WS, const float* b2, const float* sc, float* X, int M, hipStream_t s) {
-         return cn_launch_mlp_rc_ring<384, 4, 3>(Y, WS, b2, sc, X, M, 256, s);
-       }, 0},
       {"rc2_ring<384,4,nck1,nst3>",
-       [](const bf16_t* Y, const bf16_t* WS, const float* b2, const float* sc, float* X, int M, hipStream_t s) {
-         return cn_launch_mlp_rc2_ring<384, 4, 1, 3>(Y, WS, X, M, 256, s);
-       }, 1},
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, hipStream_t s) { return cn_launch_mlp_rc2_ring<384, 4, 1, 3>(Y, WS, X, M, 256, s); }, 1},
   };
 }
 
@@ -149,8 +119,7 @@ template <int C> static int run(int batch, int iters) {
   bf16_t* Y = dalloc<bf16_t>(hY.size());
   float *X = dalloc<float>(hX.size() + 64 * C), *Xref = dalloc<float>((size_t)Mc * C), *Xref2 = dalloc<float>((size_t)Mc * C);
   bf16_t* H = dalloc<bf16_t>((size_t)Mc * 4 * C);
-  bf16_t* WS = dalloc<bf16_t>((size_t)RcGeom<C>::NCH * RcGeom<C>::CHUNK_BYTES / 2);
-  bf16_t* WS2[3] = {WS, dalloc<bf16_t>(Rc2Geom<C, 1>::TOTAL_BYTES / 2), dalloc<bf16_t>(Rc2Geom<C, 2>::TOTAL_BYTES / 2)};
+  bf16_t* WS2[3] = {nullptr, dalloc<bf16_t>(Rc2Geom<C, 1>::TOTAL_BYTES / 2), dalloc<bf16_t>(Rc2Geom<C, 2>::TOTAL_BYTES / 2)};
   CK(hipMemcpy(W1, hW1.data(), hW1.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(W2, hW2.data(), hW2.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(b1, hb1.data(), 4 * C * 4, hipMemcpyHostToDevice));
@@ -158,8 +127,6 @@ template <int C> static int run(int batch, int iters) {
   CK(hipMemcpy(sc, hsc.data(), C * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(Y, hY.data(), hY.size() * 2, hipMemcpyHostToDevice));
   {
-    const int units = RcGeom<C>::NCH * RcGeom<C>::PIECES * 64;
-    hipLaunchKernelGGL(pk_mlp_rc, dim3((units + 255) / 256), dim3(256), 0, 0, W1, b1, W2, C, WS);
     for (int nck = 1; nck <= 2; ++nck) {
       const int u2 = (C / 8) * (C / 8 + 1) * 64;
       hipLaunchKernelGGL(pk_mlp_rc2, dim3((u2 + 255) / 256), dim3(256), 0, 0, W1, b1, W2, b2, sc, C, nck, WS2[nck]);
@@ -180,10 +147,10 @@ template <int C> static int run(int batch, int iters) {
   int bad = 0;
   for (auto& v : vs) {
     CK(hipMemcpy(X, hX.data(), (size_t)(Mc + 64) * C * 4, hipMemcpyHostToDevice));
-    if (v.run(Y, WS2[v.pack], b2, sc, X, Mc, 0) != CN_OK) return 1;
+    if (v.run(Y, WS2[v.pack], X, Mc, 0) != CN_OK) return 1;
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(hgot.data(), X, hgot.size() * 4, hipMemcpyDeviceToHost));
-    const std::vector<float>& href = v.pack ? href1 : href0;
+    const std::vector<float>& href = href1;  // LayerScale folded into the bf16 W2 operand
     double max_err = 0, sum_err = 0, max_ref = 0;
     size_t n_bad = 0;
     for (size_t i = 0; i < href.size(); ++i) {
@@ -209,9 +176,9 @@ template <int C> static int run(int batch, int iters) {
   const double flops = 16.0 * C * C * (double)M;
   for (int round = 0; round < 5; ++round)
     for (size_t vi = 0; vi < vs.size(); ++vi) {
-      vs[vi].run(Y, WS2[vs[vi].pack], b2, sc, X, M, 0);  // warm
+      vs[vi].run(Y, WS2[vs[vi].pack], X, M, 0);  // warm
       CK(hipEventRecord(e0, 0));
-      for (int it = 0; it < iters; ++it) vs[vi].run(Y, WS2[vs[vi].pack], b2, sc, X, M, 0);
+      for (int it = 0; it < iters; ++it) vs[vi].run(Y, WS2[vs[vi].pack], X, M, 0);
       CK(hipEventRecord(e1, 0));
       CK(hipEventSynchronize(e1));
       float ms;
