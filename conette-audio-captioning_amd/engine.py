@@ -224,9 +224,11 @@ class Engine:
         return out
 
     # ---- a2-a7 -----------------------------------------------------------------------------
-    def encode(self, wave: torch.Tensor, taps=False, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+    def encode(self, wave: torch.Tensor, taps=False, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+               slot: int = 0):
         """wave (B, L) fp32 on device -> frame_embs (B, T, 768), clip_probs (B, 527) [, taps dict].
-        ``taps="blocks"`` additionally returns the output of every ConvNeXt block ("block0" .. "block17")."""
+        ``taps="blocks"`` additionally returns the output of every ConvNeXt block ("block0" .. "block17").
+        ``slot`` selects the scratch workspace: encodes running concurrently on different streams need different slots."""
         wave = wave.to(self.device, torch.float32).contiguous()
         b, l = wave.shape
         f, hs, ws_ = encoder_geometry(l)
@@ -237,7 +239,7 @@ class Engine:
         else:
             frame_embs, clip = out
         need = self.lib.conette_encode_workspace_bytes(self._ctx, b, l)
-        wsb = self._workspace("enc", need)
+        wsb = self._workspace("enc" if slot == 0 else f"enc{slot}", need)
         tap_struct, tap_out = None, None
         if taps:
             dims = (96, 192, 384, 768)
