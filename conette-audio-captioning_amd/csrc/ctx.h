@@ -102,6 +102,7 @@ struct conette_ctx {
   const float* cls_b;
   int n_cu;  // compute units of the device the context lives on (persistent-kernel grids)
   int enc_reserved_cus;  // CONETTE_OPT_ENCODE_RESERVED_CUS
+  int forcing_stepwise;  // CONETTE_OPT_FORCING_STEPWISE
   // arena
   char* arena;
   size_t arena_bytes;

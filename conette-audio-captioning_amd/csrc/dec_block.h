@@ -244,7 +244,8 @@ __global__ __launch_bounds__(512, 1) void cn_dec_block_kernel(
     const bf16_t* __restrict__ kvx, int kv_ld, int kv_off, const int* __restrict__ lens, int Ta,  // cross K/V
     float* __restrict__ x /* in: previous layer's x2 (residual of its FFN), out: x2 */, bf16_t* __restrict__ xt,
     float scale, const unsigned long long* __restrict__ kvalid /* teacher forcing: non-pad caption positions */,
-    int dbg) {
+    int dbg, const int* __restrict__ gate /* rows still searching at this step (device counter) or null */) {
+  if (gate != nullptr && *gate == 0) return;  // every hypothesis has finished (beam.py:192-194 stops here)
   typedef G2Geom<256> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem + DB_OFF_A;

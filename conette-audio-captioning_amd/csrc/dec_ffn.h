@@ -23,7 +23,8 @@
 __global__ __launch_bounds__(256, 1) void cn_dec_ffn_kernel(const bf16_t* __restrict__ xt, int R,
                                                             const bf16_t* __restrict__ stream /* [chunk][2][...] */,
                                                             const float* __restrict__ b1, float* __restrict__ slabs,
-                                                            size_t slab_stride) {
+                                                            size_t slab_stride, const int* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;  // nothing left to decode at this step
   typedef G2Geom<256> G;
   __shared__ __attribute__((aligned(16))) char smem[DF_LDS_BYTES];
   char* sX = smem;                       // x tile, 32 rows x 512 B, chunk-swizzled

@@ -33,9 +33,10 @@ __global__ void cn_cvt_kernel(const float* __restrict__ in, T* __restrict__ out,
 __global__ void cn_init_state_kernel(int B, int beam, int maxp, const int* __restrict__ bos, int* n_active, int* slot,
                                      float* sum_lp, int* prefix, int* anc, int* cur_tok, int* out_preds,
                                      float* out_avg, int* out_len, int* sizes, int pad_id, int* trace_sel,
-                                     float* trace_val) {
+                                     float* trace_val, int* live) {
   const int R = B * beam;
   const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+  for (int i = gid; i < CN_MAX_PRED + 2; i += gsz) live[i] = 0;
   for (int i = gid; i < B; i += gsz) n_active[i] = beam;
   for (int i = gid; i < R; i += gsz) {
     slot[i] = i % beam;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void cn_search_step_kernel(float* __restrict__
                                                              const uint8_t* __restrict__ forbid, int* n_active,
                                                              int* slot, float* sum_lp, int* prefix, int* anc,
                                                              int* cur_tok, int* out_preds, float* out_avg,
-                                                             int* out_len, int* trace_sel, float* trace_val) {
+                                                             int* out_len, int* trace_sel, float* trace_val, int* live) {
   __shared__ float s_red[8];
   __shared__ ValIdx s_vi[4];
   __shared__ float s_mx[CN_MAX_BEAM], s_lg[CN_MAX_BEAM], s_base[CN_MAX_BEAM];
@@ -379,6 +380,7 @@ __global__ __launch_bounds__(256) void cn_search_step_kernel(float* __restrict__
       s_newpos[c] = fin ? -1 : cnt++;
     }
     n_active[b] = cnt;
+    if (cnt > 0) atomicAdd(&live[step + 1], cnt);  // rows that search on: gates the next step's kernels
   }
   __syncthreads();
   for (int c = 0; c < k; ++c) {
@@ -425,7 +427,8 @@ __global__ __launch_bounds__(S3_T) void cn_search_step3_kernel(const float* __re
                                                                const uint8_t* __restrict__ forbid, int* n_active,
                                                                int* slot, float* sum_lp, int* prefix, int* anc,
                                                                int* cur_tok, int* out_preds, float* out_avg,
-                                                               int* out_len, int* trace_sel, float* trace_val, int dbg) {
+                                                               int* out_len, int* trace_sel, float* trace_val, int dbg,
+                                                               int* live) {
   __shared__ float s_redm[NR][16], s_reds[NR][16];
   __shared__ ValIdx s_cand[16][CN_MAX_BEAM];
   __shared__ float s_base[CN_MAX_BEAM];
@@ -615,6 +618,7 @@ __global__ __launch_bounds__(S3_T) void cn_search_step3_kernel(const float* __re
       s_newpos[c] = fin ? -1 : cnt++;
     }
     n_active[b] = cnt;
+    if (cnt > 0) atomicAdd(&live[step + 1], cnt);  // rows that search on: gates the next step's kernels
   }
   __syncthreads();
   for (int c = 0; c < k; ++c) {
@@ -745,6 +749,7 @@ struct DecWs {
   void *fe_t, *mem, *kvc, *xt, *attn_t, *ffh, *kc, *vc;
   float *x, *x2, *qkv, *q, *tmp, *logits, *slabs;
   int *n_active, *slot, *prefix, *anc, *cur_tok, *out_len, *eos_idx;
+  int* live;  // [CN_MAX_PRED + 2] rows still searching when step s starts (summed by the search step of s - 1)
   unsigned long long* kvalid;  // teacher forcing: bit s of row r = caption position s is not padding
   float* sum_lp;
   int ldv;
@@ -778,6 +783,7 @@ static DecWs dec_ws(const conette_ctx* ctx, int B, int Ta, int beam, int maxp, c
   w.kc = take((size_t)NL * maxp * R * d * es);
   w.vc = take((size_t)NL * maxp * R * d * es);
   w.n_active = (int*)take((size_t)B * 4);
+  w.live = (int*)take((size_t)(CN_MAX_PRED + 2) * 4);
   w.slot = (int*)take((size_t)R * 4);
   w.sum_lp = (float*)take((size_t)R * 4);
   w.prefix = (int*)take((size_t)R * (maxp + 1) * 4);
@@ -831,7 +837,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
   }
   hipLaunchKernelGGL(cn_init_state_kernel, dim3(64), dim3(256), 0, s, B, beam, maxp, bos_ids, w.n_active, w.slot,
                      w.sum_lp, w.prefix, w.anc, w.cur_tok, mult_preds, mult_lprobs, w.out_len, out_sizes, cfg.pad_id,
-                     trace_sel, trace_val);
+                     trace_sel, trace_val, w.live);
   CN_LAUNCH_CHECK();
   if (forcing) {
     hipLaunchKernelGGL(cn_force_init_kernel, dim3(cn_cdiv(B, 64)), dim3(64), 0, s, force_caps, B, maxp, cfg.pad_id,
@@ -845,6 +851,10 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
       CN_LAUNCH_CHECK();
     }
     const bool block_path = std::is_same<T, bf16_t>::value && !ctx->dec_unfused;
+    // device-side early exit: once every hypothesis of every clip has finished the reference leaves its loop
+    // (beam.py:192-194); the launch sequence is static (hipGraph), so the heavy kernels of the remaining steps read the
+    // number of rows still searching and return at once
+    const int* gate = (!forcing && step > 0) ? w.live + step : nullptr;
     if (!block_path) {  // (the block path embeds in the prologue of layer 0's block kernel)
       hipLaunchKernelGGL((cn_embed_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.cur_tok, ctx->emb, ctx->pe, step, R,
                          sqrtf((float)d), w.x, xt);
@@ -886,13 +896,13 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
           CN_TRY(cn_dec_block_setup());
           hipLaunchKernelGGL(cn_dec_block_kernel, dim3(cn_cdiv(R, DB_ROWS)), dim3(512), DB_LDS_BYTES, s, pro, wt, kc, vc,
                              w.anc, step, R, beam, maxp, (const bf16_t*)kvc, kv_ld, l * 2 * d, frame_lens, Ta, w.x, xt,
-                             scale, kvalid, db_debug);
+                             scale, kvalid, db_debug, gate);
           CN_LAUNCH_CHECK();
         }
         if (ffn_fused) {
           CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
           hipLaunchKernelGGL(cn_dec_ffn_kernel, dim3(cn_cdiv(R, DF_ROWS), dff / 256), dim3(256), 0, s, (const bf16_t*)xt, R,
-                             (const bf16_t*)lw.ffn_w, lw.ff1_b, w.slabs, slab);
+                             (const bf16_t*)lw.ffn_w, lw.ff1_b, w.slabs, slab, gate);
           CN_LAUNCH_CHECK();
         } else {
           {
@@ -1023,7 +1033,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
 #define S3_LAUNCH(NR_, VPT_)                                                                                          \
   hipLaunchKernelGGL((cn_search_step3_kernel<NR_, VPT_>), dim3(B), dim3(S3_T), 0, s, w.logits, w.ldv, V, beam, maxp,  \
                      step, min_pred, cfg.eos_id, forbid, w.n_active, w.slot, w.sum_lp, w.prefix, w.anc, w.cur_tok,    \
-                     mult_preds, mult_lprobs, w.out_len, trace_sel, trace_val, db_debug)
+                     mult_preds, mult_lprobs, w.out_len, trace_sel, trace_val, db_debug, w.live)
       const int vpt = cn_cdiv(V, S3_T);
       if (beam <= 4) {
         if (vpt <= 2) S3_LAUNCH(4, 2);
@@ -1038,7 +1048,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
     } else {  // vocabularies beyond 8192 entries: the generic step (masking in place, top-k over global memory)
       hipLaunchKernelGGL(cn_search_step_kernel, dim3(B), dim3(256), 0, s, w.logits, w.ldv, V, beam, maxp, step,
                          min_pred, cfg.eos_id, forbid, w.n_active, w.slot, w.sum_lp, w.prefix, w.anc, w.cur_tok,
-                         mult_preds, mult_lprobs, w.out_len, trace_sel, trace_val);
+                         mult_preds, mult_lprobs, w.out_len, trace_sel, trace_val, w.live);
     }
     CN_LAUNCH_CHECK();
   }
@@ -1107,6 +1117,10 @@ extern "C" int conette_set_option(conette_ctx* ctx, int32_t option, int32_t valu
         }
       c->n = 0;
     }
+    return CN_OK;
+  }
+  if (option == CONETTE_OPT_FORCING_STEPWISE) {
+    ctx->forcing_stepwise = value ? 1 : 0;
     return CN_OK;
   }
   if (option == CONETTE_OPT_ENCODE_RESERVED_CUS) {
@@ -1224,12 +1238,161 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
   return CN_OK;
 }
 
+// ---- teacher forcing as ONE causal pass (nn/decoding/forcing.py:12-71 is a single decoder forward over the caption) ----
+// Rows r = clip * cap_len + position: every GEMM of the layer runs once on all B * cap_len rows (the unfused per-sub-layer
+// kernels of the step path with M = B * cap_len), the cross-attention kernel is reused with "beam" = cap_len, and the
+// self-attention reads the K / V of the clip's earlier positions from this pass's own QKV output -- at cache precision
+// (rounded to the operand type exactly as the step path stores and re-reads them), masked to valid (non-pad) keys <= t.
+template <typename T>
+__global__ __launch_bounds__(256) void cn_embed_caps_kernel(const int32_t* __restrict__ caps, const float* __restrict__ emb,
+                                                            const float* __restrict__ pe, int cap_len, int R, float scale,
+                                                            float* __restrict__ x, T* __restrict__ xt) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const int t = r % cap_len;
+  const f32x4 e = *(const f32x4*)(emb + (size_t)caps[r] * 256 + 4 * lane);
+  const f32x4 p = *(const f32x4*)(pe + (size_t)t * 256 + 4 * lane);
+  f32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = e[i] * scale + p[i];
+  *(f32x4*)(x + (size_t)r * 256 + 4 * lane) = o;
+  cn_store4(xt + (size_t)r * 256 + 4 * lane, o[0], o[1], o[2], o[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cn_self_attn_causal_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ caps,
+                                                                  int cap_len, int R, int pad_id, float scale,
+                                                                  T* __restrict__ out) {
+  constexpr int NB = 8;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const int b = r / cap_len, t = r % cap_len;
+  f32x4 q = *(const f32x4*)(qkv + (size_t)r * 768 + 4 * lane);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] *= scale;
+  const float* base = qkv + (size_t)b * cap_len * 768 + 256 + 4 * lane;
+  const int32_t* cap = caps + (size_t)b * cap_len;
+  float m = -INFINITY, l = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; s0 <= t; s0 += NB) {
+    f32x4 kk[NB], vv[NB];
+    float sc[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int sidx = min(s0 + u, t);
+      const f32x4 k4 = *(const f32x4*)(base + (size_t)sidx * 768), v4 = *(const f32x4*)(base + (size_t)sidx * 768 + 256);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {  // cache precision
+        kk[u][i] = cn_to_f32(cn_from_f32<T>(k4[i]));
+        vv[u][i] = cn_to_f32(cn_from_f32<T>(v4[i]));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) sc[u] = (s0 + u <= t && cap[min(s0 + u, t)] != pad_id) ? cn_dot8(q, kk[u]) : -INFINITY;
+    cn_attn_update<NB>(sc, vv, m, l, acc);
+  }
+  const float inv = 1.0f / l;
+  cn_store4(out + (size_t)r * 256 + 4 * lane, acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+}
+
+template <typename T>
+static int forcing_prefill_impl(conette_ctx* ctx, const float* frame_embs, const int32_t* frame_lens, const int32_t* caps,
+                                int B, int Ta, int cap_len, float* logits, char* wsp, hipStream_t s) {
+  const conette_config& cfg = ctx->cfg;
+  const int d = cfg.d_model, NL = cfg.n_layers, R = B * cap_len, V = cfg.vocab_size, dff = cfg.d_ff;
+  DecWs w = dec_ws(ctx, B, Ta, cap_len, 1, wsp);  // rows = B * cap_len ("beam" = cap_len, one step)
+  T* fe_t = (T*)w.fe_t;
+  T* mem = (T*)w.mem;
+  T* kvc = (T*)w.kvc;
+  T* xt = (T*)w.xt;
+  T* attn_t = (T*)w.attn_t;
+  T* ffh = (T*)w.ffh;
+  const int kv_ld = NL * 2 * d;
+  const float scale = 1.0f / sqrtf((float)(d / cfg.nhead));
+  const int rblocks = cn_cdiv(R, 4);
+  {
+    CnProfScope ps(ctx, CONETTE_PROF_DEC_PREPARE, s);
+    const size_t n = (size_t)B * Ta * CN_FEAT;
+    hipLaunchKernelGGL((cn_cvt_kernel<T>), dim3((unsigned)((n + 1023) / 1024 < 4096 ? (n + 1023) / 1024 : 4096)), dim3(256), 0, s,
+                       frame_embs, fe_t, n);
+    CN_LAUNCH_CHECK();
+    EpiBiasAct<T, ACT_RELU> ep{ctx->proj_b, mem, d, ACT_RELU};
+    CN_TRY(cn_mm(fe_t, CN_FEAT, (const T*)ctx->proj_w, CN_FEAT, B * Ta, d, CN_FEAT, ep, s));
+    EpiBiasAct<T, ACT_NONE> ekv{ctx->kv_b, kvc, kv_ld, ACT_NONE};
+    CN_TRY(cn_mm(mem, d, (const T*)ctx->kv_w, d, B * Ta, kv_ld, d, ekv, s));
+  }
+  hipLaunchKernelGGL((cn_embed_caps_kernel<T>), dim3(rblocks), dim3(256), 0, s, caps, ctx->emb, ctx->pe, cap_len, R,
+                     sqrtf((float)d), w.x, xt);
+  CN_LAUNCH_CHECK();
+  for (int l = 0; l < NL; ++l) {
+    const CnLayerW& lw = ctx->layers[l];
+    {
+      CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+      EpiBiasAct<float, ACT_NONE> eq{lw.sa_in_b, w.qkv, 3 * d, ACT_NONE};
+      CN_TRY(cn_mm(xt, d, (const T*)lw.sa_in_w, d, R, 3 * d, d, eq, s));
+    }
+    {
+      CnProfScope ps(ctx, CONETTE_PROF_DEC_ATTN, s);
+      hipLaunchKernelGGL((cn_self_attn_causal_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.qkv, caps, cap_len, R, cfg.pad_id,
+                         scale, attn_t);
+      CN_LAUNCH_CHECK();
+    }
+    {
+      CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+      EpiResid eo{lw.sa_out_b, nullptr, w.x, w.tmp, d};
+      CN_TRY(cn_mm(attn_t, d, (const T*)lw.sa_out_w, d, R, d, d, eo, s));
+    }
+    hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, 1, (size_t)0, (const float*)nullptr,
+                       (const float*)nullptr, lw.n1w, lw.n1b, R, w.x, xt);
+    CN_LAUNCH_CHECK();
+    {
+      CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+      EpiBiasAct<float, ACT_NONE> ecq{lw.ca_q_b, w.q, d, ACT_NONE};
+      CN_TRY(cn_mm(xt, d, (const T*)lw.ca_q_w, d, R, d, d, ecq, s));
+    }
+    {
+      CnProfScope ps(ctx, CONETTE_PROF_DEC_ATTN, s);
+      hipLaunchKernelGGL((cn_cross_attn_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.q, kvc, kv_ld, l * 2 * d, frame_lens, R,
+                         cap_len, Ta, scale, attn_t);
+      CN_LAUNCH_CHECK();
+    }
+    {
+      CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+      EpiResid eco{lw.ca_out_b, nullptr, w.x, w.tmp, d};
+      CN_TRY(cn_mm(attn_t, d, (const T*)lw.ca_out_w, d, R, d, d, eco, s));
+    }
+    hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, 1, (size_t)0, (const float*)nullptr,
+                       (const float*)nullptr, lw.n2w, lw.n2b, R, w.x, xt);
+    CN_LAUNCH_CHECK();
+    {
+      CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+      EpiBiasAct<T> e1{lw.ff1_b, ffh, dff, std::is_same<T, bf16_t>::value ? ACT_GELU_FAST : ACT_GELU};
+      CN_TRY(cn_mm(xt, d, (const T*)lw.ff1_w, d, R, dff, d, e1, s));
+    }
+    {
+      CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+      EpiResid e2{lw.ff2_b, nullptr, w.x, w.tmp, d};
+      CN_TRY(cn_mm(ffh, dff, (const T*)lw.ff2_w, dff, R, d, dff, e2, s));
+    }
+    hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.tmp, 1, (size_t)0, (const float*)nullptr,
+                       (const float*)nullptr, lw.n3w, lw.n3b, R, w.x, xt);
+    CN_LAUNCH_CHECK();
+  }
+  CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+  EpiBiasAct<float, ACT_NONE> ec{ctx->cls_b, logits, V, ACT_NONE};  // (B, cap_len, V) written in place
+  CN_TRY(cn_mm(xt, d, (const T*)ctx->cls_w, d, R, V, d, ec, s));
+  return CN_OK;
+}
+
 extern "C" size_t conette_forcing_workspace_bytes(const conette_ctx* ctx, int32_t batch, int32_t t_audio,
                                                   int32_t cap_len) {
   if (!ctx || batch <= 0 || t_audio <= 0 || cap_len <= 0) return 0;
-  // decode workspace at beam 1 + the int32 scratch the search bookkeeping of a normal decode writes into
-  return conette_decode_workspace_bytes(ctx, batch, t_audio, 1, cap_len) + cn_align((size_t)batch * cap_len * 8) +
-         cn_align((size_t)batch * 16);
+  // step path: decode workspace at beam 1 + the int32 scratch the search bookkeeping of a normal decode writes into;
+  // one-pass path: the same buffers laid out for B * cap_len rows
+  const size_t stepwise = conette_decode_workspace_bytes(ctx, batch, t_audio, 1, cap_len) + cn_align((size_t)batch * cap_len * 8) +
+                          cn_align((size_t)batch * 16);
+  const size_t onepass = dec_ws(ctx, batch, t_audio, cap_len, 1, nullptr).total;
+  return stepwise > onepass ? stepwise : onepass;
 }
 
 extern "C" int conette_forcing(conette_ctx* ctx, const float* frame_embs, const int32_t* frame_lens,
@@ -1253,6 +1416,13 @@ extern "C" int conette_forcing(conette_ctx* ctx, const float* frame_embs, const 
     return CN_ERR_WORKSPACE;
   }
   hipStream_t s = (hipStream_t)stream;
+  if (!ctx->forcing_stepwise) {  // default: one causal pass over all caption positions
+    if (ctx->cfg.precision == CONETTE_PREC_BF16)
+      return forcing_prefill_impl<bf16_t>(ctx, frame_embs, frame_lens, caps_in, batch, t_audio, cap_len, logits,
+                                          (char*)workspace, s);
+    return forcing_prefill_impl<float>(ctx, frame_embs, frame_lens, caps_in, batch, t_audio, cap_len, logits, (char*)workspace, s);
+  }
+  // CONETTE_OPT_FORCING_STEPWISE: the KV-cached step kernels fed with the caption (cross-check of the pass above)
   // outputs of the search bookkeeping that a forced pass does not produce: parked in the workspace tail
   char* tail = (char*)workspace + conette_decode_workspace_bytes(ctx, batch, t_audio, 1, cap_len);
   int32_t* mult_preds = (int32_t*)tail;

@@ -32,6 +32,7 @@ EXPORTS = (
 OPT_DECODE_GRAPH = 1
 OPT_DECODE_FUSION = 2
 OPT_ENCODE_RESERVED_CUS = 3
+OPT_FORCING_STEPWISE = 4
 PROF_CLASSES = ("frontend", "stem", "dwconv_ln", "pw1_gemm", "pw2_gemm", "downsample", "heads", "dec_prepare",
                 "dec_gemm", "dec_attn", "dec_misc", "search")
 
@@ -380,6 +381,10 @@ class Engine:
     def set_decode_fusion(self, enabled: bool) -> None:
         """bf16: fused decoder-layer kernels (default) or one launch per sub-layer (cross-check path)."""
         _check(self.lib.conette_set_option(self._ctx, OPT_DECODE_FUSION, int(bool(enabled))), "set_option")
+
+    def set_forcing_stepwise(self, enabled: bool) -> None:
+        """Teacher forcing through the KV-cached step kernels (cross-check) instead of the one-pass kernels (default)."""
+        _check(self.lib.conette_set_option(self._ctx, OPT_FORCING_STEPWISE, int(bool(enabled))), "set_option")
 
     def set_encode_reserved_cus(self, n: int) -> None:
         """Compute units the encoder's persistent kernels leave free for a decode running on another stream."""

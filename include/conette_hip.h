@@ -157,6 +157,8 @@ int conette_stream_destroy(void* stream);
 #define CONETTE_OPT_ENCODE_RESERVED_CUS 3 /* default 0: compute units the encoder's persistent kernels leave free, so that
                                             the small dependent kernels of a conette_decode running on another stream are
                                             not queued behind them (0 .. n_cu / 2) */
+#define CONETTE_OPT_FORCING_STEPWISE 4 /* default 0: conette_forcing is one causal pass over all caption positions
+                                         (forcing.py:12-71); 1: the KV-cached step kernels fed with the caption */
 int conette_set_option(conette_ctx* ctx, int32_t option, int32_t value);
 
 /* Per-kernel-class timing with HIP events recorded on the caller's stream around each launch

@@ -97,10 +97,12 @@ def test_encoder_at_256_clips(eng_bf16):
     np.testing.assert_allclose(fe8.cpu().numpy(), g["frame_embs"], atol=0.06)
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_teacher_forcing_against_bf16_operand_oracle(fused, eng_bf16, synth_weights):
-    """cn_dec_block_kernel + cn_dec_ffn_kernel (fused = True) and the one-launch-per-sub-layer kernels (False) against the
-    bf16-operand decoder oracle on the full (B, V, cap_len) logits of the ragged forcing fixture's inputs."""
+@pytest.mark.parametrize("mode", ["step_fused", "step_unfused", "onepass"])
+def test_teacher_forcing_against_bf16_operand_oracle(mode, eng_bf16, synth_weights):
+    """cn_dec_block_kernel + cn_dec_ffn_kernel (step_fused), the one-launch-per-sub-layer step kernels (step_unfused) and the
+    one-pass kernels (onepass) against the bf16-operand decoder oracle on the full (B, V, cap_len) logits of the ragged
+    forcing fixture's inputs."""
+    fused = mode == "step_fused"
     from oracle import bf16_ref as Bf
     g = np.load(os.path.join(G.GOLDEN, "forcing", "forcing_ragged.npz"))
     fe = torch.from_numpy(g["frame_embs"])
@@ -108,13 +110,15 @@ def test_teacher_forcing_against_bf16_operand_oracle(fused, eng_bf16, synth_weig
     caps = torch.from_numpy(g["caps_in"]).long()
     ref = Bf.teacher_forcing_bf16(synth_weights, fe, shp, caps).numpy()
     eng_bf16.set_decode_fusion(fused)
+    eng_bf16.set_forcing_stepwise(mode != "onepass")
     try:
         got = eng_bf16.forcing(fe.cuda(), shp[:, 1].int(), caps).permute(0, 2, 1).cpu().numpy()
     finally:
         eng_bf16.set_decode_fusion(True)
+        eng_bf16.set_forcing_stepwise(False)
     valid = (g["caps_in"] != 0)[:, None, :]                      # padded query positions carry no information
     err = np.abs(got - ref) * valid
-    print("forcing fused =", fused, "max", err.max(), "mean", err.mean())
+    print("forcing", mode, "max", err.max(), "mean", err.mean())
     np.testing.assert_allclose(got * valid, ref * valid, rtol=3e-3, atol=0.15)
     assert err.mean() < 0.03
     # and the oracle itself sits at bf16 distance from the reference's fp32 logits
@@ -145,11 +149,12 @@ def test_decoder_layer_against_bf16_operand_oracle(layer, synth_weights):
     caps = torch.from_numpy(g["caps_in"]).long()
     ref = Bf.teacher_forcing_bf16(sd, fe, shp, caps, n_layers=1).numpy()
     valid = (g["caps_in"] != 0)[:, None, :]
-    for fused in (True, False):
-        eng.set_decode_fusion(fused)
+    for mode in ("step_fused", "step_unfused", "onepass"):
+        eng.set_decode_fusion(mode == "step_fused")
+        eng.set_forcing_stepwise(mode != "onepass")
         got = eng.forcing(fe.cuda(), shp[:, 1].int(), caps).permute(0, 2, 1).cpu().numpy()
         err = np.abs(got - ref) * valid
-        print(f"layer {layer} fused={fused}: max {err.max():.4f} mean {err.mean():.5f}")
+        print(f"layer {layer} {mode}: max {err.max():.4f} mean {err.mean():.5f}")
         np.testing.assert_allclose(got * valid, ref * valid, rtol=3e-3, atol=0.1)
         assert err.mean() < 2e-3, err.mean()
 

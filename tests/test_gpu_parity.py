@@ -182,7 +182,11 @@ def test_topk_decisions_at_reference_states(name, prec, engines, synth_weights, 
     fe = torch.from_numpy(g["frame_embs"])[rows_clip].cuda()
     lens = torch.from_numpy(g["audio_shape"][:, 1].astype(np.int32))[rows_clip]
     caps = torch.as_tensor(rows_caps, dtype=torch.int64)
-    logits = eng.forcing(fe, lens, caps).cpu()                        # (rows, max_pred, V)
+    eng.set_forcing_stepwise(True)   # the KV-cached step kernels the search itself runs (fused block / FFN kernels in bf16)
+    try:
+        logits = eng.forcing(fe, lens, caps).cpu()                    # (rows, max_pred, V)
+    finally:
+        eng.set_forcing_stepwise(False)
     tol = 5e-4 if prec == "fp32" else 0.25
     n_checked = n_same = 0
     for (r0, n_rows, sm), (step, clip, par, tok, sums, margin) in zip(items, calls):
@@ -215,6 +219,34 @@ def test_topk_decisions_at_reference_states(name, prec, engines, synth_weights, 
     assert n_same >= MIN_SAME[prec] * len(calls), (n_same, len(calls))
 
 
+def test_one_pass_forcing_is_faster_than_stepwise(engines):
+    """the one-pass teacher forcing must beat the cap_len dependent steps by a wide margin at cap_len 20."""
+    eng = engines["bf16"]
+    B, T, cap = 64, 31, 20
+    g = torch.Generator().manual_seed(3)
+    fe = torch.randn((B, T, 768), generator=g).cuda()
+    lens = torch.full((B,), T, dtype=torch.int32)
+    caps = torch.randint(4, 5000, (B, cap), generator=g)
+    times = {}
+    for mode in ("onepass", "stepwise"):
+        eng.set_forcing_stepwise(mode == "stepwise")
+        try:
+            for _ in range(2):
+                out = eng.forcing(fe, lens, caps)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                out = eng.forcing(fe, lens, caps)
+            e1.record()
+            torch.cuda.synchronize()
+            times[mode] = e0.elapsed_time(e1) / 5
+        finally:
+            eng.set_forcing_stepwise(False)
+    print(f"teacher forcing B=64 cap_len=20: one pass {times['onepass']:.3f} ms, stepwise {times['stepwise']:.3f} ms")
+    assert times["onepass"] * 3 < times["stepwise"], times
+
+
 def test_frontend_against_oracle_small(engines, synth_weights):
     """Direct oracle check (DFT-as-conv restatement) on odd lengths incl. the reflect-padded edges."""
     from conette_amd import synth
@@ -238,8 +270,18 @@ def test_resample_against_oracle(engines):
         np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
 
 
+@pytest.fixture(params=["onepass", "stepwise"])
+def forcing_mode(request, engines):
+    """conette_forcing as one causal pass (default) or through the KV-cached step kernels (CONETTE_OPT_FORCING_STEPWISE)."""
+    for e in engines.values():
+        e.set_forcing_stepwise(request.param == "stepwise")
+    yield request.param
+    for e in engines.values():
+        e.set_forcing_stepwise(False)
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-def test_teacher_forcing_matches_reference_fixture(prec, engines):
+def test_teacher_forcing_matches_reference_fixture(prec, engines, forcing_mode):
     """conette_forcing against logits produced by the reference itself (all caption positions,
     padded ones included: padded positions are masked as keys exactly like tensor_to_pad_mask does)."""
     g = np.load(os.path.join(G.GOLDEN, "forcing", "forcing_ragged.npz"))
