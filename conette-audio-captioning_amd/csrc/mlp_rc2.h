@@ -232,6 +232,16 @@ template <int C, int NCK> struct Rc2Wave {
   }
 };
 
+// Grid of a persistent launch: every wave walks ceil(tiles / waves) 32-position tiles, so the launch takes that many
+// ROUNDS whatever the block count; use the fewest rounds max_blocks allows and then the SMALLEST grid that still finishes in
+// that many rounds (441 four-wave block-tiles: 208 blocks need 3 rounds, 221 need 2 and leave 35 CUs to other streams).
+static inline int cn_rc2_grid(int n_tiles, int waves_per_block, int max_blocks) {
+  const int block_tiles = cn_cdiv(n_tiles, waves_per_block);
+  if (max_blocks < 1) max_blocks = 1;
+  const int rounds = cn_cdiv(block_tiles, max_blocks);
+  return cn_cdiv(block_tiles, rounds);
+}
+
 // ---- resident variant (C = 96): the whole stream (156 KB) lives in LDS; persistent blocks; no barrier, no DMA after the fill
 template <int C, int NW, int NCK>
 __global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_resident_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ WS,
@@ -272,8 +282,7 @@ static int cn_launch_mlp_rc2_resident(const bf16_t* Y, const bf16_t* WS, float* 
   constexpr int SMEM = (int)Rc2Geom<C, NCK>::STREAM_BYTES;
   static_assert(SMEM <= 160 * 1024, "resident variant: the weight stream must fit in LDS");
   CN_TRY(cn_configure_lds((const void*)cn_mlp_rc2_resident_kernel<C, NW, NCK>, SMEM));
-  const int n_tiles = (M + 31) / 32;
-  const int grid = n_blocks < cn_cdiv(n_tiles, NW) ? n_blocks : cn_cdiv(n_tiles, NW);
+  const int grid = cn_rc2_grid((M + 31) / 32, NW, n_blocks);
   hipLaunchKernelGGL((cn_mlp_rc2_resident_kernel<C, NW, NCK>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, Y, WS, X, M);
   CN_LAUNCH_CHECK();
   return CN_OK;
@@ -370,8 +379,7 @@ static int cn_launch_mlp_rc2_ring(const bf16_t* Y, const bf16_t* WS, float* X, i
   constexpr int SMEM = NST * Rc2Geom<C, NCK>::STEP_BYTES;
   static_assert(SMEM <= 160 * 1024, "ring must fit in LDS");
   CN_TRY(cn_configure_lds((const void*)cn_mlp_rc2_ring_kernel<C, NW, NCK, NST, PROF>, SMEM));
-  const int n_tiles = (M + 31) / 32;
-  const int grid = n_blocks < cn_cdiv(n_tiles, NW) ? n_blocks : cn_cdiv(n_tiles, NW);
+  const int grid = cn_rc2_grid((M + 31) / 32, NW, n_blocks);
   hipLaunchKernelGGL((cn_mlp_rc2_ring_kernel<C, NW, NCK, NST, PROF>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, Y, WS, X, M, prof);
   CN_LAUNCH_CHECK();
   return CN_OK;
