@@ -92,6 +92,15 @@ __device__ unsigned long long g_dw_prof[8];
     t_prev = t_;                                                      \
   }
 
+// LDS tile geometry of cn_dwconv_ln_kernel: rows of PITCH words, PITCH % 4 == 0 (16-byte reads) and, where it costs at most
+// 1/4 more LDS, PITCH / 4 = PARTS (mod 16) so that the statistics pass is conflict free; otherwise the next odd chunk count.
+template <int C, int S, int TH> struct DwTile {
+  static constexpr int CT = C > 384 ? 384 : C, NPOS = TH * 4 * S, PARTS = CT * S / NPOS, NCHUNK = C / 4;
+  static constexpr int want = NCHUNK + ((PARTS % 16) - (NCHUNK % 16) + 16) % 16;   // smallest >= NCHUNK, = PARTS (mod 16)
+  static constexpr int PITCH4 = (want * 4 <= NCHUNK * 5) ? want : (NCHUNK | 1);
+  static constexpr int PITCH = PITCH4 * 4;
+};
+
 template <typename T, int C, int S, int TH>
 __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(const float* __restrict__ x, int H, int W, int tiles_h,
                                                             int tiles_w, const float* __restrict__ dw_w /*[49][C]*/,
@@ -104,7 +113,7 @@ __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(c
   unsigned long long t_prev = dbg ? clock64() : 0;
   constexpr int NP = TH * 4;      // positions per thread
   constexpr int CT = C > 384 ? 384 : C;  // threads along the channel axis (C = 768: two passes)
-  constexpr int PITCH = C + 1;           // LDS tile pitch: rows of C floats would all start on bank 0
+  constexpr int PITCH = DwTile<C, S, TH>::PITCH;  // LDS tile pitch (words): 16-byte aligned rows, see DwTile
   const int tid = threadIdx.x;
   const int c0 = tid % CT, sidx = tid / CT;
   int bid = cn_xcd_remap(blockIdx.x, gridDim.x);
@@ -204,17 +213,25 @@ __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(c
   // partial sums through LDS).  Phase B: normalise + store with the conv mapping (lanes = channels,
   // coalesced).  (One wave per position with shuffle reductions was a serial latency chain that took
   // longer than the convolution itself.)
-  constexpr int NPOS = NP * S, NT = CT * S, PARTS = NT / NPOS, CPP = C / PARTS;
-  static_assert(NT % NPOS == 0 && C % PARTS == 0, "LayerNorm thread mapping");
+  // A thread sums the 16-byte chunks part, part + PARTS, ... of its position's row: the PARTS threads of a position read
+  // consecutive chunks and, with PITCH / 4 = PARTS (mod 16), consecutive positions continue the sequence, so a
+  // ds_read_b128 wave access is bank-conflict free (rocprof r02_a: SQ_LDS_BANK_CONFLICT was 57-75 % of the LDS cycles and the
+  // LDS active for 59 % of the kernel at C = 192 with contiguous per-thread segments and 4-byte reads).
+  constexpr int NPOS = NP * S, NT = CT * S, PARTS = NT / NPOS, NCHUNK = C / 4, CPT = NCHUNK / PARTS;
+  static_assert(NT % NPOS == 0 && NCHUNK % PARTS == 0, "LayerNorm thread mapping");
   float* s_ps = s_v + NPOS * PITCH;       // [NPOS][PARTS]
   float* s_mean = s_ps + NPOS * PARTS;    // [NPOS]
   float* s_rstd = s_mean + NPOS;          // [NPOS]
   {
     const int pos = tid / PARTS, part = tid % PARTS;
-    const float* row = s_v + pos * PITCH + part * CPP;
+    const float* row = s_v + pos * PITCH + part * 4;
+    f32x4 seg[CPT];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < CPP; ++i) sum += row[i];
+    for (int i = 0; i < CPT; ++i) {
+      seg[i] = *(const f32x4*)(row + i * PARTS * 4);
+      sum += (seg[i][0] + seg[i][1]) + (seg[i][2] + seg[i][3]);
+    }
     s_ps[pos * PARTS + part] = sum;
     __syncthreads();
     float mean = 0.f;
@@ -223,10 +240,12 @@ __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(c
     mean *= (1.0f / C);
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < CPP; ++i) {
-      const float d = row[i] - mean;
-      sq = fmaf(d, d, sq);
-    }
+    for (int i = 0; i < CPT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = seg[i][e] - mean;
+        sq = fmaf(d, d, sq);
+      }
     __syncthreads();
     s_ps[pos * PARTS + part] = sq;
     __syncthreads();
@@ -249,11 +268,11 @@ __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(c
     const int h = h0 + oh, w = tw * (4 * S) + ps * 4 + ow;
     if (h >= H || w >= W) continue;
     const float mean = s_mean[pos], rstd = s_rstd[pos];
-    const float* src = s_v + pos * PITCH + c8;
+    const f32x4 v0 = *(const f32x4*)(s_v + pos * PITCH + c8), v1 = *(const f32x4*)(s_v + pos * PITCH + c8 + 4);
     T* dst = y + (((size_t)b * H + h) * W + w) * C + c8;
     float o[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (src[i] - mean) * rstd * ln_w[c8 + i] + ln_b[c8 + i];
+    for (int i = 0; i < 8; ++i) o[i] = ((i < 4 ? v0[i] : v1[i - 4]) - mean) * rstd * ln_w[c8 + i] + ln_b[c8 + i];
     cn_store4(dst, o[0], o[1], o[2], o[3]);
     cn_store4(dst + 4, o[4], o[5], o[6], o[7]);
   }
@@ -282,7 +301,7 @@ template <typename T, int C, int S, int TH>
 static int launch_dwconv(const float* x, int B, int H, int W, const CnBlockW& bw, T* y, hipStream_t s) {
   const int tiles_h = cn_cdiv(H, TH), tiles_w = cn_cdiv(W, 4 * S);
   constexpr int NPOS_ = TH * 4 * S, NT_ = (C > 384 ? 384 : C) * S;
-  const size_t smem = ((size_t)NPOS_ * (C + 1) + NPOS_ * (NT_ / NPOS_) + 2 * NPOS_) * sizeof(float);
+  const size_t smem = ((size_t)NPOS_ * DwTile<C, S, TH>::PITCH + NPOS_ * (NT_ / NPOS_) + 2 * NPOS_) * sizeof(float);
   CN_TRY(cn_configure_lds((const void*)cn_dwconv_ln_kernel<T, C, S, TH>, (int)smem));
   hipLaunchKernelGGL((cn_dwconv_ln_kernel<T, C, S, TH>), dim3((unsigned)(B * tiles_h * tiles_w)),
                      dim3((C > 384 ? 384 : C) * S), smem, s, x, H, W, tiles_h, tiles_w, bw.dw_w, bw.dw_b, bw.ln_w, bw.ln_b, y,
@@ -314,7 +333,7 @@ __global__ __launch_bounds__(384) void cn_dwconv_ln_fw_kernel(const float* __res
                                                               const float* __restrict__ ln_b, T* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* s_v = (float*)smem_raw;  // [TH*WW][C + 1]
-  constexpr int CT = 384, NPOS = TH * WW, PITCH = C + 1, NW = CT / 64;
+  constexpr int CT = 384, NPOS = TH * WW, PITCH = C + 4, NW = CT / 64;  // 16-byte aligned rows, odd chunk count
   float* s_mean = s_v + NPOS * PITCH;
   float* s_rstd = s_mean + NPOS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -411,11 +430,11 @@ __global__ __launch_bounds__(384) void cn_dwconv_ln_fw_kernel(const float* __res
     const int h = h0 + pos / WW, w = pos % WW;
     if (h >= H) continue;
     const float mean = s_mean[pos], rstd = s_rstd[pos];
-    const float* src = s_v + pos * PITCH + c8;
+    const f32x4 v0 = *(const f32x4*)(s_v + pos * PITCH + c8), v1 = *(const f32x4*)(s_v + pos * PITCH + c8 + 4);
     T* dst = y + (((size_t)b * H + h) * WW + w) * C + c8;
     float o[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (src[i] - mean) * rstd * ln_w[c8 + i] + ln_b[c8 + i];
+    for (int i = 0; i < 8; ++i) o[i] = ((i < 4 ? v0[i] : v1[i - 4]) - mean) * rstd * ln_w[c8 + i] + ln_b[c8 + i];
     cn_store4(dst, o[0], o[1], o[2], o[3]);
     cn_store4(dst + 4, o[4], o[5], o[6], o[7]);
   }
@@ -424,7 +443,7 @@ __global__ __launch_bounds__(384) void cn_dwconv_ln_fw_kernel(const float* __res
 template <typename T, int C, int WW, int TH>
 static int launch_dwconv_fw(const float* x, int B, int H, const CnBlockW& bw, T* y, hipStream_t s) {
   const int tiles_h = cn_cdiv(H, TH);
-  const size_t smem = ((size_t)TH * WW * (C + 1) + 2 * TH * WW) * sizeof(float);
+  const size_t smem = ((size_t)TH * WW * (C + 4) + 2 * TH * WW) * sizeof(float);
   CN_TRY(cn_configure_lds((const void*)cn_dwconv_ln_fw_kernel<T, C, WW, TH>, (int)smem));
   hipLaunchKernelGGL((cn_dwconv_ln_fw_kernel<T, C, WW, TH>), dim3((unsigned)(B * tiles_h)), dim3(384), smem, s, x, H,
                      tiles_h, bw.dw_w, bw.dw_b, bw.ln_w, bw.ln_b, y);
