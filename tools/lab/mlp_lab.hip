@@ -67,7 +67,7 @@ template <typename T> static T* dalloc(size_t n) {
 
 struct Variant {
   std::string name;
-  int (*run)(const bf16_t* Y, const bf16_t* WS, float* X, int M, hipStream_t s);
+  int (*run)(const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s);
   int pack = 1;  // mlp_rc2.h stream with NCK = 1 / 2
 };
 
@@ -76,25 +76,25 @@ template <int C> static std::vector<Variant> variants();
 template <> std::vector<Variant> variants<96>() {
   return {
       {"rc2_resident<96,8,nck2>",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 8, 2>(Y, WS, X, M, 256, s); }, 2},
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 8, 2>(Y, WS, X, M, nb, s); }, 2},
       {"rc2_resident<96,8,nck1>",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 8, 1>(Y, WS, X, M, 256, s); }, 1},
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 8, 1>(Y, WS, X, M, nb, s); }, 1},
       {"rc2_resident<96,12,nck1>",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 12, 1>(Y, WS, X, M, 256, s); }, 1},
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 12, 1>(Y, WS, X, M, nb, s); }, 1},
   };
 }
 template <> std::vector<Variant> variants<192>() {
   return {
       {"rc2_ring<192,8,nck1,nst5>",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, hipStream_t s) { return cn_launch_mlp_rc2_ring<192, 8, 1, 5>(Y, WS, X, M, 256, s); }, 1},
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_ring<192, 8, 1, 5>(Y, WS, X, M, nb, s); }, 1},
       {"rc2_ring<192,8,nck2,nst3>",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, hipStream_t s) { return cn_launch_mlp_rc2_ring<192, 8, 2, 3>(Y, WS, X, M, 256, s); }, 2},
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_ring<192, 8, 2, 3>(Y, WS, X, M, nb, s); }, 2},
   };
 }
 template <> std::vector<Variant> variants<384>() {
   return {
       {"rc2_ring<384,4,nck1,nst3>",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, hipStream_t s) { return cn_launch_mlp_rc2_ring<384, 4, 1, 3>(Y, WS, X, M, 256, s); }, 1},
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_ring<384, 4, 1, 3>(Y, WS, X, M, nb, s); }, 1},
   };
 }
 
@@ -145,9 +145,10 @@ template <int C> static int run(int batch, int iters) {
 
   auto vs = variants<C>();
   int bad = 0;
+  for (int nbc : {256, 5, 3})
   for (auto& v : vs) {
     CK(hipMemcpy(X, hX.data(), (size_t)(Mc + 64) * C * 4, hipMemcpyHostToDevice));
-    if (v.run(Y, WS2[v.pack], X, Mc, 0) != CN_OK) return 1;
+    if (v.run(Y, WS2[v.pack], X, Mc, nbc, 0) != CN_OK) return 1;
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(hgot.data(), X, hgot.size() * 4, hipMemcpyDeviceToHost));
     const std::vector<float>& href = href1;  // LayerScale folded into the bf16 W2 operand
@@ -162,7 +163,7 @@ template <int C> static int run(int batch, int iters) {
     }
     size_t touched = 0;  // rows beyond Mc must be untouched
     for (size_t i = href.size(); i < hgot.size(); ++i) touched += hgot[i] != hX[i];
-    printf("  check %-34s max|err| %.3e  mean %.3e  (max |delta| %.3f)  out-of-tol %zu  rows>=M touched %zu  %s\n", v.name.c_str(),
+    printf("  check nb %3d %-30s max|err| %.3e  mean %.3e  (max |delta| %.3f)  out-of-tol %zu  rows>=M touched %zu  %s\n", nbc, v.name.c_str(),
            max_err, sum_err / href.size(), max_ref, n_bad, touched, (n_bad == 0 && touched == 0) ? "OK" : "FAIL");
     bad += (n_bad != 0 || touched != 0);
   }
@@ -176,9 +177,9 @@ template <int C> static int run(int batch, int iters) {
   const double flops = 16.0 * C * C * (double)M;
   for (int round = 0; round < 5; ++round)
     for (size_t vi = 0; vi < vs.size(); ++vi) {
-      vs[vi].run(Y, WS2[vs[vi].pack], X, M, 0);  // warm
+      vs[vi].run(Y, WS2[vs[vi].pack], X, M, 256, 0);  // warm
       CK(hipEventRecord(e0, 0));
-      for (int it = 0; it < iters; ++it) vs[vi].run(Y, WS2[vs[vi].pack], X, M, 0);
+      for (int it = 0; it < iters; ++it) vs[vi].run(Y, WS2[vs[vi].pack], X, M, 256, 0);
       CK(hipEventRecord(e1, 0));
       CK(hipEventSynchronize(e1));
       float ms;
