@@ -1,5 +1,5 @@
 // Kernel lab for the fused ConvNeXt MLP kernels (development aid, not part of the product library):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I conette-audio-captioning_amd/csrc tools/lab/mlp_lab.hip -o tools/lab/mlp_lab
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DCN_RC2_GELU_PK -I conette-audio-captioning_amd/csrc -I tools/lab tools/lab/mlp_lab.hip -o tools/lab/mlp_lab
 //   tools/lab/mlp_lab [C] [batch] [iters]
 // Checks every variant against a naive bf16-operand reference kernel on a small M (full tensors), then times it on
 // the benchmark shape (batch x positions-per-clip rows) with HIP events, interleaved rounds.
@@ -11,6 +11,7 @@
 #include <algorithm>
 
 #include "mlp_rc2.h"
+#include "mlp_rc2_f8.h"
 
 void cn_set_error(const char* fmt, ...) {
   va_list ap;
@@ -51,6 +52,35 @@ __global__ void ref_out(const bf16_t* H, const float* W2, const float* b2, const
     a = fmaf((float)H[(size_t)m * 4 * C + k], (float)(bf16_t)(folded ? sc * w : w), a);
   }
   X[i] += folded ? a + sc * b2[n] : sc * (a + b2[n]);
+}
+
+
+// ---- FP8 (e4m3) variant: same quantisation points as mlp_rc2_f8.h, plain loops ----------------------------------------
+__device__ __forceinline__ float q8(float v) {
+  const int w = __builtin_amdgcn_cvt_pk_fp8_f32(v, 0.f, 0, false);
+  return __builtin_amdgcn_cvt_f32_fp8(w, 0);
+}
+__global__ void to_fp8(const float* src, unsigned char* dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(src[i], 0.f, 0, false) & 0xff);
+}
+__global__ void ref_hidden_f8(const unsigned char* Y, const float* W1, const float* b1, const float* aux, int C, int M, float* H) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)M * 4 * C) return;
+  const int m = (int)(i / (4 * C)), n = (int)(i % (4 * C));
+  const float is1 = aux[7 * C], s1 = 1.0f / is1;
+  float a = 0.f;
+  for (int k = 0; k < C; ++k) a = fmaf(__builtin_amdgcn_cvt_f32_fp8((int)Y[(size_t)m * C + k], 0), q8(s1 * W1[(size_t)n * C + k]), a);
+  H[i] = q8(cn_gelu_sig2(fmaf(a, is1, b1[n])));
+}
+__global__ void ref_out_f8(const float* H, const float* W2, const float* ls, const float* aux, int C, int M, float* X) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)M * C) return;
+  const int m = (int)(i / C), n = (int)(i % C);
+  const float f = ls[n] * aux[5 * C + n];
+  float a = X[i] * aux[5 * C + n];
+  for (int k = 0; k < 4 * C; ++k) a = fmaf(H[(size_t)m * 4 * C + k], q8(f * W2[(size_t)n * 4 * C + k]), a);
+  X[i] = fmaf(a, aux[4 * C + n], aux[6 * C + n]);
 }
 
 static uint32_t rng_state = 12345u;
@@ -205,6 +235,69 @@ template <int C> static int run(int batch, int iters) {
     const double n = (double)h[5];
     printf("  phase profile (cycles per valid wave-step, %llu wave-steps):\n", h[5]);
     for (int i = 0; i < 5; ++i) printf("    %-26s %9.1f\n", nm[i], h[i] / n);
+  }
+
+  // ---- FP8 variant --------------------------------------------------------------------------------------------------
+  {
+    typedef Rc2F8Geom<C> G8;
+    char* WS8 = dalloc<char>(G8::TOTAL_BYTES);
+    if (cn_pack_mlp_f8(W1, b1, W2, b2, sc, C, WS8, 0) != CN_OK) return 1;
+    const float* aux8 = (const float*)(WS8 + G8::STREAM_BYTES);
+    float* Yf = dalloc<float>(hY.size());
+    std::vector<float> hYf(hY.size());
+    for (size_t i = 0; i < hY.size(); ++i) hYf[i] = (float)hY[i];
+    CK(hipMemcpy(Yf, hYf.data(), hYf.size() * 4, hipMemcpyHostToDevice));
+    unsigned char* Y8 = dalloc<unsigned char>(hY.size());
+    hipLaunchKernelGGL(to_fp8, dim3((unsigned)((hY.size() + 255) / 256)), dim3(256), 0, 0, Yf, Y8, hY.size());
+    float* H8 = dalloc<float>((size_t)Mc * 4 * C);
+    CK(hipMemcpy(Xref, hX.data(), (size_t)Mc * C * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(ref_hidden_f8, dim3((unsigned)(((long)Mc * 4 * C + 255) / 256)), dim3(256), 0, 0, Y8, W1, b1, aux8, C, Mc, H8);
+    hipLaunchKernelGGL(ref_out_f8, dim3((unsigned)(((long)Mc * C + 255) / 256)), dim3(256), 0, 0, H8, W2, sc, aux8, C, Mc, Xref);
+    CK(hipDeviceSynchronize());
+    std::vector<float> href8((size_t)Mc * C);
+    CK(hipMemcpy(href8.data(), Xref, href8.size() * 4, hipMemcpyDeviceToHost));
+    auto run8 = [&](float* Xp, int Mr, int nb) -> int {
+      if constexpr (C == 96) return cn_launch_mlp_f8_resident<96, 12>(Y8, WS8, Xp, Mr, nb, 0);
+      else if constexpr (C == 192) return cn_launch_mlp_f8_ring<192, 8, 5>(Y8, WS8, Xp, Mr, nb, 0);
+      else return cn_launch_mlp_f8_ring<384, 4, 4>(Y8, WS8, Xp, Mr, nb, 0);
+    };
+    for (int nbc : {256, 5}) {
+      CK(hipMemcpy(X, hX.data(), (size_t)(Mc + 64) * C * 4, hipMemcpyHostToDevice));
+      if (run8(X, Mc, nbc) != CN_OK) return 1;
+      CK(hipDeviceSynchronize());
+      CK(hipMemcpy(hgot.data(), X, hgot.size() * 4, hipMemcpyDeviceToHost));
+      double max_err = 0, sum_err = 0, dev_bf16 = 0, ref_mag = 0;
+      size_t n_bad = 0, touched = 0;
+      for (size_t i = 0; i < href8.size(); ++i) {
+        const double e = fabs((double)hgot[i] - href8[i]);
+        max_err = std::max(max_err, e);
+        sum_err += e;
+        if (!(e <= 2e-3 + 2e-3 * fabs(href8[i]))) ++n_bad;
+        dev_bf16 += fabs((double)hgot[i] - href1[i]);
+        ref_mag += fabs((double)href1[i] - hX[i]);
+      }
+      for (size_t i = href8.size(); i < hgot.size(); ++i) touched += hgot[i] != hX[i];
+      printf("  check nb %3d fp8 kernel vs fp8-operand reference: max|err| %.3e mean %.3e out-of-tol %zu (%.4f %%) rows>=M touched %zu %s;"
+             "  vs bf16-operand reference: mean|diff| %.3e = %.2f %% of mean|delta|\n", nbc, max_err, sum_err / href8.size(), n_bad,
+             100.0 * n_bad / href8.size(), touched, (n_bad <= href8.size() / 2000 && touched == 0) ? "OK" : "FAIL", dev_bf16 / href8.size(),
+             100.0 * dev_bf16 / ref_mag);
+      bad += !(n_bad <= href8.size() / 2000 && touched == 0);
+    }
+    CK(hipMemcpy(X, hX.data(), hX.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float> ts;
+    for (int round = 0; round < 5; ++round) {
+      run8(X, M, 256);
+      CK(hipEventRecord(e0, 0));
+      for (int it = 0; it < iters; ++it) run8(X, M, 256);
+      CK(hipEventRecord(e1, 0));
+      CK(hipEventSynchronize(e1));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      ts.push_back(ms * 1000.0f / iters);
+    }
+    std::sort(ts.begin(), ts.end());
+    printf("  time  fp8 %-30s median %8.1f us  min %8.1f us  -> %7.1f TFLOP/s (%.3f of 5 PF)\n", "", ts[2], ts[0], flops / ts[2] * 1e-6,
+           flops / ts[2] * 1e-6 / 5000.0);
   }
   return bad;
 }
