@@ -1,3 +1,4 @@
+// EXPERIMENT (kernel lab only, not part of the library): see profiles/r02_notes.md.
 // Depthwise 7x7 convolution (pad 3) + LayerNorm over C (eps 1e-6), sliding-window form:
 //     x fp32 (B, H, W, C)  ->  y T (B, H, W, C)                     (reference convnext.py:62-66, Block.dwconv + Block.norm)
 //

@@ -1,3 +1,4 @@
+// EXPERIMENT (kernel lab only, not part of the library): see profiles/r02_notes.md "FP8 operands".
 // Register-chained fused ConvNeXt MLP with FP8 (OCP e4m3) operands -- the precision = fp8 variant of mlp_rc2.h:
 //
 //     x[m][:] += scale * ( W2 . gelu( W1 . y[m][:] + b1 ) + b2 )          (convnext.py:66-74)
