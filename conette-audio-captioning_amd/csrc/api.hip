@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "ctx.h"
+#include <algorithm>
 #include "mlp_rc2.h"
 
 static thread_local char g_err[512] = "";
@@ -232,7 +233,7 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
       n_cu = 256;
     ctx->n_cu = n_cu;
   }
-  size_t total = 1 << 20;
+  size_t total = (1 << 20) + (size_t)CN_N_BINS * CN_N_MELS * 4;  // (+ the band-compact mel matrix, at most a dense copy)
   for (int i = 0; i < n_tensors; ++i) total += cn_align((size_t)numel[i] * 4) + 256;
   ctx->arena_bytes = total;
   hipError_t e = hipMalloc((void**)&ctx->arena, total);
@@ -298,7 +299,6 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
     ctx->tw512 = d512;
     ctx->tw1024 = d1024;
     const float* mw = B.find(E + "logmel_extractor.melW", (int64_t)CN_N_BINS * CN_N_MELS);
-    ctx->melW = B.f32(E + "logmel_extractor.melW", (int64_t)CN_N_BINS * CN_N_MELS);
     std::vector<int> band(2 * CN_N_MELS, 0);
     if (mw) {
       std::vector<float> h((size_t)CN_N_BINS * CN_N_MELS);
@@ -314,6 +314,20 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
         band[2 * m] = lo;
         band[2 * m + 1] = hi;
       }
+    }
+    {  // band-compact copy of melW for the kernel: row i holds, for every mel bin m, the weight of FFT bin lo(m) + i
+      int maxw = 1;
+      for (int m = 0; m < CN_N_MELS; ++m) maxw = std::max(maxw, band[2 * m + 1] - band[2 * m]);
+      std::vector<float> mc((size_t)maxw * CN_N_MELS, 0.f);
+      if (mw) {
+        std::vector<float> h((size_t)CN_N_BINS * CN_N_MELS);
+        hipMemcpy(h.data(), mw, h.size() * 4, hipMemcpyDeviceToHost);
+        for (int m = 0; m < CN_N_MELS; ++m)
+          for (int k = band[2 * m]; k < band[2 * m + 1]; ++k) mc[(size_t)(k - band[2 * m]) * CN_N_MELS + m] = h[(size_t)k * CN_N_MELS + m];
+      }
+      float* dmc = (float*)B.alloc(mc.size() * 4);
+      hipMemcpy(dmc, mc.data(), mc.size() * 4, hipMemcpyHostToDevice);
+      ctx->melC = dmc;
     }
     int* dband = (int*)B.alloc(band.size() * 4);
     hipMemcpy(dband, band.data(), band.size() * 4, hipMemcpyHostToDevice);

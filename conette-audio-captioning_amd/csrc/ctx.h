@@ -74,8 +74,8 @@ struct conette_ctx {
   const float* window;     // [1024]
   const float2* tw512;     // [512]
   const float2* tw1024;    // [513]
-  const float* melW;       // [513][224]
   const int* band;         // [224][2] lo, hi
+  const float* melC;       // [max band width][224]: melC[i][m] = melW[band lo(m) + i][m] (lanes = mel bins read consecutive words)
   const float* bn_scale;   // [224]
   const float* bn_shift;   // [224]
   // stem

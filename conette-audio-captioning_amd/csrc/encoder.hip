@@ -13,65 +13,84 @@
 
 // ---------------------------------------------------------------------------------------------
 // stem: Conv2d(1 -> 96, k 4x4, s 4x4, pad (4, 0)) + LayerNorm(channels_first, eps 1e-6)
-// in: logmel (B, F, 224) fp32; out: (B, H0, 56, 96) fp32.  4 lanes per output position.
+// in: logmel (B, F, 224) fp32; out: (B, H0, 56, 96) fp32.  4 lanes per output position (24 channels each, weights
+// read from LDS 16 bytes at a time); the 64 positions of a block are contiguous in the output, so the normalised
+// values go through an LDS tile and leave as whole 1 KB wave stores (16-byte pieces at a 96-byte lane stride made
+// the kernel store bound: 172 us for 403 MB).
 // ---------------------------------------------------------------------------------------------
+template <int P>  // positions per lane group: the weights read from LDS (6 KB per position otherwise) are shared by P positions
 __global__ __launch_bounds__(256) void cn_stem_kernel(const float* __restrict__ in, int F, int H0, long n_pos,
                                                       const float* __restrict__ w /*[16][96]*/,
                                                       const float* __restrict__ bias, const float* __restrict__ ln_w,
                                                       const float* __restrict__ ln_b, float* __restrict__ out) {
-  __shared__ float s_w[16 * 96];
+  __shared__ __attribute__((aligned(16))) float s_w[16 * 96];
+  __shared__ __attribute__((aligned(16))) float s_o[P * 64 * 96];
   for (int i = threadIdx.x; i < 16 * 96; i += 256) s_w[i] = w[i];
   __syncthreads();
-  const int q = threadIdx.x & 3;
-  const long pos = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
-  const bool act = pos < n_pos;
-  const long p = act ? pos : n_pos - 1;
-  const int wq = (int)(p % 56);
-  const long t = p / 56;
-  const int h = (int)(t % H0);
-  const int b = (int)(t / H0);
-  float xin[16];
+  const int q = threadIdx.x & 3, lp = threadIdx.x >> 2;
+  const long pos0 = (long)blockIdx.x * (64 * P);
+  float xin[P][16];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = 4 * h - 4 + i;
-    if (r >= 0 && r < F) {
-      const f32x4 v = *(const f32x4*)(in + ((size_t)b * F + r) * CN_N_MELS + 4 * wq);
-      xin[4 * i] = v[0], xin[4 * i + 1] = v[1], xin[4 * i + 2] = v[2], xin[4 * i + 3] = v[3];
-    } else {
-      xin[4 * i] = xin[4 * i + 1] = xin[4 * i + 2] = xin[4 * i + 3] = 0.f;
+  for (int u = 0; u < P; ++u) {
+    const long pos = pos0 + 64 * u + lp;
+    const long p = pos < n_pos ? pos : n_pos - 1;
+    const int wq = (int)(p % 56);
+    const long t = p / 56;
+    const int h = (int)(t % H0);
+    const int b = (int)(t / H0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * h - 4 + i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r >= 0 && r < F) v = *(const f32x4*)(in + ((size_t)b * F + r) * CN_N_MELS + 4 * wq);
+      xin[u][4 * i] = v[0], xin[u][4 * i + 1] = v[1], xin[u][4 * i + 2] = v[2], xin[u][4 * i + 3] = v[3];
     }
   }
-  float acc[24];
+  f32x4 acc[P][6];
 #pragma unroll
-  for (int j = 0; j < 24; ++j) acc[j] = bias[q * 24 + j];
+  for (int j = 0; j < 6; ++j) {
+    const f32x4 b4 = *(const f32x4*)(bias + q * 24 + 4 * j);
+#pragma unroll
+    for (int u = 0; u < P; ++u) acc[u][j] = b4;
+  }
 #pragma unroll
   for (int i = 0; i < 16; ++i)
 #pragma unroll
-    for (int j = 0; j < 24; ++j) acc[j] = fmaf(xin[i], s_w[i * 96 + q * 24 + j], acc[j]);
-  float s = 0.f;
+    for (int j = 0; j < 6; ++j) {
+      const f32x4 w4 = *(const f32x4*)(s_w + i * 96 + q * 24 + 4 * j);
 #pragma unroll
-  for (int j = 0; j < 24; ++j) s += acc[j];
-  s += __shfl_xor(s, 1);
-  s += __shfl_xor(s, 2);
-  const float mean = s * (1.0f / 96.0f);
-  float v2 = 0.f;
-#pragma unroll
-  for (int j = 0; j < 24; ++j) {
-    const float d = acc[j] - mean;
-    v2 = fmaf(d, d, v2);
-  }
-  v2 += __shfl_xor(v2, 1);
-  v2 += __shfl_xor(v2, 2);
-  const float rstd = 1.0f / sqrtf(v2 * (1.0f / 96.0f) + 1e-6f);
-  if (act) {
-    float* o = out + (size_t)pos * 96 + q * 24;
-#pragma unroll
-    for (int j = 0; j < 24; j += 4) {
-      f32x4 r;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) r[e] = (acc[j + e] - mean) * rstd * ln_w[q * 24 + j + e] + ln_b[q * 24 + j + e];
-      *(f32x4*)(o + j) = r;
+      for (int u = 0; u < P; ++u) acc[u][j] += xin[u][i] * w4;
     }
+#pragma unroll
+  for (int u = 0; u < P; ++u) {
+    const f32x4 s4 = (acc[u][0] + acc[u][1]) + (acc[u][2] + acc[u][3]) + (acc[u][4] + acc[u][5]);
+    float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    const float mean = s * (1.0f / 96.0f);
+    f32x4 q4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      acc[u][j] -= mean;
+      q4 += acc[u][j] * acc[u][j];
+    }
+    float v2 = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+    v2 += __shfl_xor(v2, 1);
+    v2 += __shfl_xor(v2, 2);
+    const float rstd = 1.0f / sqrtf(v2 * (1.0f / 96.0f) + 1e-6f);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int ch = q * 24 + 4 * j;
+      *(f32x4*)(s_o + (64 * u + lp) * 96 + ch) = acc[u][j] * rstd * *(const f32x4*)(ln_w + ch) + *(const f32x4*)(ln_b + ch);
+    }
+  }
+  __syncthreads();
+  const long n4 = min((long)(64 * P), n_pos - pos0) * 24;  // 16-byte pieces of this block's positions
+  f32x4* o4 = (f32x4*)(out + (size_t)pos0 * 96);
+#pragma unroll
+  for (int k = 0; k < 6 * P; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    if (i < n4) o4[i] = ((const f32x4*)s_o)[i];
   }
 }
 
@@ -674,7 +693,7 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
   {
     const long n_pos = (long)B * g.H[0] * g.W[0];
     CnProfScope ps(ctx, CONETTE_PROF_STEM, s);
-    hipLaunchKernelGGL(cn_stem_kernel, dim3((unsigned)((n_pos + 63) / 64)), dim3(256), 0, s, ws.logmel, g.F, g.H[0],
+    hipLaunchKernelGGL(cn_stem_kernel<1>, dim3((unsigned)((n_pos + 63) / 64)), dim3(256), 0, s, ws.logmel, g.F, g.H[0],
                        n_pos, ctx->stem_w, ctx->stem_b, ctx->stem_ln_w, ctx->stem_ln_b, ws.x);
     CN_LAUNCH_CHECK();
     if (taps) CN_TRY(tap_copy(taps->stem, ws.x, (size_t)n_pos * 96, s));

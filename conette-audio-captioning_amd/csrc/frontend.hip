@@ -41,13 +41,17 @@ __device__ __forceinline__ void dft8(float2 (&v)[8]) {
   v[7] = csub(b6, b7);
 }
 
+// The four waves of a block work on their own frames and their own LDS buffers: the stages of a frame only need the LDS
+// operations of ONE wave to stay in program order (they do: a wave's ds instructions execute in order), not a block barrier.
+__device__ __forceinline__ void cn_wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
 #define FE_PITCH 72  // complex elements per transpose row (64 + 8 pad)
 
 __global__ __launch_bounds__(256) void cn_logmel_kernel(const float* __restrict__ wave, int L, int F, int total,
                                                         const float* __restrict__ window,
                                                         const float2* __restrict__ tw512,
                                                         const float2* __restrict__ tw1024,
-                                                        const float* __restrict__ melW, const int* __restrict__ band,
+                                                        const float* __restrict__ melC, const int* __restrict__ band,
                                                         const float* __restrict__ bn_scale,
                                                         const float* __restrict__ bn_shift, float* __restrict__ out) {
   __shared__ float2 s_tw512[512];
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) void cn_logmel_kernel(const float* __restrict_
     for (int c = 1; c < 8; ++c) v[c] = cmul(v[c], s_tw512[lane * c]);
 #pragma unroll
     for (int c = 0; c < 8; ++c) sx[c * FE_PITCH + lane] = v[c];
-    __syncthreads();
+    cn_wave_sync();
     // ---- stage 2: lane = (c, b'), v[a'] = Y[c][8a' + b'] --------------------------------------
     const int c = lane >> 3, lo3 = lane & 7;
 #pragma unroll
@@ -97,18 +101,18 @@ __global__ __launch_bounds__(256) void cn_logmel_kernel(const float* __restrict_
     dft8(v);
 #pragma unroll
     for (int cp = 1; cp < 8; ++cp) v[cp] = cmul(v[cp], s_tw512[8 * lo3 * cp]);
-    __syncthreads();
+    cn_wave_sync();
 #pragma unroll
     for (int cp = 0; cp < 8; ++cp) sx[c * FE_PITCH + cp * 8 + lo3] = v[cp];
-    __syncthreads();
+    cn_wave_sync();
     // ---- stage 3: lane = (c, c'), v[b'] = Y'[c][c'][b'] ---------------------------------------
 #pragma unroll
     for (int bp = 0; bp < 8; ++bp) v[bp] = sx[c * FE_PITCH + lo3 * 8 + bp];
     dft8(v);
-    __syncthreads();
+    cn_wave_sync();
 #pragma unroll
     for (int dp = 0; dp < 8; ++dp) sx[c + 8 * lo3 + 64 * dp] = v[dp];  // Z[k], k = c + 8c' + 64d'
-    __syncthreads();
+    cn_wave_sync();
     // ---- real-FFT untangle -> power spectrum ---------------------------------------------------
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -125,22 +129,22 @@ __global__ __launch_bounds__(256) void cn_logmel_kernel(const float* __restrict_
       const float xr = A.x - A.y;  // X[512] = Re Z0 - Im Z0
       sp[512] = xr * xr;
     }
-    __syncthreads();
+    cn_wave_sync();
     // ---- mel band sums, dB, bn0 affine ---------------------------------------------------------
     if (act) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int m = lane + 64 * g;
         if (m < CN_N_MELS) {
-          const int lo = band[2 * m], hi = band[2 * m + 1];
+          const int lo = band[2 * m], nb = band[2 * m + 1] - lo;
           float acc = 0.f;
-          for (int k = lo; k < hi; ++k) acc = fmaf(sp[k], melW[k * CN_N_MELS + m], acc);
+          for (int i = 0; i < nb; ++i) acc = fmaf(sp[lo + i], melC[i * CN_N_MELS + m], acc);  // bins lo, lo+1, ..: same order as the dense row
           const float db = 10.0f * log10f(fmaxf(acc, 1e-10f));
           out[(size_t)fr * CN_N_MELS + m] = db * bn_scale[m] + bn_shift[m];
         }
       }
     }
-    __syncthreads();
+    cn_wave_sync();
   }
 }
 
@@ -154,7 +158,7 @@ int cn_frontend(conette_ctx* ctx, const float* wave, int B, int L, float* out, h
   int grid = (int)((total + 3) / 4);
   if (grid > 256 * 8) grid = 256 * 8;
   hipLaunchKernelGGL(cn_logmel_kernel, dim3(grid), dim3(256), 0, s, wave, L, F, (int)total, ctx->window, ctx->tw512,
-                     ctx->tw1024, ctx->melW, ctx->band, ctx->bn_scale, ctx->bn_shift, out);
+                     ctx->tw1024, ctx->melC, ctx->band, ctx->bn_scale, ctx->bn_shift, out);
   CN_LAUNCH_CHECK();
   return CN_OK;
 }
