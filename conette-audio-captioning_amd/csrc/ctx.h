@@ -35,6 +35,7 @@ struct CnDownW {
   const float* ln_b;
   const void* w;  // [2C][(kh,kw,c)] operand type
   const float* bias;
+  const void* fused;  // down_fused.h stream (bf16, stage 0 -> 1 only), else nullptr
 };
 
 struct CnLayerW {

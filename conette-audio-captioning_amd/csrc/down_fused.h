@@ -1,0 +1,170 @@
+// Fused downsample layer (bf16), stage 0 -> 1:   LayerNorm(channels_first, eps 1e-6) + Conv2d(C -> 2C, k 2x2, s 2)
+//     x fp32 (B, H, W, C)  ->  out fp32 (B, H/2, W/2, 2C)                        (reference convnext.py:207-217)
+//
+// The two-kernel form (cn_ln_patchify_kernel writes the bf16 patch matrix, cn_gemm2 reads it back) moves the patch matrix
+// through HBM twice; here a wave owns 32 OUTPUT positions and builds its GEMM operand in registers:
+//   * the K = 4C row of an output position is (kh, kw, c) = its four input positions back to back, so the MFMA fragment of
+//     k-step s (8 consecutive k per lane half) is 8 consecutive channels of ONE input position: lane l loads the channels
+//     16 j + 8 (l >> 5) .. + 8, j < C/16, of each of its four input positions (fp32), the LayerNorm statistics of an input
+//     position are the sums of lanes l and l ^ 32, and the normalised values become the fragment registers directly;
+//   * the LayerNorm affine is folded into the packed weights at create time: W'[n][k] = bf16(W[n][k] g[c(k)]),
+//     bias'[n] = bias[n] + sum_k W[n][k] b[c(k)] (fp32), so the operand is bf16((x - mean) rstd);
+//   * the whole packed weight matrix (K x N bf16 = 144 KB at C = 96) is resident in LDS; persistent blocks, no barrier
+//     after the fill; C[pos][n] accumulates with the channels on the lanes, stored like the fused MLP's epilogue.
+// Packed stream: fragment (s, t), s < K/16, t < N/32: lane l holds W'[32 t + (l & 31)][16 s + 8 (l >> 5) .. + 8]; then bias'[N] fp32.
+#pragma once
+#include "mlp_rc2.h"
+
+template <int CP> struct DownGeom {
+  static constexpr int K = 4 * CP, N = 2 * CP, KS = K / 16, NT = N / 32, CH = CP / 16;
+  static constexpr size_t STREAM_BYTES = (size_t)KS * NT * 1024;
+  static constexpr size_t TOTAL_BYTES = STREAM_BYTES + N * 4;
+};
+
+// src: Conv2d weight (N, C, 2, 2) fp32; g, b: LayerNorm weight / bias (C); bias (N)
+static __global__ void pk_down_fused(const float* __restrict__ src, const float* __restrict__ g, const float* __restrict__ b,
+                                     const float* __restrict__ bias, int N, int C, bf16_t* __restrict__ dst) {
+  const int K = 4 * C, KS = K / 16, NT = N / 32;
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < N) {  // bias' behind the stream
+    float a = bias[u];
+    for (int k = 0; k < K; ++k) a = fmaf(src[((size_t)u * C + k % C) * 4 + k / C], b[k % C], a);
+    ((float*)((char*)dst + (size_t)KS * NT * 1024))[u] = a;
+  }
+  if (u >= KS * NT * 64) return;
+  const int l = u & 63, t = (u >> 6) % NT, s = (u >> 6) / NT;
+  const int n = 32 * t + (l & 31);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = 16 * s + 8 * (l >> 5) + i, kk = k / C, c = k % C;
+    dst[(size_t)u * 8 + i] = (bf16_t)(src[((size_t)n * C + c) * 4 + kk] * g[c]);
+  }
+}
+
+
+// MFMA q = s NT + t of a tile consumes fragment q of the packed stream; a rolling window of PRE fragments is in flight.
+// (Left to the scheduler, all 144 LDS reads are hoisted to the top and ~500 registers spill.)
+template <int CP> struct DownMma {
+  typedef DownGeom<CP> G;
+  static constexpr int NM = G::KS * G::NT, PRE = 6, R = PRE + 1;
+  template <int Q>
+  static __device__ __forceinline__ void step(const char* wl, const bf16x8 (&a)[G::KS], f32x16 (&acc)[G::NT], bf16x8 (&f)[R]) {
+    if constexpr (Q + PRE < NM) f[(Q + PRE) % R] = *(const bf16x8*)(wl + (Q + PRE) * 1024);
+    constexpr int s = Q / G::NT, t = Q % G::NT;
+    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], f[Q % R], acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (Q + 1 < NM) step<Q + 1>(wl, a, acc, f);
+  }
+  template <int Q>
+  static __device__ __forceinline__ void run(const char* wl, const bf16x8 (&a)[G::KS], f32x16 (&acc)[G::NT]) {
+    bf16x8 f[R];
+#pragma unroll
+    for (int q = 0; q < PRE; ++q) f[q] = *(const bf16x8*)(wl + q * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    step<0>(wl, a, acc, f);
+  }
+};
+
+template <int CP, int NW>
+__global__ __launch_bounds__(NW * 64) void cn_down_fused_kernel(const float* __restrict__ X, int H, int W, long P,
+                                                                const bf16_t* __restrict__ WS, float* __restrict__ OUT) {
+  typedef DownGeom<CP> G;
+  constexpr int KS = G::KS, NT = G::NT, CH = G::CH, N = G::N;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int PIECES = (int)(G::STREAM_BYTES / 1024);
+  for (int i = wave; i < PIECES; i += NW)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)WS + (size_t)i * 1024 + lane * 16),
+                                     (__attribute__((address_space(3))) void*)(smem + i * 1024), 16, 0, 0);
+  const float* biasp = (const float*)((const char*)WS + G::STREAM_BYTES);
+  const int H2 = H / 2, W2 = W / 2;
+  const long n_tiles = (P + 31) >> 5;
+  const long t_lo = (long)blockIdx.x * n_tiles / gridDim.x, t_hi = (long)(blockIdx.x + 1) * n_tiles / gridDim.x;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const char* wl = smem + lane * 16;
+  const int hh = lane >> 5;
+  for (long tile = t_lo + wave; tile < t_hi; tile += NW) {
+    // ---- operand: 4 input positions x CH fragments ----------------------------------------------------------------
+    const long p = min(tile * 32 + (lane & 31), P - 1);
+    const int w2 = (int)(p % W2);
+    const long tq = p / W2;
+    const int h2 = (int)(tq % H2);
+    const long b = tq / H2;
+    const float* x00 = X + (((size_t)b * H + 2 * h2) * W + 2 * w2) * CP + 8 * hh;
+    bf16x8 a[KS];
+    f32x4 v[2][CH][2];
+    auto load_ip = [&](int ip, f32x4 (&d)[CH][2]) {
+      const float* src = x00 + ((size_t)(ip >> 1) * W + (ip & 1)) * CP;
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        d[j][0] = *(const f32x4*)(src + 16 * j);
+        d[j][1] = *(const f32x4*)(src + 16 * j + 4);
+      }
+    };
+    load_ip(0, v[0]);
+#pragma unroll
+    for (int ip = 0; ip < 4; ++ip) {
+      if (ip + 1 < 4) load_ip(ip + 1, v[(ip + 1) & 1]);
+      f32x4(&d)[CH][2] = v[ip & 1];
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < CH; ++j) s4 += d[j][0] + d[j][1];
+      float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+      s += __shfl_xor(s, 32);
+      const float mean = s * (1.0f / CP);
+      f32x4 q4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        d[j][0] -= mean;
+        d[j][1] -= mean;
+        q4 += d[j][0] * d[j][0] + d[j][1] * d[j][1];
+      }
+      float q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+      q += __shfl_xor(q, 32);
+      const float rstd = 1.0f / sqrtf(q * (1.0f / CP) + 1e-6f);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const f32x4 lo = d[j][0] * rstd, hi = d[j][1] * rstd;
+        a[ip * CH + j] = bf16x8{(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
+                                (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
+      }
+    }
+    // ---- C[pos][n] = sum_k a[pos][k] W'[n][k]: positions in the registers' rows, channels on the lanes ------------------
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    DownMma<CP>::template run<0>(wl, a, acc);  // hand-ordered: fragment q + PRE is requested before MFMA q (see mlp_rc2.h)
+    // ---- epilogue: + bias', 128-byte row pieces ---------------------------------------------------------------------
+    const long m0 = tile * 32;
+    const int voff = 4 * hh * N + (lane & 31);
+    const long plim = P - m0 - 4 * hh;
+    float bb[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bb[t] = biasp[32 * t + (lane & 31)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float* row = OUT + (size_t)(m0 + (r & 3) + 8 * (r >> 2)) * N;  // scalar
+      if ((r & 3) + 8 * (r >> 2) < plim) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) row[voff + 32 * t] = acc[t][r] + bb[t];
+      }
+    }
+  }
+}
+
+template <int CP, int NW>
+static int cn_launch_down_fused(const float* X, int B, int H, int W, const void* WS, float* OUT, int n_blocks, hipStream_t s) {
+  typedef DownGeom<CP> G;
+  constexpr int SMEM = (int)G::STREAM_BYTES;
+  static_assert(SMEM <= 160 * 1024, "the packed weights must fit in LDS");
+  const long P = (long)B * (H / 2) * (W / 2);
+  CN_TRY(cn_configure_lds((const void*)cn_down_fused_kernel<CP, NW>, SMEM));
+  const int grid = cn_rc2_grid((int)((P + 31) / 32), NW, n_blocks);
+  hipLaunchKernelGGL((cn_down_fused_kernel<CP, NW>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, X, H, W, P, (const bf16_t*)WS, OUT);
+  CN_LAUNCH_CHECK();
+  return CN_OK;
+}

@@ -10,6 +10,7 @@
 
 #include "gemm2.h"
 #include "mlp_rc2.h"
+#include "down_fused.h"
 
 // ---------------------------------------------------------------------------------------------
 // stem: Conv2d(1 -> 96, k 4x4, s 4x4, pad (4, 0)) + LayerNorm(channels_first, eps 1e-6)
@@ -698,6 +699,7 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
     CN_LAUNCH_CHECK();
     if (taps) CN_TRY(tap_copy(taps->stem, ws.x, (size_t)n_pos * 96, s));
   }
+  float* xc = ws.x;  // the residual stream: ws.x, or ws.h after the fused stage-1 downsample (which cannot run in place)
   int blk = 0;
   for (int st = 0; st < 4; ++st) {
     const int C = CN_DIMS[st], H = g.H[st], W = g.W[st];
@@ -707,24 +709,32 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
       const long n_in = (long)B * Hp * Wp;
       const CnDownW& dw = ctx->down[st - 1];
       CnProfScope ps(ctx, CONETTE_PROF_DOWNSAMPLE, s);
+      if (std::is_same<T, bf16_t>::value && Cp == 96 && dw.fused != nullptr) {
+        // LayerNorm + patch GEMM in one kernel (down_fused.h); stages 0-2 run the fused MLP in bf16, so ws.h is free here
+        CN_TRY((cn_launch_down_fused<96, 8>(xc, B, Hp, Wp, dw.fused, (float*)ws.h, ctx->n_cu - ctx->enc_reserved_cus, s)));
+        xc = (float*)ws.h;
+        if (taps) CN_TRY(tap_copy(taps->down[st], xc, (size_t)P * C, s));
+      } else {
       const int ppb = Cp == 96 ? 32 : 16;           // positions per block: 4 waves x 4 groups x (2 | 1) positions
       const dim3 pg((unsigned)((n_in + ppb - 1) / ppb));
       if (Cp == 96)
-        hipLaunchKernelGGL((cn_ln_patchify_kernel<T, 96>), pg, dim3(256), 0, s, ws.x, Hp, Wp, n_in, dw.ln_w, dw.ln_b, y);
+        hipLaunchKernelGGL((cn_ln_patchify_kernel<T, 96>), pg, dim3(256), 0, s, xc, Hp, Wp, n_in, dw.ln_w, dw.ln_b, y);
       else if (Cp == 192)
-        hipLaunchKernelGGL((cn_ln_patchify_kernel<T, 192>), pg, dim3(256), 0, s, ws.x, Hp, Wp, n_in, dw.ln_w, dw.ln_b, y);
+        hipLaunchKernelGGL((cn_ln_patchify_kernel<T, 192>), pg, dim3(256), 0, s, xc, Hp, Wp, n_in, dw.ln_w, dw.ln_b, y);
       else
-        hipLaunchKernelGGL((cn_ln_patchify_kernel<T, 384>), pg, dim3(256), 0, s, ws.x, Hp, Wp, n_in, dw.ln_w, dw.ln_b, y);
+        hipLaunchKernelGGL((cn_ln_patchify_kernel<T, 384>), pg, dim3(256), 0, s, xc, Hp, Wp, n_in, dw.ln_w, dw.ln_b, y);
       CN_LAUNCH_CHECK();
       EpiBiasAct<float, ACT_NONE> epi{dw.bias, ws.x, C, ACT_NONE};
       CN_TRY(cn_mm(y, 4 * Cp, (const T*)dw.w, 4 * Cp, (int)P, C, 4 * Cp, epi, s));
-      if (taps) CN_TRY(tap_copy(taps->down[st], ws.x, (size_t)P * C, s));
+      xc = ws.x;
+      if (taps) CN_TRY(tap_copy(taps->down[st], xc, (size_t)P * C, s));
+      }
     }
     for (int b = 0; b < CN_DEPTHS[st]; ++b, ++blk) {
       const CnBlockW& bw = ctx->blocks[blk];
       {
         CnProfScope ps(ctx, CONETTE_PROF_DWCONV_LN, s);
-        CN_TRY(dwconv_dispatch<T>(C, ws.x, B, H, W, bw, y, s));
+        CN_TRY(dwconv_dispatch<T>(C, xc, B, H, W, bw, y, s));
       }
       bool fused = false;
       if constexpr (std::is_same<T, bf16_t>::value) {
@@ -732,9 +742,9 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
         if (bw.mlp_stream != nullptr && C <= 384) {
           CnProfScope ps(ctx, CONETTE_PROF_PW1_GEMM, s);
           const bf16_t* wsm = (const bf16_t*)bw.mlp_stream;
-          if (C == 96) CN_TRY((cn_launch_mlp_rc2_resident<96, 12, 1>(y, wsm, ws.x, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
-          else if (C == 192) CN_TRY((cn_launch_mlp_rc2_ring<192, 8, 1, 5>(y, wsm, ws.x, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
-          else CN_TRY((cn_launch_mlp_rc2_ring<384, 4, 1, 3>(y, wsm, ws.x, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
+          if (C == 96) CN_TRY((cn_launch_mlp_rc2_resident<96, 12, 1>(y, wsm, xc, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
+          else if (C == 192) CN_TRY((cn_launch_mlp_rc2_ring<192, 8, 1, 5>(y, wsm, xc, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
+          else CN_TRY((cn_launch_mlp_rc2_ring<384, 4, 1, 3>(y, wsm, xc, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
           fused = true;
         }
       }
@@ -751,18 +761,18 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
         }
         {
           CnProfScope ps(ctx, CONETTE_PROF_PW2_GEMM, s);
-          EpiResid e2{bw.b2, bw.scale, ws.x, ws.x, C};
+          EpiResid e2{bw.b2, bw.scale, xc, xc, C};
           CN_TRY(cn_mm(hbuf, 4 * C, (const T*)bw.w2, 4 * C, (int)P, C, 4 * C, e2, s));
         }
       }
-      if (taps && b == 0) CN_TRY(tap_copy(taps->stage_block0[st], ws.x, (size_t)P * C, s));
-      if (taps) CN_TRY(tap_copy(taps->block[blk], ws.x, (size_t)P * C, s));
+      if (taps && b == 0) CN_TRY(tap_copy(taps->stage_block0[st], xc, (size_t)P * C, s));
+      if (taps) CN_TRY(tap_copy(taps->block[blk], xc, (size_t)P * C, s));
     }
-    if (taps) CN_TRY(tap_copy(taps->stage[st], ws.x, (size_t)P * C, s));
+    if (taps) CN_TRY(tap_copy(taps->stage[st], xc, (size_t)P * C, s));
   }
   const int Tn = g.H[3];
   CnProfScope ps_heads(ctx, CONETTE_PROF_HEADS, s);
-  hipLaunchKernelGGL((cn_frame_mean_kernel<T>), dim3((unsigned)(B * Tn)), dim3(256), 0, s, ws.x, g.W[3], CN_FEAT,
+  hipLaunchKernelGGL((cn_frame_mean_kernel<T>), dim3((unsigned)(B * Tn)), dim3(256), 0, s, xc, g.W[3], CN_FEAT,
                      frame_embs, (T*)nullptr);
   CN_LAUNCH_CHECK();
   if (clip_probs) {

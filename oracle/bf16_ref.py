@@ -49,11 +49,19 @@ def convnext_block_bf16(w: Weights, prefix: str, x: Tensor, folded: bool) -> Ten
     return x + z.permute(0, 3, 1, 2)
 
 
-def downsample_bf16(w: Weights, i: int, x: Tensor) -> Tensor:
-    """downsample_layers[i], i = 1..3 (convnext.py:207-217): LayerNorm(channels_first) + 2x2/2 conv, bf16 operands."""
+def downsample_bf16(w: Weights, i: int, x: Tensor, folded: bool = False) -> Tensor:
+    """downsample_layers[i], i = 1..3 (convnext.py:207-217): LayerNorm(channels_first) + 2x2/2 conv, bf16 operands.
+
+    folded (csrc/down_fused.h, stage 0 -> 1): the LayerNorm affine lives in the packed weights -- the activation operand
+    is bf16((x - mean) rstd), the weight operand bf16(W g) (g per input channel) and the bias is b + sum W beta in fp32."""
     d = f"preprocessor.encoder.downsample_layers.{i}."
-    y = bf16(O._ln_cf(x, w[d + "0.weight"], w[d + "0.bias"]))
-    return F.conv2d(y, bf16(w[d + "1.weight"]), w[d + "1.bias"], stride=2)
+    if not folded:
+        y = bf16(O._ln_cf(x, w[d + "0.weight"], w[d + "0.bias"]))
+        return F.conv2d(y, bf16(w[d + "1.weight"]), w[d + "1.bias"], stride=2)
+    g, beta, W, b = w[d + "0.weight"].float(), w[d + "0.bias"].float(), w[d + "1.weight"].float(), w[d + "1.bias"].float()
+    y = bf16(O._ln_cf(x, torch.ones_like(g), torch.zeros_like(beta)))
+    bias = b + (W * beta.view(1, -1, 1, 1)).sum(dim=(1, 2, 3))
+    return F.conv2d(y, bf16(W * g.view(1, -1, 1, 1)), bias, stride=2)
 
 
 def block_prefix(blk: int) -> str:
