@@ -367,9 +367,9 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
     ctx->down[i].w = dst;
     ctx->down[i].bias = B.f32(p + "1.bias", C2);
     ctx->down[i].fused = nullptr;
-    if (i == 0 && ctx->esize == 2) {  // fused LayerNorm + patch GEMM (down_fused.h): LN affine folded into the packed weights
+    if (i <= 1 && ctx->esize == 2) {  // fused LayerNorm + patch GEMM (down_fused.h): LN affine folded into the packed weights
       const float *g = B.find(p + "0.weight", C), *bt = B.find(p + "0.bias", C), *cb = B.find(p + "1.bias", C2);
-      void* fs = B.alloc(DownGeom<96>::TOTAL_BYTES);
+      void* fs = B.alloc(i == 0 ? DownGeom<96>::TOTAL_BYTES : DownGeom<192>::TOTAL_BYTES);
       if (w && g && bt && cb) {
         const int n = (4 * C / 16) * (C2 / 32) * 64;
         hipLaunchKernelGGL(pk_down_fused, dim3((n + 255) / 256), dim3(256), 0, 0, w, g, bt, cb, C2, C, (bf16_t*)fs);

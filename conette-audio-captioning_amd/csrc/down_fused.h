@@ -42,6 +42,82 @@ static __global__ void pk_down_fused(const float* __restrict__ src, const float*
 }
 
 
+// The GEMM operand of a 32-position tile: a[(ip - IP0) * CH + j] = bf16((x - mean) rstd) of channels 16 j + 8 (lane >> 5) .. + 8 of
+// input position ip (IP0 <= ip < IP0 + NIP; ip = 2 kh + kw) of output position `tile * 32 + (lane & 31)` (clamped to P - 1).
+template <int CP, int IP0 = 0, int NIP = 4>
+static __device__ __forceinline__ void cn_down_operand(const float* __restrict__ X, int H, int W, long P, long tile, int lane,
+                                                       bf16x8 (&a)[NIP * DownGeom<CP>::CH]) {
+  constexpr int CH = DownGeom<CP>::CH;
+  const int H2 = H / 2, W2 = W / 2, hh = lane >> 5;
+    // ---- operand: 4 input positions x CH fragments ----------------------------------------------------------------
+    const long p = min(tile * 32 + (lane & 31), P - 1);
+    const int w2 = (int)(p % W2);
+    const long tq = p / W2;
+    const int h2 = (int)(tq % H2);
+    const long b = tq / H2;
+    const float* x00 = X + (((size_t)b * H + 2 * h2) * W + 2 * w2) * CP + 8 * hh;
+    f32x4 v[2][CH][2];
+    auto load_ip = [&](int ip, f32x4 (&d)[CH][2]) {
+      const float* src = x00 + ((size_t)(ip >> 1) * W + (ip & 1)) * CP;
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        d[j][0] = *(const f32x4*)(src + 16 * j);
+        d[j][1] = *(const f32x4*)(src + 16 * j + 4);
+      }
+    };
+    load_ip(IP0, v[0]);
+#pragma unroll
+    for (int ii = 0; ii < NIP; ++ii) {
+      const int ip = IP0 + ii;
+      if (ii + 1 < NIP) load_ip(ip + 1, v[(ii + 1) & 1]);
+      f32x4(&d)[CH][2] = v[ii & 1];
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < CH; ++j) s4 += d[j][0] + d[j][1];
+      float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+      s += __shfl_xor(s, 32);
+      const float mean = s * (1.0f / CP);
+      f32x4 q4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        d[j][0] -= mean;
+        d[j][1] -= mean;
+        q4 += d[j][0] * d[j][0] + d[j][1] * d[j][1];
+      }
+      float q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+      q += __shfl_xor(q, 32);
+      const float rstd = 1.0f / sqrtf(q * (1.0f / CP) + 1e-6f);
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const f32x4 lo = d[j][0] * rstd, hi = d[j][1] * rstd;
+        a[ii * CH + j] = bf16x8{(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
+                                (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
+      }
+    }
+}
+
+// out[m0 + row][:] = acc + bias' (channels on the lanes, 128-byte row pieces)
+template <int CP>
+static __device__ __forceinline__ void cn_down_store(float* __restrict__ OUT, const float* __restrict__ biasp, long P, long tile, int lane,
+                                                     const f32x16 (&acc)[DownGeom<CP>::NT]) {
+  constexpr int NT = DownGeom<CP>::NT, N = DownGeom<CP>::N;
+  const int hh = lane >> 5;
+  const long m0 = tile * 32;
+  const int voff = 4 * hh * N + (lane & 31);
+  const long plim = P - m0 - 4 * hh;
+  float bb[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bb[t] = biasp[32 * t + (lane & 31)];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float* row = OUT + (size_t)(m0 + (r & 3) + 8 * (r >> 2)) * N;  // scalar
+    if ((r & 3) + 8 * (r >> 2) < plim) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) row[voff + 32 * t] = acc[t][r] + bb[t];
+    }
+  }
+}
+
 // MFMA q = s NT + t of a tile consumes fragment q of the packed stream; a rolling window of PRE fragments is in flight.
 // (Left to the scheduler, all 144 LDS reads are hoisted to the top and ~500 registers spill.)
 template <int CP> struct DownMma {
@@ -78,59 +154,14 @@ __global__ __launch_bounds__(NW * 64) void cn_down_fused_kernel(const float* __r
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)WS + (size_t)i * 1024 + lane * 16),
                                      (__attribute__((address_space(3))) void*)(smem + i * 1024), 16, 0, 0);
   const float* biasp = (const float*)((const char*)WS + G::STREAM_BYTES);
-  const int H2 = H / 2, W2 = W / 2;
   const long n_tiles = (P + 31) >> 5;
   const long t_lo = (long)blockIdx.x * n_tiles / gridDim.x, t_hi = (long)(blockIdx.x + 1) * n_tiles / gridDim.x;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const char* wl = smem + lane * 16;
-  const int hh = lane >> 5;
   for (long tile = t_lo + wave; tile < t_hi; tile += NW) {
-    // ---- operand: 4 input positions x CH fragments ----------------------------------------------------------------
-    const long p = min(tile * 32 + (lane & 31), P - 1);
-    const int w2 = (int)(p % W2);
-    const long tq = p / W2;
-    const int h2 = (int)(tq % H2);
-    const long b = tq / H2;
-    const float* x00 = X + (((size_t)b * H + 2 * h2) * W + 2 * w2) * CP + 8 * hh;
     bf16x8 a[KS];
-    f32x4 v[2][CH][2];
-    auto load_ip = [&](int ip, f32x4 (&d)[CH][2]) {
-      const float* src = x00 + ((size_t)(ip >> 1) * W + (ip & 1)) * CP;
-#pragma unroll
-      for (int j = 0; j < CH; ++j) {
-        d[j][0] = *(const f32x4*)(src + 16 * j);
-        d[j][1] = *(const f32x4*)(src + 16 * j + 4);
-      }
-    };
-    load_ip(0, v[0]);
-#pragma unroll
-    for (int ip = 0; ip < 4; ++ip) {
-      if (ip + 1 < 4) load_ip(ip + 1, v[(ip + 1) & 1]);
-      f32x4(&d)[CH][2] = v[ip & 1];
-      f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < CH; ++j) s4 += d[j][0] + d[j][1];
-      float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-      s += __shfl_xor(s, 32);
-      const float mean = s * (1.0f / CP);
-      f32x4 q4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int j = 0; j < CH; ++j) {
-        d[j][0] -= mean;
-        d[j][1] -= mean;
-        q4 += d[j][0] * d[j][0] + d[j][1] * d[j][1];
-      }
-      float q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
-      q += __shfl_xor(q, 32);
-      const float rstd = 1.0f / sqrtf(q * (1.0f / CP) + 1e-6f);
-#pragma unroll
-      for (int j = 0; j < CH; ++j) {
-        const f32x4 lo = d[j][0] * rstd, hi = d[j][1] * rstd;
-        a[ip * CH + j] = bf16x8{(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
-                                (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
-      }
-    }
+    cn_down_operand<CP>(X, H, W, P, tile, lane, a);
     // ---- C[pos][n] = sum_k a[pos][k] W'[n][k]: positions in the registers' rows, channels on the lanes ------------------
     f32x16 acc[NT];
 #pragma unroll
@@ -138,21 +169,7 @@ __global__ __launch_bounds__(NW * 64) void cn_down_fused_kernel(const float* __r
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     DownMma<CP>::template run<0>(wl, a, acc);  // hand-ordered: fragment q + PRE is requested before MFMA q (see mlp_rc2.h)
-    // ---- epilogue: + bias', 128-byte row pieces ---------------------------------------------------------------------
-    const long m0 = tile * 32;
-    const int voff = 4 * hh * N + (lane & 31);
-    const long plim = P - m0 - 4 * hh;
-    float bb[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) bb[t] = biasp[32 * t + (lane & 31)];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float* row = OUT + (size_t)(m0 + (r & 3) + 8 * (r >> 2)) * N;  // scalar
-      if ((r & 3) + 8 * (r >> 2) < plim) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) row[voff + 32 * t] = acc[t][r] + bb[t];
-      }
-    }
+    cn_down_store<CP>(OUT, biasp, P, tile, lane, acc);
   }
 }
 
@@ -165,6 +182,107 @@ static int cn_launch_down_fused(const float* X, int B, int H, int W, const void*
   CN_TRY(cn_configure_lds((const void*)cn_down_fused_kernel<CP, NW>, SMEM));
   const int grid = cn_rc2_grid((int)((P + 31) / 32), NW, n_blocks);
   hipLaunchKernelGGL((cn_down_fused_kernel<CP, NW>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, X, H, W, P, (const bf16_t*)WS, OUT);
+  CN_LAUNCH_CHECK();
+  return CN_OK;
+}
+
+// ---- ring variant (C = 192: K = 768, N = 384, 576 KB of weights): the stream goes L2 -> LDS in steps of KSTEP k-steps --
+// One wave per SIMD (accumulators 192 registers + the operand of HALF the K range, 96); a tile is NSTEP = KS / KSTEP ring steps, each
+// wait (counted vmcnt) -> barrier -> request entry g + NST - 1 -> KSTEP NT MFMAs, fully unrolled per tile because the
+// operand fragment a[s] must be a compile-time register choice.  NSTEP is a multiple of NST, so the slot of step J of a
+// tile is J % NST.  The vmcnt discipline is mlp_rc2.h's: the operand loads and the stores of a tile sit in the same
+// in-order queue and only make a wait stricter.
+template <int CP, int NW, int KSTEP, int NST> struct DownRing {
+  typedef DownGeom<CP> G;
+  static constexpr int NT = G::NT, KS = G::KS, NSTEP = KS / KSTEP, FR = KSTEP * NT, SB = FR * 1024;
+  static constexpr int DPW = FR / NW, PRE = 6, R = PRE + 1;
+  static_assert(KS % KSTEP == 0 && NSTEP % NST == 0 && FR % NW == 0, "ring geometry");
+  static constexpr int SMEM = NST * SB;
+
+  static __device__ __forceinline__ void stage(const char* wsrc, char* smem, int wave, int g) {
+    const char* src = wsrc + (size_t)(g % NSTEP) * SB;
+    char* dst = smem + (g % NST) * SB;
+#pragma unroll
+    for (int i = 0; i < DPW; ++i) {
+      const int piece = wave + i * NW;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+    }
+  }
+  static constexpr int HS = NSTEP / 2;  // steps per half tile (input positions 0, 1 | 2, 3)
+  static_assert(NSTEP % 2 == 0 && (KS / 2) % KSTEP == 0, "a half tile is a whole number of steps");
+  template <int J, int Q>
+  static __device__ __forceinline__ void mma(const char* wl, const bf16x8 (&a)[KS / 2], f32x16 (&acc)[NT], bf16x8 (&f)[R]) {
+    if constexpr (Q + PRE < FR) f[(Q + PRE) % R] = *(const bf16x8*)(wl + (Q + PRE) * 1024);
+    constexpr int s = (J % HS) * KSTEP + Q / NT, t = Q % NT;
+    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], f[Q % R], acc[t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (Q + 1 < FR) mma<J, Q + 1>(wl, a, acc, f);
+  }
+  // steps J .. JE - 1 of a tile (one half)
+  template <int J, int JE>
+  static __device__ __forceinline__ void steps(const char* wsrc, char* smem, int wave, int lane, int g0, bool valid,
+                                               const bf16x8 (&a)[KS / 2], f32x16 (&acc)[NT]) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * DPW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    stage(wsrc, smem, wave, g0 + J + NST - 1);
+    if (valid) {
+      const char* wl = smem + (J % NST) * SB + lane * 16;
+      bf16x8 f[R];
+#pragma unroll
+      for (int q = 0; q < PRE; ++q) f[q] = *(const bf16x8*)(wl + q * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+      mma<J, 0>(wl, a, acc, f);
+    }
+    if constexpr (J + 1 < JE) steps<J + 1, JE>(wsrc, smem, wave, lane, g0, valid, a, acc);
+  }
+};
+
+template <int CP, int NW, int KSTEP, int NST>
+__global__ __launch_bounds__(NW * 64) void cn_down_fused_ring_kernel(const float* __restrict__ X, int H, int W, long P,
+                                                                     const bf16_t* __restrict__ WS, float* __restrict__ OUT) {
+  typedef DownGeom<CP> G;
+  typedef DownRing<CP, NW, KSTEP, NST> K;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float* biasp = (const float*)((const char*)WS + G::STREAM_BYTES);
+  const char* wsrc = (const char*)WS + lane * 16;
+  const long n_tiles = (P + 31) >> 5;
+  const long t_lo = (long)blockIdx.x * n_tiles / gridDim.x, t_hi = (long)(blockIdx.x + 1) * n_tiles / gridDim.x;
+  const int max_it = (int)((t_hi - t_lo + NW - 1) / NW);  // block-uniform: every wave runs the same number of steps
+#pragma unroll
+  for (int g = 0; g < NST - 1; ++g) K::stage(wsrc, smem, wave, g);
+  for (int it = 0; it < max_it; ++it) {
+    const long tile = t_lo + wave + (long)it * NW;
+    const bool valid = tile < t_hi;
+    const long ltile = valid ? tile : t_hi - 1;
+    f32x16 acc[G::NT];
+#pragma unroll
+    for (int t = 0; t < G::NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    {  // K in two halves: the operand of two input positions (96 registers) at a time
+      bf16x8 a[G::KS / 2];
+      cn_down_operand<CP, 0, 2>(X, H, W, P, ltile, lane, a);
+      K::template steps<0, K::HS>(wsrc, smem, wave, lane, it * K::NSTEP, valid, a, acc);
+      cn_down_operand<CP, 2, 2>(X, H, W, P, ltile, lane, a);
+      K::template steps<K::HS, K::NSTEP>(wsrc, smem, wave, lane, it * K::NSTEP, valid, a, acc);
+    }
+    if (valid) cn_down_store<CP>(OUT, biasp, P, tile, lane, acc);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring was filled NST - 1 entries past the end
+}
+
+template <int CP, int NW, int KSTEP, int NST>
+static int cn_launch_down_fused_ring(const float* X, int B, int H, int W, const void* WS, float* OUT, int n_blocks, hipStream_t s) {
+  typedef DownRing<CP, NW, KSTEP, NST> K;
+  static_assert(K::SMEM <= 160 * 1024, "ring must fit in LDS");
+  const long P = (long)B * (H / 2) * (W / 2);
+  CN_TRY(cn_configure_lds((const void*)cn_down_fused_ring_kernel<CP, NW, KSTEP, NST>, K::SMEM));
+  const int grid = cn_rc2_grid((int)((P + 31) / 32), NW, n_blocks);
+  hipLaunchKernelGGL((cn_down_fused_ring_kernel<CP, NW, KSTEP, NST>), dim3((unsigned)grid), dim3(NW * 64), K::SMEM, s, X, H, W, P,
+                     (const bf16_t*)WS, OUT);
   CN_LAUNCH_CHECK();
   return CN_OK;
 }

@@ -709,10 +709,14 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
       const long n_in = (long)B * Hp * Wp;
       const CnDownW& dw = ctx->down[st - 1];
       CnProfScope ps(ctx, CONETTE_PROF_DOWNSAMPLE, s);
-      if (std::is_same<T, bf16_t>::value && Cp == 96 && dw.fused != nullptr) {
-        // LayerNorm + patch GEMM in one kernel (down_fused.h); stages 0-2 run the fused MLP in bf16, so ws.h is free here
-        CN_TRY((cn_launch_down_fused<96, 8>(xc, B, Hp, Wp, dw.fused, (float*)ws.h, ctx->n_cu - ctx->enc_reserved_cus, s)));
-        xc = (float*)ws.h;
+      if (std::is_same<T, bf16_t>::value && Cp <= 192 && dw.fused != nullptr) {
+        // LayerNorm + patch GEMM in one kernel (down_fused.h).  It cannot run in place: the residual stream moves to the
+        // other of ws.x / ws.h (stages 0-2 run the fused MLP in bf16, so the hidden buffer is free until stage 3).
+        float* xo = xc == ws.x ? (float*)ws.h : ws.x;
+        const int nb = ctx->n_cu - ctx->enc_reserved_cus;
+        if (Cp == 96) CN_TRY((cn_launch_down_fused<96, 8>(xc, B, Hp, Wp, dw.fused, xo, nb, s)));
+        else CN_TRY((cn_launch_down_fused_ring<192, 4, 4, 3>(xc, B, Hp, Wp, dw.fused, xo, nb, s)));
+        xc = xo;
         if (taps) CN_TRY(tap_copy(taps->down[st], xc, (size_t)P * C, s));
       } else {
       const int ppb = Cp == 96 ? 32 : 16;           // positions per block: 4 waves x 4 groups x (2 | 1) positions
