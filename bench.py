@@ -246,7 +246,7 @@ def main() -> None:
     eng = Engine(sd, precision=args.precision, device=dev)
     if os.environ.get("CN_NO_GRAPH"):
         eng.set_decode_graph(False)
-    eng.set_encode_reserved_cus(int(os.environ.get("CN_ENC_RESERVE", "32")))
+    eng.set_encode_reserved_cus(int(os.environ.get("CN_ENC_RESERVE", "16")))
     bos_all = sd["model.task_id_to_token_id"]
     forbid = sd["model.forbid_rep_mask"].to(dev)
 
@@ -277,13 +277,17 @@ def main() -> None:
     n_enc = int(os.environ.get("CN_ENC_STREAMS", "1"))   # 2: encodes of consecutive batches on alternating streams (the blocks
     # of one batch start on the CUs the previous batch has left; measured 3 % slower than one stream, kept as a knob)
     s_encs = [torch.cuda.Stream(dev) for _ in range(max(1, min(n_enc, 2)))]
-    s_dec = torch.cuda.Stream(dev, priority=prio)
-    n_slot = 2
+    # CN_DEC_STREAMS decode chains in flight (default 2): a decode is a serial chain of ~300 latency-bound launches that
+    # stretches to the length of an encode when it shares the chip with one; with two chains (batches i-1 and i-2 decode
+    # while batch i encodes) a chain may take two steps, and the step is bounded by the encoder again.
+    n_dec = max(1, min(int(os.environ.get("CN_DEC_STREAMS", "2")), 3))
+    s_decs = [torch.cuda.Stream(dev, priority=prio) for _ in range(n_dec)]
+    n_slot = n_dec + 1
     slots = []
     for k, (w_, lens_, t_) in enumerate(batches):
         for sl in range(n_slot):
             slots.append(dict(
-                fe=eng.decode_input_buffer(w_.shape[0], t_, beam, max_pred, slot=2 * k + sl),
+                fe=eng.decode_input_buffer(w_.shape[0], t_, beam, max_pred, slot=n_slot * k + sl),
                 clip=torch.empty((w_.shape[0], 527), dtype=torch.float32, device=dev),
                 enc_done=torch.cuda.Event(), dec_done=torch.cuda.Event()))
     state = {"i": 0, "last": None}
@@ -294,22 +298,24 @@ def main() -> None:
         i = state["i"]
         res = []
         for k, (w_, lens_, t_) in enumerate(batches):
-            sl = slots[n_slot * k + (i & 1)]
+            sl = slots[n_slot * k + (i % n_slot)]
             bos = bos_dev[k]
             s_enc = s_encs[i % len(s_encs)]
+            s_dec = s_decs[i % n_dec]
             with torch.cuda.stream(s_enc):
-                if i >= 2:
-                    s_enc.wait_event(sl["dec_done"])          # slot's frame buffer (and encode workspace) is free again
+                if i >= n_slot:
+                    s_enc.wait_event(sl["dec_done"])          # slot's frame buffer is free again
                 eng.encode(w_, out=(sl["fe"], sl["clip"]), slot=i & 1)
                 sl["enc_done"].record(s_enc)
             with torch.cuda.stream(s_dec):
                 s_dec.wait_event(sl["enc_done"])
-                out = eng.decode(sl["fe"], lens_, bos, forbid, beam, min_pred, max_pred, clone=False, slot=n_slot * k + (i & 1))
+                out = eng.decode(sl["fe"], lens_, bos, forbid, beam, min_pred, max_pred, clone=False, slot=n_slot * k + (i % n_slot))
                 res.append((out["best_preds"], out["best_lprobs"]))
                 sl["dec_done"].record(s_dec)
-        with torch.cuda.stream(s_dec):
+        with torch.cuda.stream(s_decs[i % n_dec]):
             preds = res[0][0] if len(res) == 1 else torch.cat([r[0] for r in res])
             lps = res[0][1] if len(res) == 1 else torch.cat([r[1] for r in res])
+            state["last_local"] = (preds, lps)  # this rank's captions of the step (before the all-gather)
             if world > 1:
                 preds, lps = gather_captions(preds, lps, total_clips)
         state["i"] = i + 1
@@ -322,7 +328,7 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    warm_used = max(args.warmup, 6)  # >= 3 per slot: the third identical decode call replays its hipGraph
+    warm_used = max(args.warmup, 3 * n_slot)  # >= 3 per slot: the third identical decode call replays its hipGraph
     for _ in range(warm_used):
         step()
     fence()
@@ -345,6 +351,7 @@ def main() -> None:
     encode_ms, decode_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
     stage_ms = {k: round(v[0], 4) for k, v in pre.items()}
     dominant = max(("pw1_gemm", "pw2_gemm", "dwconv_ln"), key=lambda k: pre.get(k, (0.0, 0))[0])
+    solo_preds, solo_lps = out["best_preds"].clone(), out["best_lprobs"].clone()  # un-pipelined result of batch 0
     bm = int(out["sizes"][1].item())
     best = out["best_preds"][:, :bm]
     best_tokens = int((best != 0).sum().item())            # tokens of the returned captions (<eos> included)
@@ -359,6 +366,22 @@ def main() -> None:
         step()
     fence()
     dt = time.perf_counter() - t0
+    # the pipelined steps (encode of batch i next to the decodes of batches i-1, i-2) must reproduce the solo pass bit for bit
+    lp_, ll_ = state["last_local"][0][:B0], state["last_local"][1][:B0]
+    pipeline_consistent = bool(torch.equal(lp_[:, : solo_preds.shape[1]], solo_preds[: lp_.shape[0], : lp_.shape[1]]) and
+                               torch.equal(ll_, solo_lps[: ll_.shape[0]]))
+    if not pipeline_consistent and os.environ.get("CN_BENCH_DEBUG"):
+        eng.encode(w0, out=(slots[0]["fe"], slots[0]["clip"]))
+        o2 = eng.decode(slots[0]["fe"], lens0, bos0, forbid, beam, min_pred, max_pred, clone=True, slot=0)
+        torch.cuda.synchronize(dev)
+        print("[bench] solo again == solo pre:", torch.equal(o2["best_preds"], solo_preds), torch.equal(o2["best_lprobs"], solo_lps),
+              "| solo again == pipelined:", torch.equal(o2["best_preds"], lp_), torch.equal(o2["best_lprobs"], ll_), file=sys.stderr, flush=True)
+    if not pipeline_consistent:
+        a_, b_ = lp_[:, : solo_preds.shape[1]], solo_preds[: lp_.shape[0], : lp_.shape[1]]
+        rows = (a_ != b_).any(dim=1).nonzero().flatten().tolist()
+        print("[bench] differing rows:", rows[:16], "of", a_.shape[0], "| lprob diffs:", int((ll_ != solo_lps[: ll_.shape[0]]).sum()),
+              "| example:", a_[rows[0]].tolist() if rows else None, b_[rows[0]].tolist() if rows else None, file=sys.stderr, flush=True)
+        raise SystemExit("bench: the pipelined steps returned other captions than the un-pipelined pass of the same batch")
     prof = eng.profile_read()
     eng.profile_enable(())
     if world > 1:
@@ -409,7 +432,7 @@ def main() -> None:
                   f"(min 3 / max 20 tokens, V=5631), synthetic seeded checkpoint")
         result = {
             "metric": "clips_per_sec", "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "warmup_run": warm_used, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "steps": args.steps, "warmup": args.warmup, "warmup_run": warm_used, "ms_per_step": round(dt / args.steps * 1e3, 3), "pipeline_consistent": pipeline_consistent,
             "timed_region_s": round(dt, 4),
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",

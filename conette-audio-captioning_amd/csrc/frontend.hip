@@ -47,7 +47,11 @@ __device__ __forceinline__ void cn_wave_sync() { __builtin_amdgcn_wave_barrier()
 
 #define FE_PITCH 72  // complex elements per transpose row (64 + 8 pad)
 
-__global__ __launch_bounds__(256) void cn_logmel_kernel(const float* __restrict__ wave, int L, int F, int total,
+#ifndef FE_NW
+#define FE_NW 16  // waves (= frames in flight) per block
+#endif
+#define FE_FILL_BYTES (16 * 1024)  // unused dynamic LDS on top of the 117 KB of static arrays: the block owns >= 132 KB of the CU's 160
+__global__ __launch_bounds__(FE_NW * 64) void cn_logmel_kernel(const float* __restrict__ wave, int L, int F, int total,
                                                         const float* __restrict__ window,
                                                         const float2* __restrict__ tw512,
                                                         const float2* __restrict__ tw1024,
@@ -57,17 +61,21 @@ __global__ __launch_bounds__(256) void cn_logmel_kernel(const float* __restrict_
   __shared__ float2 s_tw512[512];
   __shared__ float2 s_tw1024[513];
   __shared__ float s_win[1024];
-  __shared__ float2 s_x[4][8 * FE_PITCH];
-  __shared__ float s_p[4][520];
+  __shared__ float2 s_x[FE_NW][8 * FE_PITCH];
+  __shared__ float s_p[FE_NW][520];
+  // A block takes a compute unit's LDS for itself (>= 132 KB of 160): nothing that needs an LDS tile can start beside it.
+  // (Frames came out wrong, a 16-lane quarter of one VALU result at a time, whenever the decoder's small GEMM workgroups
+  // shared a CU with this kernel on another stream: profiles/r02_notes.md, tools/pipeline_probe3.py.)
+  // (the launch adds FE_FILL_BYTES of unused dynamic LDS)
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  for (int i = tid; i < 512; i += 256) s_tw512[i] = tw512[i];
-  for (int i = tid; i < 513; i += 256) s_tw1024[i] = tw1024[i];
-  for (int i = tid; i < 1024; i += 256) s_win[i] = window[i];
+  for (int i = tid; i < 512; i += FE_NW * 64) s_tw512[i] = tw512[i];
+  for (int i = tid; i < 513; i += FE_NW * 64) s_tw1024[i] = tw1024[i];
+  for (int i = tid; i < 1024; i += FE_NW * 64) s_win[i] = window[i];
   __syncthreads();
   float2* sx = s_x[wv];
   float* sp = s_p[wv];
 
-  for (int base = blockIdx.x * 4; base < total; base += gridDim.x * 4) {
+  for (int base = blockIdx.x * FE_NW; base < total; base += gridDim.x * FE_NW) {
     const int fr = base + wv;
     const bool act = fr < total;
     float2 v[8];
@@ -155,9 +163,10 @@ int cn_frontend(conette_ctx* ctx, const float* wave, int B, int L, float* out, h
   }
   const int F = L / CN_HOP + 1;
   const long total = (long)B * F;
-  int grid = (int)((total + 3) / 4);
-  if (grid > 256 * 8) grid = 256 * 8;
-  hipLaunchKernelGGL(cn_logmel_kernel, dim3(grid), dim3(256), 0, s, wave, L, F, (int)total, ctx->window, ctx->tw512,
+  int grid = (int)((total + FE_NW - 1) / FE_NW);
+  if (grid > ctx->n_cu) grid = ctx->n_cu;  // one block per compute unit (its LDS), each walking its share of the frames
+  CN_TRY(cn_configure_lds((const void*)cn_logmel_kernel, FE_FILL_BYTES));
+  hipLaunchKernelGGL(cn_logmel_kernel, dim3(grid), dim3(FE_NW * 64), FE_FILL_BYTES, s, wave, L, F, (int)total, ctx->window, ctx->tw512,
                      ctx->tw1024, ctx->melC, ctx->band, ctx->bn_scale, ctx->bn_shift, out);
   CN_LAUNCH_CHECK();
   return CN_OK;

@@ -319,7 +319,7 @@ class Engine:
             buf["forbid"].copy_(forbid_mask.to(torch.uint8), non_blocking=True)
             forbid_ptr = buf["forbid"]
         need = self.lib.conette_decode_workspace_bytes(self._ctx, b, t, beam, max_pred)
-        wsb = self._workspace("dec", need)  # one workspace: decodes of all slots serialise on their stream
+        wsb = self._workspace("dec" if slot == 0 else f"dec{slot}", need)  # per slot: decodes of different slots may run on different streams
         st = self.lib.conette_decode(self._ctx, _ptr(buf["fe"]), _ptr(buf["lens"]), _ptr(buf["bos"]), _ptr(forbid_ptr),
                                      b, t, beam, min_pred, max_pred, _ptr(buf["best_preds"]), _ptr(buf["best_lprobs"]),
                                      _ptr(buf["mult_preds"]), _ptr(buf["mult_lprobs"]), _ptr(buf["sizes"]),
