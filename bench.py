@@ -246,7 +246,7 @@ def main() -> None:
     eng = Engine(sd, precision=args.precision, device=dev)
     if os.environ.get("CN_NO_GRAPH"):
         eng.set_decode_graph(False)
-    eng.set_encode_reserved_cus(int(os.environ.get("CN_ENC_RESERVE", "16")))
+    eng.set_encode_reserved_cus(int(os.environ.get("CN_ENC_RESERVE", "24")))
     bos_all = sd["model.task_id_to_token_id"]
     forbid = sd["model.forbid_rep_mask"].to(dev)
 
