@@ -50,8 +50,8 @@ PMC_KERNELS = {
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=0, help="total clips, sharded over the GPUs (strong scaling)")
     ap.add_argument("--beam", type=int, default=3)
