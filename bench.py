@@ -370,18 +370,17 @@ def main() -> None:
     lp_, ll_ = state["last_local"][0][:B0], state["last_local"][1][:B0]
     pipeline_consistent = bool(torch.equal(lp_[:, : solo_preds.shape[1]], solo_preds[: lp_.shape[0], : lp_.shape[1]]) and
                                torch.equal(ll_, solo_lps[: ll_.shape[0]]))
-    if not pipeline_consistent and os.environ.get("CN_BENCH_DEBUG"):
-        eng.encode(w0, out=(slots[0]["fe"], slots[0]["clip"]))
-        o2 = eng.decode(slots[0]["fe"], lens0, bos0, forbid, beam, min_pred, max_pred, clone=True, slot=0)
-        torch.cuda.synchronize(dev)
-        print("[bench] solo again == solo pre:", torch.equal(o2["best_preds"], solo_preds), torch.equal(o2["best_lprobs"], solo_lps),
-              "| solo again == pipelined:", torch.equal(o2["best_preds"], lp_), torch.equal(o2["best_lprobs"], ll_), file=sys.stderr, flush=True)
     if not pipeline_consistent:
         a_, b_ = lp_[:, : solo_preds.shape[1]], solo_preds[: lp_.shape[0], : lp_.shape[1]]
         rows = (a_ != b_).any(dim=1).nonzero().flatten().tolist()
-        print("[bench] differing rows:", rows[:16], "of", a_.shape[0], "| lprob diffs:", int((ll_ != solo_lps[: ll_.shape[0]]).sum()),
-              "| example:", a_[rows[0]].tolist() if rows else None, b_[rows[0]].tolist() if rows else None, file=sys.stderr, flush=True)
-        raise SystemExit("bench: the pipelined steps returned other captions than the un-pipelined pass of the same batch")
+        print(f"[bench] rank {rank}: the pipelined steps returned other captions than the un-pipelined pass of the same batch: rows",
+              rows[:16], "of", a_.shape[0], "| score diffs:", int((ll_ != solo_lps[: ll_.shape[0]]).sum()), file=sys.stderr, flush=True)
+    if world > 1:  # every rank must agree before a number is printed
+        flag = torch.tensor([1 if pipeline_consistent else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        pipeline_consistent = bool(flag.item())
+    if not pipeline_consistent and os.environ.get("CN_BENCH_STRICT", "1") != "0":
+        raise SystemExit("bench: pipelined and un-pipelined results differ (CN_BENCH_STRICT=0 reports the number anyway, with pipeline_consistent false)")
     prof = eng.profile_read()
     eng.profile_enable(())
     if world > 1:
