@@ -345,15 +345,74 @@ static int launch_dwconv(const float* x, int B, int H, int W, const CnBlockW& bw
 // block-uniform branch.  LayerNorm: conv results through an LDS tile [pos][C], one wave per position with DPP
 // sums, two positions in flight; 16-byte bf16 stores as in the tiled kernel.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int C, int WW, int TH>
-__global__ __launch_bounds__(384) void cn_dwconv_ln_fw_kernel(const float* __restrict__ x, int H, int tiles_h,
+// The convolution of one channel for output columns [OW0, OW0 + NOW) of TH rows: the thread loads the NQ input columns those
+// outputs can see and keeps TH x NOW accumulators.  SPLIT = 2 (C = 384) gives each half of the width to its own thread, so a
+// block has twice the waves over the same LDS tile (12 per CU instead of 6) and a thread half the accumulators; the taps of
+// an output are still added in the same (kh, kw) order, so the result does not depend on SPLIT.
+template <int C, int WW, int TH, int OW0, int NOW>
+__device__ __forceinline__ void cn_fw_conv(const float* __restrict__ xb /* + c */, int H, int h0,
+                                           const float* __restrict__ dw_w, float bias, int c, float* __restrict__ s_v,
+                                           int PITCH) {
+  constexpr int Q0 = OW0 - 3 < 0 ? 0 : OW0 - 3, Q1 = OW0 + NOW + 3 > WW ? WW : OW0 + NOW + 3, NQ = Q1 - Q0;
+  float k[49];
+#pragma unroll
+  for (int i = 0; i < 49; ++i) k[i] = dw_w[i * C + c];
+  float acc[TH][NOW];
+#pragma unroll
+  for (int a = 0; a < TH; ++a)
+#pragma unroll
+    for (int e = 0; e < NOW; ++e) acc[a][e] = bias;
+  auto load_row = [&](int r, float (&v)[NQ]) {
+    const int hh = h0 - 3 + r;
+    if (hh >= 0 && hh < H) {  // block-uniform
+      const float* xr = xb + (size_t)hh * WW * C;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) v[q] = xr[(Q0 + q) * C];
+    } else {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) v[q] = 0.f;
+    }
+  };
+  auto fma_row = [&](int r, const float (&v)[NQ]) {
+#pragma unroll
+    for (int oh = 0; oh < TH; ++oh) {
+      const int i = r - oh;
+      if (i < 0 || i > 6) continue;
+#pragma unroll
+      for (int ow = 0; ow < NOW; ++ow)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          const int q = OW0 + ow + j - 3;
+          if (q < 0 || q >= WW) continue;  // zero padding left / right of the map: the tap does not exist
+          acc[oh][ow] = fmaf(v[q - Q0], k[i * 7 + j], acc[oh][ow]);
+        }
+    }
+  };
+  float va[NQ], vb[NQ];
+  load_row(0, va);
+#pragma unroll
+  for (int r = 0; r < TH + 6; r += 2) {
+    if (r + 1 < TH + 6) load_row(r + 1, vb);
+    fma_row(r, va);
+    if (r + 2 < TH + 6) load_row(r + 2, va);
+    if (r + 1 < TH + 6) fma_row(r + 1, vb);
+  }
+#pragma unroll
+  for (int oh = 0; oh < TH; ++oh)
+#pragma unroll
+    for (int ow = 0; ow < NOW; ++ow) s_v[(oh * WW + OW0 + ow) * PITCH + c] = acc[oh][ow];
+}
+
+template <typename T, int C, int WW, int TH, int SPLIT>
+__global__ __launch_bounds__(C* SPLIT > 384 ? 768 : 384) void cn_dwconv_ln_fw_kernel(const float* __restrict__ x, int H, int tiles_h,
                                                               const float* __restrict__ dw_w /*[49][C]*/,
                                                               const float* __restrict__ dw_b,
                                                               const float* __restrict__ ln_w,
                                                               const float* __restrict__ ln_b, T* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* s_v = (float*)smem_raw;  // [TH*WW][C + 1]
-  constexpr int CT = 384, NPOS = TH * WW, PITCH = C + 4, NW = CT / 64;  // 16-byte aligned rows, odd chunk count
+  float* s_v = (float*)smem_raw;  // [TH*WW][C + 4]
+  constexpr int CT = C * SPLIT > 384 ? 768 : 384, NPOS = TH * WW, PITCH = C + 4, NW = CT / 64;  // 16-byte aligned rows, odd chunk count
+  static_assert(SPLIT == 1 || (SPLIT == 2 && C == 384 && WW % 2 == 0), "the width is split in two only at C = 384");
   float* s_mean = s_v + NPOS * PITCH;
   float* s_rstd = s_mean + NPOS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -361,58 +420,17 @@ __global__ __launch_bounds__(384) void cn_dwconv_ln_fw_kernel(const float* __res
   const int th = bid % tiles_h;
   const int b = bid / tiles_h;
   const int h0 = th * TH;
+  const float* xb0 = x + (size_t)b * H * WW * C;
 
+  if constexpr (SPLIT == 1) {
 #pragma unroll 1
-  for (int c = tid; c < C; c += CT) {
-    float k[49];
-#pragma unroll
-    for (int i = 0; i < 49; ++i) k[i] = dw_w[i * C + c];
-    float acc[TH][WW];
-    const float bias = dw_b[c];
-#pragma unroll
-    for (int a = 0; a < TH; ++a)
-#pragma unroll
-      for (int e = 0; e < WW; ++e) acc[a][e] = bias;
-    const float* xb = x + (size_t)b * H * WW * C + c;
-    auto load_row = [&](int r, float (&v)[WW]) {
-      const int hh = h0 - 3 + r;
-      if (hh >= 0 && hh < H) {  // block-uniform
-        const float* xr = xb + (size_t)hh * WW * C;
-#pragma unroll
-        for (int q = 0; q < WW; ++q) v[q] = xr[q * C];
-      } else {
-#pragma unroll
-        for (int q = 0; q < WW; ++q) v[q] = 0.f;
-      }
-    };
-    auto fma_row = [&](int r, const float (&v)[WW]) {
-#pragma unroll
-      for (int oh = 0; oh < TH; ++oh) {
-        const int i = r - oh;
-        if (i < 0 || i > 6) continue;
-#pragma unroll
-        for (int ow = 0; ow < WW; ++ow)
-#pragma unroll
-          for (int j = 0; j < 7; ++j) {
-            const int q = ow + j - 3;
-            if (q < 0 || q >= WW) continue;  // zero padding left / right of the map: the tap does not exist
-            acc[oh][ow] = fmaf(v[q], k[i * 7 + j], acc[oh][ow]);
-          }
-      }
-    };
-    float va[WW], vb[WW];
-    load_row(0, va);
-#pragma unroll
-    for (int r = 0; r < TH + 6; r += 2) {
-      if (r + 1 < TH + 6) load_row(r + 1, vb);
-      fma_row(r, va);
-      if (r + 2 < TH + 6) load_row(r + 2, va);
-      if (r + 1 < TH + 6) fma_row(r + 1, vb);
-    }
-#pragma unroll
-    for (int oh = 0; oh < TH; ++oh)
-#pragma unroll
-      for (int ow = 0; ow < WW; ++ow) s_v[(oh * WW + ow) * PITCH + c] = acc[oh][ow];
+    for (int c = tid; c < C; c += CT) cn_fw_conv<C, WW, TH, 0, WW>(xb0 + c, H, h0, dw_w, dw_b[c], c, s_v, PITCH);
+  } else {
+    const int c = tid < C ? tid : tid - C;  // waves 0-5: left half, waves 6-11: right half (wave-uniform)
+    if (tid < C)
+      cn_fw_conv<C, WW, TH, 0, WW / 2>(xb0 + c, H, h0, dw_w, dw_b[c], c, s_v, PITCH);
+    else
+      cn_fw_conv<C, WW, TH, WW / 2, WW / 2>(xb0 + c, H, h0, dw_w, dw_b[c], c, s_v, PITCH);
   }
   __syncthreads();
   // LayerNorm statistics: wave per position, C / 64 values per lane, two positions per iteration
@@ -460,12 +478,15 @@ __global__ __launch_bounds__(384) void cn_dwconv_ln_fw_kernel(const float* __res
   }
 }
 
-template <typename T, int C, int WW, int TH>
+#ifndef CN_FW_SPLIT
+#define CN_FW_SPLIT 2
+#endif
+template <typename T, int C, int WW, int TH, int SPLIT = 1>
 static int launch_dwconv_fw(const float* x, int B, int H, const CnBlockW& bw, T* y, hipStream_t s) {
   const int tiles_h = cn_cdiv(H, TH);
   const size_t smem = ((size_t)TH * WW * (C + 4) + 2 * TH * WW) * sizeof(float);
-  CN_TRY(cn_configure_lds((const void*)cn_dwconv_ln_fw_kernel<T, C, WW, TH>, (int)smem));
-  hipLaunchKernelGGL((cn_dwconv_ln_fw_kernel<T, C, WW, TH>), dim3((unsigned)(B * tiles_h)), dim3(384), smem, s, x, H,
+  CN_TRY(cn_configure_lds((const void*)cn_dwconv_ln_fw_kernel<T, C, WW, TH, SPLIT>, (int)smem));
+  hipLaunchKernelGGL((cn_dwconv_ln_fw_kernel<T, C, WW, TH, SPLIT>), dim3((unsigned)(B * tiles_h)), dim3(C * SPLIT > 384 ? 768 : 384), smem, s, x, H,
                      tiles_h, bw.dw_w, bw.dw_b, bw.ln_w, bw.ln_b, y);
   CN_LAUNCH_CHECK();
   return CN_OK;
@@ -664,7 +685,7 @@ static int dwconv_dispatch(int C, const float* x, int B, int H, int W, const CnB
     case 96: return launch_dwconv<T, 96, 2, 8>(x, B, H, W, bw, y, s);
     case 192: return launch_dwconv<T, 192, 1, 8>(x, B, H, W, bw, y, s);
     case 384:
-      if (W == 14) return launch_dwconv_fw<T, 384, 14, 4>(x, B, H, bw, y, s);
+      if (W == 14) return launch_dwconv_fw<T, 384, 14, 4, CN_FW_SPLIT>(x, B, H, bw, y, s);
       return launch_dwconv<T, 384, 1, 4>(x, B, H, W, bw, y, s);
     case 768:
       if (W == 7) return launch_dwconv_fw<T, 768, 7, 4>(x, B, H, bw, y, s);
