@@ -329,6 +329,7 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
       float* dmc = (float*)B.alloc(mc.size() * 4);
       hipMemcpy(dmc, mc.data(), mc.size() * 4, hipMemcpyHostToDevice);
       ctx->melC = dmc;
+      ctx->mel_rows = maxw;
     }
     int* dband = (int*)B.alloc(band.size() * 4);
     hipMemcpy(dband, band.data(), band.size() * 4, hipMemcpyHostToDevice);

@@ -76,6 +76,7 @@ struct conette_ctx {
   const float2* tw512;     // [512]
   const float2* tw1024;    // [513]
   const int* band;         // [224][2] lo, hi
+  int mel_rows;            // rows of melC (the widest band)
   const float* melC;       // [max band width][224]: melC[i][m] = melW[band lo(m) + i][m] (lanes = mel bins read consecutive words)
   const float* bn_scale;   // [224]
   const float* bn_shift;   // [224]

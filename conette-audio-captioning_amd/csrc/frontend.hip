@@ -50,8 +50,10 @@ __device__ __forceinline__ void cn_wave_sync() { __builtin_amdgcn_wave_barrier()
 #ifndef FE_NW
 #define FE_NW 16  // waves (= frames in flight) per block
 #endif
-#define FE_FILL_BYTES (16 * 1024)  // unused dynamic LDS on top of the 117 KB of static arrays: the block owns >= 132 KB of the CU's 160
-__global__ __launch_bounds__(FE_NW * 64) void cn_logmel_kernel(const float* __restrict__ wave, int L, int F, int total,
+#define FE_FILL_BYTES (16 * 1024)  // dynamic LDS on top of the 117 KB of static arrays: the block owns >= 132 KB of the CU's 160
+#define FE_MEL_LDS_MAX (40 * 1024)  // the band-compact mel matrix lives in that dynamic LDS when it fits (it does: ~16 rows x 224)
+template <bool MEL_LDS>
+__global__ __launch_bounds__(FE_NW * 64) void cn_logmel_kernel(const float* __restrict__ wave, int L, int F, int total, int mel_rows,
                                                         const float* __restrict__ window,
                                                         const float2* __restrict__ tw512,
                                                         const float2* __restrict__ tw1024,
@@ -60,20 +62,37 @@ __global__ __launch_bounds__(FE_NW * 64) void cn_logmel_kernel(const float* __re
                                                         const float* __restrict__ bn_shift, float* __restrict__ out) {
   __shared__ float2 s_tw512[512];
   __shared__ float2 s_tw1024[513];
-  __shared__ float s_win[1024];
+  __shared__ __attribute__((aligned(16))) float s_win[1024];
   __shared__ float2 s_x[FE_NW][8 * FE_PITCH];
   __shared__ float s_p[FE_NW][520];
   // A block takes a compute unit's LDS for itself (>= 132 KB of 160): nothing that needs an LDS tile can start beside it.
   // (Frames came out wrong, a 16-lane quarter of one VALU result at a time, whenever the decoder's small GEMM workgroups
   // shared a CU with this kernel on another stream: profiles/r02_notes.md, tools/pipeline_probe3.py.)
-  // (the launch adds FE_FILL_BYTES of unused dynamic LDS)
+  // (the launch adds >= FE_FILL_BYTES of dynamic LDS; it holds the mel matrix when that fits)
+  extern __shared__ __attribute__((aligned(16))) float s_mel[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (MEL_LDS)
+    for (int i = tid; i < mel_rows * CN_N_MELS; i += FE_NW * 64) s_mel[i] = melC[i];
   for (int i = tid; i < 512; i += FE_NW * 64) s_tw512[i] = tw512[i];
   for (int i = tid; i < 513; i += FE_NW * 64) s_tw1024[i] = tw1024[i];
   for (int i = tid; i < 1024; i += FE_NW * 64) s_win[i] = window[i];
   __syncthreads();
   float2* sx = s_x[wv];
   float* sp = s_p[wv];
+  // mel bands of this lane's four bins; the trip count of a group of 64 bins is its widest band (rows past a bin's own band
+  // hold zeros in melC, and acc + p * 0 = acc, so the sum is still the dense row's sum in the dense row's order)
+  int m_lo[4], m_trip[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int m = lane + 64 * g;
+    const bool on = m < CN_N_MELS;
+    m_lo[g] = on ? band[2 * m] : 0;
+    int nb = on ? band[2 * m + 1] - m_lo[g] : 0;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) nb = max(nb, __shfl_xor(nb, d));
+    m_trip[g] = min(nb, mel_rows);
+  }
+  const bool pair_loads = (L & 1) == 0 && (((size_t)wave) & 7) == 0;  // every even sample index is 8-byte aligned
 
   for (int base = blockIdx.x * FE_NW; base < total; base += gridDim.x * FE_NW) {
     const int fr = base + wv;
@@ -83,14 +102,24 @@ __global__ __launch_bounds__(FE_NW * 64) void cn_logmel_kernel(const float* __re
     if (act) {
       const int b = fr / F, f = fr - b * F;
       const float* x = wave + (size_t)b * L;
-      const int p0 = f * CN_HOP - CN_N_FFT / 2;
+      const int p0 = f * CN_HOP - CN_N_FFT / 2;  // even
+      if (pair_loads && p0 >= 0 && p0 + CN_N_FFT <= L) {  // the whole window inside the clip (wave-uniform): 8-byte loads
 #pragma unroll
-      for (int a = 0; a < 8; ++a) {
-        const int n2 = 2 * (64 * a + lane);
-        int q0 = p0 + n2, q1 = q0 + 1;
-        q0 = q0 < 0 ? -q0 : (q0 >= L ? 2 * L - 2 - q0 : q0);  // reflect (no edge repeat)
-        q1 = q1 < 0 ? -q1 : (q1 >= L ? 2 * L - 2 - q1 : q1);
-        v[a] = float2{x[q0] * s_win[n2], x[q1] * s_win[n2 + 1]};
+        for (int a = 0; a < 8; ++a) {
+          const int n2 = 2 * (64 * a + lane);
+          const float2 xv = *(const float2*)(x + p0 + n2);
+          const float2 wv2 = *(const float2*)(s_win + n2);
+          v[a] = float2{xv.x * wv2.x, xv.y * wv2.y};
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+          const int n2 = 2 * (64 * a + lane);
+          int q0 = p0 + n2, q1 = q0 + 1;
+          q0 = q0 < 0 ? -q0 : (q0 >= L ? 2 * L - 2 - q0 : q0);  // reflect (no edge repeat)
+          q1 = q1 < 0 ? -q1 : (q1 >= L ? 2 * L - 2 - q1 : q1);
+          v[a] = float2{x[q0] * s_win[n2], x[q1] * s_win[n2 + 1]};
+        }
       }
     } else {
 #pragma unroll
@@ -144,9 +173,21 @@ __global__ __launch_bounds__(FE_NW * 64) void cn_logmel_kernel(const float* __re
       for (int g = 0; g < 4; ++g) {
         const int m = lane + 64 * g;
         if (m < CN_N_MELS) {
-          const int lo = band[2 * m], nb = band[2 * m + 1] - lo;
+          const int lo = m_lo[g], trip = m_trip[g];
+          const float* mc = MEL_LDS ? s_mel : melC;
           float acc = 0.f;
-          for (int i = 0; i < nb; ++i) acc = fmaf(sp[lo + i], melC[i * CN_N_MELS + m], acc);  // bins lo, lo+1, ..: same order as the dense row
+          int i = 0;
+          for (; i + 4 <= trip; i += 4) {  // bins lo, lo+1, ..: same order as the dense row
+            float p[4], w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              p[u] = sp[min(lo + i + u, CN_N_BINS - 1)];
+              w[u] = mc[(i + u) * CN_N_MELS + m];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = fmaf(p[u], w[u], acc);
+          }
+          for (; i < trip; ++i) acc = fmaf(sp[min(lo + i, CN_N_BINS - 1)], mc[i * CN_N_MELS + m], acc);
           const float db = 10.0f * log10f(fmaxf(acc, 1e-10f));
           out[(size_t)fr * CN_N_MELS + m] = db * bn_scale[m] + bn_shift[m];
         }
@@ -165,9 +206,17 @@ int cn_frontend(conette_ctx* ctx, const float* wave, int B, int L, float* out, h
   const long total = (long)B * F;
   int grid = (int)((total + FE_NW - 1) / FE_NW);
   if (grid > ctx->n_cu) grid = ctx->n_cu;  // one block per compute unit (its LDS), each walking its share of the frames
-  CN_TRY(cn_configure_lds((const void*)cn_logmel_kernel, FE_FILL_BYTES));
-  hipLaunchKernelGGL(cn_logmel_kernel, dim3(grid), dim3(FE_NW * 64), FE_FILL_BYTES, s, wave, L, F, (int)total, ctx->window, ctx->tw512,
-                     ctx->tw1024, ctx->melC, ctx->band, ctx->bn_scale, ctx->bn_shift, out);
+  const int mel_bytes = ctx->mel_rows * CN_N_MELS * 4;
+  if (mel_bytes <= FE_MEL_LDS_MAX) {
+    const int dyn = mel_bytes > FE_FILL_BYTES ? mel_bytes : FE_FILL_BYTES;
+    CN_TRY(cn_configure_lds((const void*)cn_logmel_kernel<true>, dyn));
+    hipLaunchKernelGGL(cn_logmel_kernel<true>, dim3(grid), dim3(FE_NW * 64), dyn, s, wave, L, F, (int)total, ctx->mel_rows,
+                       ctx->window, ctx->tw512, ctx->tw1024, ctx->melC, ctx->band, ctx->bn_scale, ctx->bn_shift, out);
+  } else {  // a checkpoint with very wide mel bands: the matrix stays in global memory
+    CN_TRY(cn_configure_lds((const void*)cn_logmel_kernel<false>, FE_FILL_BYTES));
+    hipLaunchKernelGGL(cn_logmel_kernel<false>, dim3(grid), dim3(FE_NW * 64), FE_FILL_BYTES, s, wave, L, F, (int)total,
+                       ctx->mel_rows, ctx->window, ctx->tw512, ctx->tw1024, ctx->melC, ctx->band, ctx->bn_scale, ctx->bn_shift, out);
+  }
   CN_LAUNCH_CHECK();
   return CN_OK;
 }
