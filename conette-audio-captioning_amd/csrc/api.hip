@@ -408,7 +408,7 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
           const float* w2 = B.find(p + "pwconv2.weight", (int64_t)4 * C * C);
           if (w1 && w2 && bw.b1 && bw.b2 && bw.scale) {
             const int units = (C / 8) * (C / 8 + 1) * 64;
-            hipLaunchKernelGGL(pk_mlp_rc2, dim3((units + 255) / 256), dim3(256), 0, 0, w1, bw.b1, w2, bw.b2, bw.scale, C, 1, ms);
+            hipLaunchKernelGGL(pk_mlp_rc2, dim3((units + 255) / 256), dim3(256), 0, 0, w1, bw.b1, w2, bw.b2, bw.scale, C, CN_RC2_NCK(C), ms);
             bw.mlp_stream = ms;
           }
         }

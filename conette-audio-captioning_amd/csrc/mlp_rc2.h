@@ -94,10 +94,25 @@ static __global__ void pk_mlp_rc2(const float* __restrict__ W1, const float* __r
   for (int i = 0; i < 8; ++i) dst[(size_t)u * 8 + i] = (bf16_t)v[i];
 }
 
+// hidden chunks (of 32) per step: two at C = 192 (3-deep ring of 50 KB entries), one elsewhere
+#define CN_RC2_NCK(C) ((C) == 192 ? 2 : 1)
+
 // sched_group_barrier masks (LLVM AMDGPU IGroupLP)
 #define CN_SG_VALU 0x002
 #define CN_SG_MFMA 0x008
 #define CN_SG_DSR 0x100
+
+// One 1 KB piece of a ring entry, global -> LDS (wave-uniform base addresses, lane * 16 as the only vector operand).
+// Inline asm, not __builtin_amdgcn_global_load_lds: with the builtin pending, the compiler's wait-count pass treats every
+// later LDS read as possibly out of order and emits `s_waitcnt lgkmcnt(0)` in front of every fifth MFMA of the step loop
+// where lgkmcnt(3) was meant.  The compiler does not count these pieces in vmcnt; the ring's own waits are written by hand
+// below, and a compiler wait that does not know about pieces in flight only waits for more than it needs (the counter
+// retires in order), never for less.
+// (Lab: issuing piece q inside the step, behind MFMA q by wave q % NW, moved the ~70 cycles a piece costs its wave from
+// the top of the step into the step, MFMAs or not: 201 us against 189.  profiles/r02_notes.md)
+__device__ __forceinline__ void cn_rc2_dma_piece(const char* src, unsigned lds, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(lds) : "memory", "m0");
+}
 
 template <int C, int NCK> struct Rc2Wave {
   typedef Rc2Geom<C, NCK> G;
@@ -320,16 +335,15 @@ __global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_ring_kernel(const bf16_t* 
   const int t_lo = (int)((long)blockIdx.x * n_tiles / gridDim.x), t_hi = (int)((long)(blockIdx.x + 1) * n_tiles / gridDim.x);
   const int max_it = (t_hi - t_lo + NW - 1) / NW;  // block-uniform: every wave runs the same number of steps
 
-  const char* wsrc = (const char*)WS + lane * 16;
+  const unsigned voff = lane * 16;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   auto stage = [&](int g) {  // stream step g % NSTEP -> slot g % NST (this wave's pieces)
-    const char* src = wsrc + (size_t)(g % G::NSTEP) * SB;
-    char* dst = smem + (g % NST) * SB;
+    const char* src = (const char*)WS + (size_t)(g % G::NSTEP) * SB;  // wave-uniform
+    const unsigned dst = lds0 + (unsigned)((g % NST) * SB);
 #pragma unroll
     for (int i = 0; i < DPW_LO + 1; ++i) {
       const int piece = wave + i * NW;
-      if (i < DPW_LO || wave < N_HI)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
-                                         (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+      if (i < DPW_LO || wave < N_HI) cn_rc2_dma_piece(src + piece * 1024, dst + piece * 1024, voff);
     }
   };
   bf16x8 ones;
@@ -346,6 +360,13 @@ __global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_ring_kernel(const bf16_t* 
     const int tile = t_lo + wave + it * NW;
     const bool valid = tile < t_hi;
     f32x16 O[G::NT2];
+    if (valid) W::init_o(X, tile * 32, lane, O);
+    {
+      // The residual (and the y fragments requested at the end of the last tile) land HERE, once per tile, in a wait the
+      // compiler sees and that dominates the step loop: otherwise the step code, shared by every j, carries the waits for
+      // their first uses, and those -- counted or not -- drain the ring's pieces in flight at every step.
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), on every path into the loop (the compiler's bookkeeping is not path-sensitive)
+    }
     for (int j = 0; j < G::NSTEP; ++j, ++g) {
       stamp(4);
       if (N_HI > 0 && wave < N_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (DPW_LO + 1)) : "memory");
@@ -354,14 +375,17 @@ __global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_ring_kernel(const bf16_t* 
       __builtin_amdgcn_s_barrier();
       stamp(1);
       stage(g + NST - 1);
-      if (j == 0 && valid) W::init_o(X, tile * 32, lane, O);
       stamp(2);
       if (valid) W::step(wl + (g % NST) * SB, fy, ones, O);
       stamp(3);
       if constexpr (PROF) nstep += valid;
     }
     if (tile + NW < t_hi) W::load_y(Y, (tile + NW) * 32, lane, fy);
-    if (valid) W::store_o(X, aux, tile * 32, M, lane, O);
+    if (valid) {
+      const float* bbv = aux;
+      asm volatile("" : "+s"(bbv));  // re-read per tile: hoisted out of the tile loop the 12 bias registers would live through every step
+      W::store_o(X, bbv, tile * 32, M, lane, O);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring was filled NST - 1 entries past the end
   if constexpr (PROF) {
