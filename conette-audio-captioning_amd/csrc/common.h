@@ -12,6 +12,26 @@ typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// ---- LDS-DMA (global -> LDS, 16 bytes per lane, 1 KB per wave instruction) through inline asm ------------------------
+// Not __builtin_amdgcn_global_load_lds: while a builtin piece is pending, the compiler's wait-count pass treats every later
+// LDS read as possibly out of order and emits `s_waitcnt lgkmcnt(0)` -- a full drain, the read issued one instruction
+// earlier included -- wherever a counted wait was meant (seen in every MFMA loop that reads fragments while a ring is
+// being filled).  The compiler does not count these pieces in vmcnt: every kernel that uses them waits for its pieces
+// with hand-written `s_waitcnt vmcnt(n)`, and a compiler-generated wait that does not know about pieces in flight only
+// waits for more than it needs (the counter retires in order), never for less.
+__device__ __forceinline__ unsigned cn_lds_addr(const void* p) {  // LDS byte address of a pointer into __shared__ memory
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+// lane-private 64-bit source address; lds = wave-uniform LDS byte address of the 1 KB piece
+__device__ __forceinline__ void cn_dma16_v(const void* src_lane, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds) : "memory", "m0");
+}
+// wave-uniform source base + 32-bit lane offset
+__device__ __forceinline__ void cn_dma16_s(const void* src_base, unsigned voff, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src_base), "s"(lds) : "memory", "m0");
+}
+
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #define CN_OK 0

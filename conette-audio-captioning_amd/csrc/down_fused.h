@@ -205,8 +205,7 @@ template <int CP, int NW, int KSTEP, int NST> struct DownRing {
 #pragma unroll
     for (int i = 0; i < DPW; ++i) {
       const int piece = wave + i * NW;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
-                                       (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+      cn_dma16_v(src + piece * 1024, cn_lds_addr(dst + piece * 1024));
     }
   }
   static constexpr int HS = NSTEP / 2;  // steps per half tile (input positions 0, 1 | 2, 3)

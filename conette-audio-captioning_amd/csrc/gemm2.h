@@ -227,14 +227,13 @@ __global__ __launch_bounds__(256) void cn_gemm2_kernel(const bf16_t* __restrict_
       src[i] = (const char*)A;
     }
   }
+  const unsigned lds0 = cn_lds_addr(smem);
   auto stage = [&](int buf, int kt) {
 #pragma unroll
     for (int i = 0; i < DPW; ++i) {
       const int inst = wave * DPW + i;
       if (N_DMA % 4 == 0 || inst < N_DMA)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)kt * RBY),
-                                         (__attribute__((address_space(3))) void*)(smem + buf * BUF + inst * 1024), 16, 0,
-                                         0);
+        cn_dma16_v(src[i] + (size_t)kt * RBY, lds0 + (unsigned)(buf * BUF + inst * 1024));
     }
   };
 

@@ -102,17 +102,9 @@ static __global__ void pk_mlp_rc2(const float* __restrict__ W1, const float* __r
 #define CN_SG_MFMA 0x008
 #define CN_SG_DSR 0x100
 
-// One 1 KB piece of a ring entry, global -> LDS (wave-uniform base addresses, lane * 16 as the only vector operand).
-// Inline asm, not __builtin_amdgcn_global_load_lds: with the builtin pending, the compiler's wait-count pass treats every
-// later LDS read as possibly out of order and emits `s_waitcnt lgkmcnt(0)` in front of every fifth MFMA of the step loop
-// where lgkmcnt(3) was meant.  The compiler does not count these pieces in vmcnt; the ring's own waits are written by hand
-// below, and a compiler wait that does not know about pieces in flight only waits for more than it needs (the counter
-// retires in order), never for less.
-// (Lab: issuing piece q inside the step, behind MFMA q by wave q % NW, moved the ~70 cycles a piece costs its wave from
-// the top of the step into the step, MFMAs or not: 201 us against 189.  profiles/r02_notes.md)
-__device__ __forceinline__ void cn_rc2_dma_piece(const char* src, unsigned lds, unsigned voff) {
-  asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(src), "s"(lds) : "memory", "m0");
-}
+// Ring pieces go through cn_dma16_s (common.h: inline-asm LDS-DMA; the builtin cost a full lgkmcnt drain at every fifth
+// MFMA of the step loop).  (Lab: issuing piece q INSIDE the step, behind MFMA q by wave q % NW, only moved the ~70 cycles
+// a piece costs its wave from the top of the step into the step, MFMAs or not: 201 us against 189.  profiles/r02_notes.md)
 
 template <int C, int NCK> struct Rc2Wave {
   typedef Rc2Geom<C, NCK> G;
@@ -336,14 +328,14 @@ __global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_ring_kernel(const bf16_t* 
   const int max_it = (t_hi - t_lo + NW - 1) / NW;  // block-uniform: every wave runs the same number of steps
 
   const unsigned voff = lane * 16;
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned lds0 = cn_lds_addr(smem);
   auto stage = [&](int g) {  // stream step g % NSTEP -> slot g % NST (this wave's pieces)
     const char* src = (const char*)WS + (size_t)(g % G::NSTEP) * SB;  // wave-uniform
     const unsigned dst = lds0 + (unsigned)((g % NST) * SB);
 #pragma unroll
     for (int i = 0; i < DPW_LO + 1; ++i) {
       const int piece = wave + i * NW;
-      if (i < DPW_LO || wave < N_HI) cn_rc2_dma_piece(src + piece * 1024, dst + piece * 1024, voff);
+      if (i < DPW_LO || wave < N_HI) cn_dma16_s(src + piece * 1024, voff, dst + piece * 1024);
     }
   };
   bf16x8 ones;
