@@ -59,11 +59,12 @@ template <int BK> struct G2Geom {
 };
 
 // all MFMAs of one staged k-tile: acc[a][b] += W-tile(a) . A-tile(b)^T
-template <int BM, int BN, int BK>
+// (WM x WN waves per block, each owning a (BM / WM) x (BN / WN) sub-tile: 2 x 2 everywhere but the 256 x 256 tiles, 2 x 4)
+template <int BM, int BN, int BK, int WM = 2, int WN = 2>
 __device__ __forceinline__ void cn_g2_compute(const char* sA, const char* sW, int lane, int wm, int wn,
-                                              f32x4 (&acc)[BN / 32][BM / 32]) {
+                                              f32x4 (&acc)[BN / (16 * WN)][BM / (16 * WM)]) {
   typedef G2Geom<BK> G;
-  constexpr int TM = BM / 32, TN = BN / 32, KS = BK / 32;
+  constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN), KS = BK / 32;
   const int lr = lane & 15;
   const int sw = (lr / G::RPB) & G::SWM;
   const int row_off = lr * G::RBY;
@@ -72,9 +73,9 @@ __device__ __forceinline__ void cn_g2_compute(const char* sA, const char* sW, in
     const int coff = (((lane >> 4) + 4 * ks) ^ sw) * 16;
     bf16x8 fw[TN], fa[TM];
 #pragma unroll
-    for (int a = 0; a < TN; ++a) fw[a] = *(const bf16x8*)(sW + (wn * (BN / 2) + a * 16) * G::RBY + row_off + coff);
+    for (int a = 0; a < TN; ++a) fw[a] = *(const bf16x8*)(sW + (wn * (BN / WN) + a * 16) * G::RBY + row_off + coff);
 #pragma unroll
-    for (int b = 0; b < TM; ++b) fa[b] = *(const bf16x8*)(sA + (wm * (BM / 2) + b * 16) * G::RBY + row_off + coff);
+    for (int b = 0; b < TM; ++b) fa[b] = *(const bf16x8*)(sA + (wm * (BM / WM) + b * 16) * G::RBY + row_off + coff);
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -102,14 +103,14 @@ __device__ unsigned long long g_g2_prof[16];
 // bf16 outputs go registers -> LDS tile [BM][BN] -> whole-row 16-byte chunks: direct stores would be
 // 8 bytes per lane scattered over 16 rows = up to 2.2x write amplification at HBM (rocprof
 // WRITE_SIZE).  Must be entered after a barrier (the LDS pipeline buffers are reused).
-template <int BM, int BN, class Epi>
-__device__ __forceinline__ void cn_g2_epilogue(char* smem, f32x4 (&acc)[BN / 32][BM / 32], int m0, int n0, int M, int N,
+template <int BM, int BN, class Epi, int WM = 2, int WN = 2>
+__device__ __forceinline__ void cn_g2_epilogue(char* smem, f32x4 (&acc)[BN / (16 * WN)][BM / (16 * WM)], int m0, int n0, int M, int N,
                                                const Epi& epi, int ks, int tid, int wm, int wn
 #ifdef CN_G2_PROF
                                                , int dbg, unsigned long long& t_prev, unsigned long long (&t_acc)[8]
 #endif
 ) {
-  constexpr int TM = BM / 32, TN = BN / 32;
+  constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN), NT = WM * WN * 64;
   const int lane = tid & 63;
   typedef typename Epi::stage_t ST;
   if constexpr (sizeof(ST) == 4) {
@@ -118,8 +119,8 @@ __device__ __forceinline__ void cn_g2_epilogue(char* smem, f32x4 (&acc)[BN / 32]
       // tile `a` all TM residual loads in flight before the first store, the next tile's loads issued before this
       // tile's stores
       if (epi.fast(N) && m0 + BM <= M && n0 + BN <= N) {
-        const int mb = m0 + wm * (BM / 2) + (lane & 15);
-        const int nb = n0 + wn * (BN / 2) + 4 * (lane >> 4);
+        const int mb = m0 + wm * (BM / WM) + (lane & 15);
+        const int nb = n0 + wn * (BN / WN) + 4 * (lane >> 4);
         // (register budget: the 128 x 128 tiles must stay at 148 registers so that a decode block can start next to
         // one resident GEMM workgroup, dec_block.h; sched_barrier keeps hipcc from hoisting every accumulator read
         // and column load to the top of the epilogue)
@@ -150,8 +151,8 @@ __device__ __forceinline__ void cn_g2_epilogue(char* smem, f32x4 (&acc)[BN / 32]
     for (int a = 0; a < TN; ++a)
 #pragma unroll
       for (int b = 0; b < TM; ++b) {
-        const int m = m0 + wm * (BM / 2) + b * 16 + (lane & 15);
-        const int n = n0 + wn * (BN / 2) + a * 16 + 4 * (lane >> 4);
+        const int m = m0 + wm * (BM / WM) + b * 16 + (lane & 15);
+        const int n = n0 + wn * (BN / WN) + a * 16 + 4 * (lane >> 4);
         if (m < M && n < N) epi(m, n, acc[a][b], N, ks);
       }
   } else {
@@ -163,15 +164,15 @@ __device__ __forceinline__ void cn_g2_epilogue(char* smem, f32x4 (&acc)[BN / 32]
     for (int a = 0; a < TN; ++a)
 #pragma unroll
       for (int b = 0; b < TM; ++b) {
-        const int ml = wm * (BM / 2) + b * 16 + (lane & 15);
-        const int nl = wn * (BN / 2) + a * 16 + 4 * (lane >> 4);
+        const int ml = wm * (BM / WM) + b * 16 + (lane & 15);
+        const int nl = wn * (BN / WN) + a * 16 + 4 * (lane >> 4);
         const f32x4 v = epi.pre4(n0 + nl, acc[a][b], N);
         cn_store4(tile + ml * PITCH + nl, v[0], v[1], v[2], v[3]);
       }
     G2_STAMP(5)
     __syncthreads();
     G2_STAMP(6)
-    for (int idx = tid; idx < BM * CH; idx += 256) {
+    for (int idx = tid; idx < BM * CH; idx += NT) {
       const int r = idx / CH, c = idx % CH;
       const int m = m0 + r, n = n0 + c * EPC;
       if (m < M && n < N) epi.commit(m, n, tile + r * PITCH + c * EPC, N, ks);
@@ -179,8 +180,8 @@ __device__ __forceinline__ void cn_g2_epilogue(char* smem, f32x4 (&acc)[BN / 32]
   }
 }
 
-template <int BM, int BN, int BK, int NST, class Epi>
-__global__ __launch_bounds__(256) void cn_gemm2_kernel(const bf16_t* __restrict__ A, int lda,
+template <int BM, int BN, int BK, int NST, class Epi, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(WM * WN * 64) void cn_gemm2_kernel(const bf16_t* __restrict__ A, int lda,
                                                        const bf16_t* __restrict__ W, int ldw, int M, int N, int K,
                                                        int k_slice, Epi epi, int dbg) {
 #ifdef CN_G2_PROF
@@ -192,8 +193,9 @@ __global__ __launch_bounds__(256) void cn_gemm2_kernel(const bf16_t* __restrict_
   constexpr int A_BYTES = BM * RBY, W_BYTES = BN * RBY, BUF = A_BYTES + W_BYTES;
   constexpr int N_DMA = BUF / 1024;
   static_assert(BUF % 1024 == 0 && A_BYTES % 1024 == 0, "tile must be a whole number of 1 KiB DMA pieces");
-  constexpr int DPW = (N_DMA + 3) / 4;  // DMA instructions per wave and stage
-  constexpr int TM = BM / 32, TN = BN / 32;
+  constexpr int NWV = WM * WN;
+  constexpr int DPW = (N_DMA + NWV - 1) / NWV;  // DMA instructions per wave and stage
+  constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN);
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int n_tiles = (N + BN - 1) / BN;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256) void cn_gemm2_kernel(const bf16_t* __restrict_
   const int n0 = (bid % n_tiles) * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int k_begin = blockIdx.y * k_slice;
   const int k_end = min(K, k_begin + k_slice);
   const int KT = (k_end - k_begin) / BK;
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256) void cn_gemm2_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int i = 0; i < DPW; ++i) {
       const int inst = wave * DPW + i;
-      if (N_DMA % 4 == 0 || inst < N_DMA)
+      if (N_DMA % NWV == 0 || inst < N_DMA)
         cn_dma16_v(src[i] + (size_t)kt * RBY, lds0 + (unsigned)(buf * BUF + inst * 1024));
     }
   };
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256) void cn_gemm2_kernel(const bf16_t* __restrict_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
-      cn_g2_compute<BM, BN, BK>(smem, smem + A_BYTES, lane, wm, wn, acc);
+      cn_g2_compute<BM, BN, BK, WM, WN>(smem, smem + A_BYTES, lane, wm, wn, acc);
       if (kt + 1 < KT) {
         __syncthreads();
         stage(0, kt + 1);
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void cn_gemm2_kernel(const bf16_t* __restrict_
 #ifdef CN_G2_PROF
       if (!(dbg & 4))
 #endif
-      cn_g2_compute<BM, BN, BK>(sA, sA + A_BYTES, lane, wm, wn, acc);
+      cn_g2_compute<BM, BN, BK, WM, WN>(sA, sA + A_BYTES, lane, wm, wn, acc);
       G2_STAMP(3)
     }
     __syncthreads();  // all fragment reads done before the epilogue reuses the LDS
@@ -287,9 +289,9 @@ __global__ __launch_bounds__(256) void cn_gemm2_kernel(const bf16_t* __restrict_
   G2_STAMP(4)
 #ifdef CN_G2_PROF
   if (!(dbg & 2) || acc[0][0][0] == 12345.678f)  // experiment: skip the epilogue (wrong results)
-    cn_g2_epilogue<BM, BN, Epi>(smem, acc, m0, n0, M, N, epi, (int)blockIdx.y, tid, wm, wn, dbg & 1, t_prev, t_acc);
+    cn_g2_epilogue<BM, BN, Epi, WM, WN>(smem, acc, m0, n0, M, N, epi, (int)blockIdx.y, tid, wm, wn, dbg & 1, t_prev, t_acc);
 #else
-  cn_g2_epilogue<BM, BN, Epi>(smem, acc, m0, n0, M, N, epi, (int)blockIdx.y, tid, wm, wn);
+  cn_g2_epilogue<BM, BN, Epi, WM, WN>(smem, acc, m0, n0, M, N, epi, (int)blockIdx.y, tid, wm, wn);
 #endif
   G2_STAMP(7)
 #ifdef CN_G2_PROF
@@ -322,16 +324,16 @@ static inline int g2_debug_skip() { return 0; }
 static inline int g2_debug_epi() { return 0; }
 #endif
 
-template <int BM, int BN, int BK, int NST, class Epi>
+template <int BM, int BN, int BK, int NST, class Epi, int WM = 2, int WN = 2>
 static int cn_launch_gemm2_t(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, int splits,
                              const Epi& epi, hipStream_t stream) {
   constexpr int EPI_BYTES = sizeof(typename Epi::stage_t) == 4 ? 0 : BM * (BN * 2 + 16);
   constexpr int PIPE_BYTES = NST * (BM + BN) * BK * 2;
   constexpr int SMEM = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
-  CN_TRY(cn_configure_lds((const void*)cn_gemm2_kernel<BM, BN, BK, NST, Epi>, SMEM));
+  CN_TRY(cn_configure_lds((const void*)cn_gemm2_kernel<BM, BN, BK, NST, Epi, WM, WN>, SMEM));
   const long blocks = (long)cn_cdiv(M, BM) * cn_cdiv(N, BN);
   const int k_slice = K / splits;
-  hipLaunchKernelGGL((cn_gemm2_kernel<BM, BN, BK, NST, Epi>), dim3((unsigned)blocks, (unsigned)splits), dim3(256), SMEM,
+  hipLaunchKernelGGL((cn_gemm2_kernel<BM, BN, BK, NST, Epi, WM, WN>), dim3((unsigned)blocks, (unsigned)splits), dim3(WM * WN * 64), SMEM,
                      stream, A, lda, W, ldw, M, N, K, k_slice, epi, (g2_debug_level() == BM + BN && (g2_debug_epi() == 0 || g2_debug_epi() == (int)sizeof(typename Epi::stage_t)) ? 1 : 0) | g2_debug_skip());
   CN_LAUNCH_CHECK();
   return CN_OK;
@@ -350,6 +352,12 @@ static int cn_gemm2(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, i
     const bool n96 = (N % 96 == 0) && (N % 128 != 0);
     if (!k64) return cn_launch_gemm2_t<128, 128, 32, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
     if (n96) return cn_launch_gemm2_t<128, 96, 64, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+#ifndef CN_G2_NO256
+    // 256 x 256 tiles, 8 waves (2 x 4), one block per CU: a 128 x 128 tile asks the CU's load path for 512 bytes per MFMA
+    // -- all of the ~64 B/clk it delivers when four SIMDs run MFMAs back to back -- this one for 256
+    if (N % 256 == 0 && M >= 8192 && splits == 1)
+      return cn_launch_gemm2_t<256, 256, 64, 2, Epi, 2, 4>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+#endif
     return cn_launch_gemm2_t<128, 128, 64, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
   }
   if (!k64) return cn_launch_gemm2_t<64, 64, 32, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
