@@ -339,6 +339,17 @@ static int cn_launch_gemm2_t(const bf16_t* A, int lda, const bf16_t* W, int ldw,
   return CN_OK;
 }
 
+static inline int cn_g2_cus() {  // compute units of the current device (cached)
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
 // bf16 dispatch.  splits > 1 only with a slab epilogue; K / splits must be a multiple of 64.
 template <class Epi>
 static int cn_gemm2(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const Epi& epi,
@@ -355,8 +366,17 @@ static int cn_gemm2(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, i
 #ifndef CN_G2_NO256
     // 256 x 256 tiles, 8 waves (2 x 4), one block per CU: a 128 x 128 tile asks the CU's load path for 512 bytes per MFMA
     // -- all of the ~64 B/clk it delivers when four SIMDs run MFMAs back to back -- this one for 256
-    if (N % 256 == 0 && M >= 8192 && splits == 1)
+    // A launch of several rounds over the chip takes 224-row tiles when that saves row-rounds (M = 13 888, N = 3072: 3 rounds
+    // of 744 tiles of 224 rows instead of 3 of 660 of 256: 103 -> 96 us).  One-round launches keep 256 rows: they are bound by
+    // the operand traffic, and more, smaller tiles re-read W more often (N = 768: 96 us with 165 tiles of 256 rows, 108 with
+    // 186 of 224, 101 with 219 of 192).
+    if (N % 256 == 0 && M >= 8192 && splits == 1) {
+      const long ncu = cn_g2_cus(), nt = N / 256;
+      const long r256 = cn_cdiv(cn_cdiv(M, 256) * (int)nt, (int)ncu), r224 = cn_cdiv(cn_cdiv(M, 224) * (int)nt, (int)ncu);
+      if (r256 > 1 && r224 * 224 < r256 * 256)
+        return cn_launch_gemm2_t<224, 256, 64, 2, Epi, 2, 4>(A, lda, W, ldw, M, N, K, splits, epi, stream);
       return cn_launch_gemm2_t<256, 256, 64, 2, Epi, 2, 4>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+    }
 #endif
     return cn_launch_gemm2_t<128, 128, 64, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
   }
