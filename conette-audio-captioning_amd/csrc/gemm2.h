@@ -367,12 +367,17 @@ static int cn_gemm2(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, i
     // 256 x 256 tiles, 8 waves (2 x 4), one block per CU: a 128 x 128 tile asks the CU's load path for 512 bytes per MFMA
     // -- all of the ~64 B/clk it delivers when four SIMDs run MFMAs back to back -- this one for 256
     // A launch of several rounds over the chip takes 224-row tiles when that saves row-rounds (M = 13 888, N = 3072: 3 rounds
-    // of 744 tiles of 224 rows instead of 3 of 660 of 256: 103 -> 96 us).  One-round launches keep 256 rows: they are bound by
-    // the operand traffic, and more, smaller tiles re-read W more often (N = 768: 96 us with 165 tiles of 256 rows, 108 with
-    // 186 of 224, 101 with 219 of 192).
+    // of 744 tiles of 224 rows instead of 3 of 660 of 256: 103 -> 96 us).  A launch that fits in ONE round (N = 768: the
+    // stage-3 pw2 and downsample products, K = 3072 / 1536) is bound by waiting for the next k-tile -- two 64 KB stages do not
+    // cover the load latency -- and takes 224 x 192 tiles with a THREE-deep ring (156 KB, 248 of 256 compute units busy):
+    // 96 -> 80 us and 61 -> 48 us (same-box traces; with two stages 186 tiles of 224 x 256 took 108 us, 219 of 192 x 256
+    // 101).  The N = 3072 product has 12 k-tiles per tile and a heavy epilogue: there the wider two-stage tile wins (96 us
+    // against 102).
     if (N % 256 == 0 && M >= 8192 && splits == 1) {
       const long ncu = cn_g2_cus(), nt = N / 256;
       const long r256 = cn_cdiv(cn_cdiv(M, 256) * (int)nt, (int)ncu), r224 = cn_cdiv(cn_cdiv(M, 224) * (int)nt, (int)ncu);
+      if (r256 == 1 && N % 192 == 0 && cn_cdiv(M, 224) * (N / 192) <= ncu)
+        return cn_launch_gemm2_t<224, 192, 64, 3, Epi, 2, 4>(A, lda, W, ldw, M, N, K, splits, epi, stream);
       if (r256 > 1 && r224 * 224 < r256 * 256)
         return cn_launch_gemm2_t<224, 256, 64, 2, Epi, 2, 4>(A, lda, W, ldw, M, N, K, splits, epi, stream);
       return cn_launch_gemm2_t<256, 256, 64, 2, Epi, 2, 4>(A, lda, W, ldw, M, N, K, splits, epi, stream);
