@@ -190,3 +190,11 @@ __device__ __forceinline__ void cn_store4(float* p, float a, float b, float c, f
 __device__ __forceinline__ void cn_store4(bf16_t* p, float a, float b, float c, float d) {
   *(bf16x4*)p = bf16x4{(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
 }
+// store 8 consecutive values as T; p must be 8-element aligned (bf16: ONE 16-byte store)
+__device__ __forceinline__ void cn_store8(float* p, const float (&o)[8]) {
+  *(f32x4*)p = f32x4{o[0], o[1], o[2], o[3]};
+  *(f32x4*)(p + 4) = f32x4{o[4], o[5], o[6], o[7]};
+}
+__device__ __forceinline__ void cn_store8(bf16_t* p, const float (&o)[8]) {
+  *(bf16x8*)p = bf16x8{(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3], (bf16_t)o[4], (bf16_t)o[5], (bf16_t)o[6], (bf16_t)o[7]};
+}

@@ -282,8 +282,12 @@ __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(c
   // Phase B: normalise + store, 8 consecutive channels per item (one 16-byte bf16 store; 2-byte
   // stores per lane made this phase as long as the convolution itself -- store-issue bound)
   constexpr int C8 = C / 8;
+  static_assert(NT % C8 == 0, "a thread keeps its 8 channels over all its items: the LN affine is loaded once");
+  const int c8 = (tid % C8) * 8;
+  const f32x4 lw0 = *(const f32x4*)(ln_w + c8), lw1 = *(const f32x4*)(ln_w + c8 + 4);
+  const f32x4 lb0 = *(const f32x4*)(ln_b + c8), lb1 = *(const f32x4*)(ln_b + c8 + 4);
   for (int item = tid; item < NPOS * C8; item += NT) {
-    const int pos = item / C8, c8 = (item % C8) * 8;
+    const int pos = item / C8;
     const int ps = pos / NP, oh = (pos % NP) >> 2, ow = pos & 3;
     const int h = h0 + oh, w = tw * (4 * S) + ps * 4 + ow;
     if (h >= H || w >= W) continue;
@@ -292,9 +296,8 @@ __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(c
     T* dst = y + (((size_t)b * H + h) * W + w) * C + c8;
     float o[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = ((i < 4 ? v0[i] : v1[i - 4]) - mean) * rstd * ln_w[c8 + i] + ln_b[c8 + i];
-    cn_store4(dst, o[0], o[1], o[2], o[3]);
-    cn_store4(dst + 4, o[4], o[5], o[6], o[7]);
+    for (int i = 0; i < 8; ++i) o[i] = ((i < 4 ? v0[i] : v1[i - 4]) - mean) * rstd * (i < 4 ? lw0[i] : lw1[i - 4]) + (i < 4 ? lb0[i] : lb1[i - 4]);
+    cn_store8(dst, o);
   }
   DW_STAMP(4)
 }
@@ -463,8 +466,12 @@ __global__ __launch_bounds__(C* SPLIT > 384 ? 768 : 384) void cn_dwconv_ln_fw_ke
   }
   __syncthreads();
   constexpr int C8 = C / 8;
+  static_assert(CT % C8 == 0, "a thread keeps its 8 channels over all its items: the LN affine is loaded once");
+  const int c8 = (tid % C8) * 8;
+  const f32x4 lw0 = *(const f32x4*)(ln_w + c8), lw1 = *(const f32x4*)(ln_w + c8 + 4);
+  const f32x4 lb0 = *(const f32x4*)(ln_b + c8), lb1 = *(const f32x4*)(ln_b + c8 + 4);
   for (int item = tid; item < NPOS * C8; item += CT) {
-    const int pos = item / C8, c8 = (item % C8) * 8;
+    const int pos = item / C8;
     const int h = h0 + pos / WW, w = pos % WW;
     if (h >= H) continue;
     const float mean = s_mean[pos], rstd = s_rstd[pos];
@@ -472,9 +479,8 @@ __global__ __launch_bounds__(C* SPLIT > 384 ? 768 : 384) void cn_dwconv_ln_fw_ke
     T* dst = y + (((size_t)b * H + h) * WW + w) * C + c8;
     float o[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = ((i < 4 ? v0[i] : v1[i - 4]) - mean) * rstd * ln_w[c8 + i] + ln_b[c8 + i];
-    cn_store4(dst, o[0], o[1], o[2], o[3]);
-    cn_store4(dst + 4, o[4], o[5], o[6], o[7]);
+    for (int i = 0; i < 8; ++i) o[i] = ((i < 4 ? v0[i] : v1[i - 4]) - mean) * rstd * (i < 4 ? lw0[i] : lw1[i - 4]) + (i < 4 ? lb0[i] : lb1[i - 4]);
+    cn_store8(dst, o);
   }
 }
 
