@@ -82,10 +82,13 @@ __global__ __launch_bounds__(FE_NW * 64) void cn_logmel_kernel(const float* __re
   // mel bands of this lane's four bins; the trip count of a group of 64 bins is its widest band (rows past a bin's own band
   // hold zeros in melC, and acc + p * 0 = acc, so the sum is still the dense row's sum in the dense row's order)
   int m_lo[4], m_trip[4];
+  float m_sc[4], m_sh[4];  // bn0 affine of this lane's bins (loaded once, not per frame)
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int m = lane + 64 * g;
     const bool on = m < CN_N_MELS;
+    m_sc[g] = on ? bn_scale[m] : 0.f;
+    m_sh[g] = on ? bn_shift[m] : 0.f;
     m_lo[g] = on ? band[2 * m] : 0;
     int nb = on ? band[2 * m + 1] - m_lo[g] : 0;
 #pragma unroll
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(FE_NW * 64) void cn_logmel_kernel(const float* __re
           }
           for (; i < trip; ++i) acc = fmaf(sp[min(lo + i, CN_N_BINS - 1)], mc[i * CN_N_MELS + m], acc);
           const float db = 10.0f * log10f(fmaxf(acc, 1e-10f));
-          out[(size_t)fr * CN_N_MELS + m] = db * bn_scale[m] + bn_shift[m];
+          out[(size_t)fr * CN_N_MELS + m] = db * m_sc[g] + m_sh[g];
         }
       }
     }
