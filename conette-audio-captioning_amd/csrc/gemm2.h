@@ -271,9 +271,19 @@ __global__ __launch_bounds__(WM * WN * 64) void cn_gemm2_kernel(const bf16_t* __
     G2_STAMP(0)
     for (int kt = 0; kt < KT; ++kt) {
       const int newer = KT - 1 - kt;  // stages issued after tile kt that may stay in flight
-      if (NST >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW) : "memory");
-      else if (NST >= 3 && newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // (pieces are dealt DPW per wave in order, so only the LAST wave can own fewer: its count decides its wait -- with
+      // vmcnt(DPW) it would let one of tile kt's own pieces stay in flight and read the tile before it has landed)
+      constexpr int LASTW = N_DMA - (NWV - 1) * DPW;  // pieces per stage of the last wave
+      static_assert(LASTW > 0 && LASTW <= DPW, "pieces are dealt to every wave");
+      if (LASTW != DPW && wave == NWV - 1) {
+        if (NST >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LASTW) : "memory");
+        else if (NST >= 3 && newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LASTW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        if (NST >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPW) : "memory");
+        else if (NST >= 3 && newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       __builtin_amdgcn_s_barrier();
       if (kt == 0) { G2_STAMP(1) } else { G2_STAMP(2) }
       if (kt + NST - 1 < KT) stage((kt + NST - 1) % NST, kt + NST - 1);
