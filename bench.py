@@ -316,6 +316,10 @@ def main() -> None:
             preds = res[0][0] if len(res) == 1 else torch.cat([r[0] for r in res])
             lps = res[0][1] if len(res) == 1 else torch.cat([r[1] for r in res])
             state["last_local"] = (preds, lps)  # this rank's captions of the step (before the all-gather)
+            if state.get("keep") is not None and i < state["keep"][0].shape[0]:  # batch 0's result of every timed step, compared after the run
+                kp, kl = state["keep"]
+                kp[i].copy_(preds[: kp.shape[1], : kp.shape[2]], non_blocking=True)
+                kl[i].copy_(lps[: kl.shape[1]], non_blocking=True)
             if world > 1:
                 preds, lps = gather_captions(preds, lps, total_clips)
         state["i"] = i + 1
@@ -360,6 +364,9 @@ def main() -> None:
     # ---- timed region: exactly K steps, events only around the dominant class --------------------------
     eng.profile_enable((dominant,))
     state["i"] = 0
+    n_keep = args.steps if os.environ.get("CN_BENCH_CHECK_ALL", "1") != "0" else 0  # (0: only the last step is compared)
+    state["keep"] = (torch.zeros((n_keep,) + tuple(solo_preds.shape), dtype=solo_preds.dtype, device=dev),
+                     torch.zeros((n_keep,) + tuple(solo_lps.shape), dtype=solo_lps.dtype, device=dev))
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -368,12 +375,16 @@ def main() -> None:
     dt = time.perf_counter() - t0
     # the pipelined steps (encode of batch i next to the decodes of batches i-1, i-2) must reproduce the solo pass bit for bit
     lp_, ll_ = state["last_local"][0][:B0], state["last_local"][1][:B0]
-    pipeline_consistent = bool(torch.equal(lp_[:, : solo_preds.shape[1]], solo_preds[: lp_.shape[0], : lp_.shape[1]]) and
+    kp, kl = state["keep"]
+    state["keep"] = None
+    wp = min(kp.shape[2], lp_.shape[1])  # timed steps whose captions / scores of batch 0 differ from the solo pass
+    bad_steps = int(((kp[:, :, :wp] != solo_preds[None, :, :wp]).flatten(1).any(dim=1) | (kl != solo_lps[None]).flatten(1).any(dim=1)).sum().item())
+    pipeline_consistent = bool(bad_steps == 0 and torch.equal(lp_[:, : solo_preds.shape[1]], solo_preds[: lp_.shape[0], : lp_.shape[1]]) and
                                torch.equal(ll_, solo_lps[: ll_.shape[0]]))
     if not pipeline_consistent:
         a_, b_ = lp_[:, : solo_preds.shape[1]], solo_preds[: lp_.shape[0], : lp_.shape[1]]
         rows = (a_ != b_).any(dim=1).nonzero().flatten().tolist()
-        print(f"[bench] rank {rank}: the pipelined steps returned other captions than the un-pipelined pass of the same batch: rows",
+        print(f"[bench] rank {rank}: {bad_steps} of {args.steps} pipelined steps returned other captions / scores than the un-pipelined pass of the same batch; last step: rows",
               rows[:16], "of", a_.shape[0], "| score diffs:", int((ll_ != solo_lps[: ll_.shape[0]]).sum()), file=sys.stderr, flush=True)
     if world > 1:  # every rank must agree before a number is printed
         flag = torch.tensor([1 if pipeline_consistent else 0], dtype=torch.int32, device=dev)
@@ -431,7 +442,7 @@ def main() -> None:
                   f"(min 3 / max 20 tokens, V=5631), synthetic seeded checkpoint")
         result = {
             "metric": "clips_per_sec", "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "warmup_run": warm_used, "ms_per_step": round(dt / args.steps * 1e3, 3), "pipeline_consistent": pipeline_consistent,
+            "steps": args.steps, "warmup": args.warmup, "warmup_run": warm_used, "ms_per_step": round(dt / args.steps * 1e3, 3), "pipeline_consistent": pipeline_consistent, "pipeline_steps_checked": n_keep if n_keep else 1,
             "timed_region_s": round(dt, 4),
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
