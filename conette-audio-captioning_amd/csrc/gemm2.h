@@ -13,7 +13,13 @@
 //  * the DMA of k-tile t+1 is issued before the fragments of tile t are read, one
 //    vmcnt(0) + barrier per k-tile;
 //  * optional split-K over blockIdx.y: the epilogue receives the slice index (partial slabs,
-//    summed in a fixed order by the consumer -> deterministic, no atomics).
+//    summed in a fixed order by the consumer -> deterministic, no atomics);
+//  * tile shapes (cn_gemm2 below): 64 x 64 (decoder), 128 x 128 / 128 x 96 with 4 waves and two blocks per CU, and for the
+//    large N % 256 == 0 products of stage 3 one block of 8 waves (2 x 4) per CU: 224 / 256 x 256 two-deep, or 224 x 192
+//    with a three-deep ring when the whole product fits in one round over the chip.  A 128 x 128 tile asks the CU's load
+//    path for 512 bytes per 32x32x16-sized MFMA -- all it delivers at full MFMA rate -- the big tiles for 256-300;
+//  * the LDS-DMA pieces are issued through inline asm (common.h: cn_dma16_v) and are invisible to the compiler: every
+//    ring wait below is counted by hand, per wave (the last wave may own fewer pieces per stage than the others).
 #pragma once
 #include <stdlib.h>
 
