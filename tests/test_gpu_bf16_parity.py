@@ -73,27 +73,30 @@ def test_every_block_against_bf16_operand_oracle(name, eng_bf16, synth_weights):
     print("max / mean |err| per block:", {k: (round(a, 5), round(b, 7)) for k, (a, b) in worst.items()})
 
 
-def test_encoder_at_256_clips(eng_bf16):
+@pytest.mark.parametrize("copies", [32, 8])
+def test_encoder_at_256_clips(copies, eng_bf16):
     """BASELINE config 3's encoder half: 32 copies of the b8_10s fixture batch (B = 256) -- every copy must reproduce
     copy 0 bit for bit in every tap (persistent kernels walk many tiles per wave, tiles straddle clip boundaries at
-    stages 1-3), and copy 0 must match the reference fixture like the B = 8 run does."""
+    stages 1-3), and copy 0 must match the reference fixture like the B = 8 run does.  8 copies (B = 64) is the benchmark's
+    shape: its stage-3 products run in other GEMM tiles (224 x 256 and the three-deep 224 x 192 ring) than B = 256
+    (224 x 256 throughout) and B = 8 (64 x 64) -- all must agree bit for bit (same k order per output element)."""
     g = G.load("b8_10s_beam3_all")
     w8 = _wave(g)
-    wave = w8.repeat(32, 1).cuda()
+    wave = w8.repeat(copies, 1).cuda()
     fe, clip, taps = eng_bf16.encode(wave, taps=True)
     fe8, clip8, taps8 = eng_bf16.encode(w8.cuda(), taps=True)
     torch.cuda.synchronize()
     for k in ["stem", "stage0_block0", "stage0", "down1", "stage1_block0", "stage1", "down2", "stage2_block0", "stage2",
               "down3", "stage3_block0", "stage3"]:
         t = taps[k]
-        v = t.view(32, 8, *t.shape[1:])
+        v = t.view(copies, 8, *t.shape[1:])
         assert torch.equal(v, v[0:1].expand_as(v)), k
         assert torch.equal(v[0], taps8[k]), k
         if "sub_" + k in g.files:
             got = G.sub(taps8[k].permute(0, 3, 1, 2).contiguous())
             np.testing.assert_allclose(got, g["sub_" + k], rtol=0, atol=0.1, err_msg=k)
-    assert torch.equal(fe.view(32, 8, *fe.shape[1:]), fe8[None].expand(32, *fe8.shape))
-    assert torch.equal(clip.view(32, 8, -1), clip8[None].expand(32, *clip8.shape))
+    assert torch.equal(fe.view(copies, 8, *fe.shape[1:]), fe8[None].expand(copies, *fe8.shape))
+    assert torch.equal(clip.view(copies, 8, -1), clip8[None].expand(copies, *clip8.shape))
     np.testing.assert_allclose(fe8.cpu().numpy(), g["frame_embs"], atol=0.06)
 
 
