@@ -600,8 +600,20 @@ __global__ __launch_bounds__(256) void cn_clip_pool_ln_kernel(const float* __res
   for (int i = 0; i < 3; ++i) {
     const int c = tid + 256 * i;
     float mx = -INFINITY, sm = 0.f;
-    for (int t = 0; t < Tn; ++t) {
-      const float a = fe[((size_t)b * Tn + t) * CN_FEAT + c];
+    const float* col = fe + (size_t)b * Tn * CN_FEAT + c;
+    int t = 0;
+    for (; t + 8 <= Tn; t += 8) {  // eight loads in flight (one at a time this loop was a latency chain); same order of the sum
+      float a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = col[(size_t)(t + u) * CN_FEAT];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        mx = fmaxf(mx, a[u]);
+        sm += a[u];
+      }
+    }
+    for (; t < Tn; ++t) {
+      const float a = col[(size_t)t * CN_FEAT];
       mx = fmaxf(mx, a);
       sm += a;
     }
