@@ -12,6 +12,7 @@
 
 #include "mlp_rc2.h"
 #include "mlp_rc2_f8.h"
+#include "mlp_rc2_skew.h"
 
 void cn_set_error(const char* fmt, ...) {
   va_list ap;
@@ -125,6 +126,8 @@ template <> std::vector<Variant> variants<384>() {
   return {
       {"rc2_ring<384,4,nck1,nst3>",
        [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_ring<384, 4, 1, 3>(Y, WS, X, M, nb, s); }, 1},
+      {"rc2_skew<384,4,nst3>",
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_skew<384, 4, 3>(Y, WS, X, M, nb, s); }, 3},
   };
 }
 
@@ -149,7 +152,8 @@ template <int C> static int run(int batch, int iters) {
   bf16_t* Y = dalloc<bf16_t>(hY.size());
   float *X = dalloc<float>(hX.size() + 64 * C), *Xref = dalloc<float>((size_t)Mc * C), *Xref2 = dalloc<float>((size_t)Mc * C);
   bf16_t* H = dalloc<bf16_t>((size_t)Mc * 4 * C);
-  bf16_t* WS2[3] = {nullptr, dalloc<bf16_t>(Rc2Geom<C, 1>::TOTAL_BYTES / 2), dalloc<bf16_t>(Rc2Geom<C, 2>::TOTAL_BYTES / 2)};
+  bf16_t* WS2[4] = {nullptr, dalloc<bf16_t>(Rc2Geom<C, 1>::TOTAL_BYTES / 2), dalloc<bf16_t>(Rc2Geom<C, 2>::TOTAL_BYTES / 2),
+                    dalloc<bf16_t>(Rc2Geom<C, 1>::TOTAL_BYTES / 2)};  // [3]: NCK = 1, skewed entries
   CK(hipMemcpy(W1, hW1.data(), hW1.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(W2, hW2.data(), hW2.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(b1, hb1.data(), 4 * C * 4, hipMemcpyHostToDevice));
@@ -161,6 +165,8 @@ template <int C> static int run(int batch, int iters) {
       const int u2 = (C / 8) * (C / 8 + 1) * 64;
       hipLaunchKernelGGL(pk_mlp_rc2, dim3((u2 + 255) / 256), dim3(256), 0, 0, W1, b1, W2, b2, sc, C, nck, WS2[nck]);
     }
+    const int u3 = (C / 8) * (C / 8 + 1) * 64;
+    hipLaunchKernelGGL(pk_mlp_rc2_skew, dim3((u3 + 255) / 256), dim3(256), 0, 0, W1, b1, W2, b2, sc, C, 1, WS2[3], 1);
   }
   // reference on the first Mc rows
   CK(hipMemcpy(Xref, hX.data(), (size_t)Mc * C * 4, hipMemcpyHostToDevice));
