@@ -73,13 +73,14 @@ def test_every_block_against_bf16_operand_oracle(name, eng_bf16, synth_weights):
     print("max / mean |err| per block:", {k: (round(a, 5), round(b, 7)) for k, (a, b) in worst.items()})
 
 
-@pytest.mark.parametrize("copies", [32, 8])
+@pytest.mark.parametrize("copies", [32, 8, 5, 13])
 def test_encoder_at_256_clips(copies, eng_bf16):
     """BASELINE config 3's encoder half: 32 copies of the b8_10s fixture batch (B = 256) -- every copy must reproduce
     copy 0 bit for bit in every tap (persistent kernels walk many tiles per wave, tiles straddle clip boundaries at
     stages 1-3), and copy 0 must match the reference fixture like the B = 8 run does.  8 copies (B = 64) is the benchmark's
     shape: its stage-3 products run in other GEMM tiles (224 x 256 and the three-deep 224 x 192 ring) than B = 256
-    (224 x 256 throughout) and B = 8 (64 x 64) -- all must agree bit for bit (same k order per output element)."""
+    (224 x 256 throughout) and B = 8 (64 x 64) -- all must agree bit for bit (same k order per output element).  5 and 13
+    copies (B = 40, 104) put ragged last tiles and the other branches of the tile-height rule under the same check."""
     g = G.load("b8_10s_beam3_all")
     w8 = _wave(g)
     wave = w8.repeat(copies, 1).cuda()
