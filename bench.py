@@ -55,7 +55,10 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=0, help="total clips, sharded over the GPUs (strong scaling)")
     ap.add_argument("--beam", type=int, default=3)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "exact"])
+    ap.add_argument("--repeat", type=int, default=5,
+                    help="timed windows of --steps steps each (barrier + synchronize around every window); `value` and "
+                         "`ms_per_step` are the MEDIAN window's, every window's clips/s is listed under `windows`")
     ap.add_argument("--workload", default="fixed", choices=["fixed", "mixed"],
                     help="fixed: 10 s clips; mixed: lengths U[1 s, 30 s] (seed 1234), length-bucketed batches")
     ap.add_argument("--cpu-clips", type=int, default=32, help="clips in the CPU-baseline sample (0 = skip)")
@@ -199,6 +202,155 @@ def agreement(a, b, eos: int = 2):
     live = (pa != 0) | (pb != 0)
     same_tok = float(((pa == pb) & live).sum() / max(int(live.sum()), 1))
     return round(same_seq, 4), round(same_tok, 4)
+
+
+def decode_algorithmic_bytes(batch: int, beam: int, t_audio: int, n_steps: int, vocab: int, d: int = 256, n_layers: int = 6,
+                             d_ff: int = 2048, feat: int = 768):
+    """HBM bytes one beam search has to move if every operand is touched once per use (DESIGN.md section 4, bf16 operands):
+    preparation = frame_embs in, projection + cross K/V of all layers out; per step: every weight matrix once (the six
+    attention-side d x d matrices + the FFN pair per layer, the classifier), the clip's cross K/V per layer (shared by its
+    beams), the self-attention cache rows written so far, the (rows, vocab) fp32 logits written and read once."""
+    rows = batch * beam
+    w_layer = (6 * d * d + 2 * d * d_ff) * 2
+    w_step = n_layers * w_layer + vocab * d * 2
+    prep = batch * t_audio * feat * 4 + (feat * d + n_layers * 2 * d * d) * 2 + batch * t_audio * (d + n_layers * 2 * d) * 2
+    total = prep
+    for t in range(n_steps):
+        r = batch if t == 0 else rows                                  # step 0 runs one row per clip
+        total += w_step + n_layers * batch * t_audio * 2 * d * 2       # weights + cross K/V
+        total += n_layers * r * (t + 1) * 2 * d * 2                    # self K/V cache read (and one row appended)
+        total += 2 * r * vocab * 4                                     # logits out + in
+    return total
+
+
+def clip_min_margins(trace, n_clips: int):
+    """Smallest top-k margin (candidate k vs candidate k + 1) over all search steps of every clip, from the oracle's
+    per-call trace (oracle/cpu_ref.py generate(trace=...)): how close the clip's closest decision was."""
+    m = [float("inf")] * n_clips
+    for step in trace:
+        for call in step:
+            m[call["clip"]] = min(m[call["clip"]], call["margin"])
+    return m
+
+
+def _ids(out):
+    return out["best_preds"][:, : int(out["sizes"][1].item())].cpu()
+
+
+def compare_ids(got, got_lp, ref, ref_lp=None, margins=None):
+    """Agreement of (n, P) id matrices with the checker's: identical sequences, identical tokens, |score diff| over the
+    clips whose ids agree, and -- when the checker's decision margins are known -- the same over the clips whose closest
+    decision was wider than 0.05 / 0.25 (a precision can only be blamed for flips of decisions that were not ties)."""
+    import torch
+    n = min(got.shape[0], ref.shape[0])
+    got, ref = got[:n], ref[:n]
+    seq, tok = agreement(got, ref)
+    w = max(got.shape[1], ref.shape[1])
+    pa = torch.zeros((n, w), dtype=torch.long)
+    pb = torch.zeros((n, w), dtype=torch.long)
+    pa[:, : got.shape[1]] = got.long()
+    pb[:, : ref.shape[1]] = ref.long()
+    same = (pa == pb).all(dim=1)
+    r = {"clips": n, "seq_identical": seq, "token_agree": tok}
+    if ref_lp is not None and got_lp is not None:
+        d = (got_lp[:n].cpu().float() - ref_lp[:n].cpu().float()).abs()
+        r["max_abs_lprob_diff_same_ids"] = round(float(d[same].max()), 6) if bool(same.any()) else None
+        r["max_abs_lprob_diff"] = round(float(d.max()), 6)
+    if margins is not None:
+        mg = torch.tensor(margins[:n])
+        for thr in (0.05, 0.25):
+            sel = mg > thr
+            r[f"seq_identical_margin_gt_{thr}"] = [int((same & sel).sum()), int(sel.sum())]
+    return r
+
+
+def parity_report(args, Engine, eng, sd, dev, w0, lens0, bos0, forbid, t_audio, beam, min_pred, max_pred, ora, result):
+    """Ids / scores of every precision of the library against the CPU ORACLE on the clips of the cpu_baseline sample (the
+    checker is oracle/cpu_ref.py, run above on the same waveforms), plus -- on all --parity-clips clips -- against the
+    library's fp32 mode, with the encoder and the decoder switched to bf16 one at a time: frame_embs (B, T, 768) fp32 is
+    the interface between the two, so "bf16 encoder + fp32 decoder" is engine A's encode fed to engine B's decode."""
+    import torch
+    n = min(args.parity_clips, w0.shape[0])
+    wv, ln, bs = w0[:n].contiguous(), lens0[:n].contiguous(), bos0[:n].contiguous()
+    engines = {args.precision: eng}
+    for name in ("bf16", "exact", "fp32"):
+        if name not in engines:
+            try:
+                engines[name] = Engine(sd, precision=name, device=dev)
+            except (KeyError, RuntimeError, ValueError) as e:  # a precision this build does not have
+                print(f"[bench] parity: precision {name} unavailable ({e})", file=sys.stderr)
+    fe, outs = {}, {}
+    for name, e in engines.items():
+        fe[name], _ = e.encode(wv)
+        fe[name] = fe[name].clone()
+        for bm_ in (1, beam):
+            o = e.decode(fe[name], ln, bs, forbid, bm_, min_pred, max_pred)
+            outs[(name, name, bm_)] = (_ids(o), o["best_lprobs"].cpu())
+    mixes = [(a, b) for a in engines for b in engines if a != b and {a, b} <= {"bf16", "fp32"}]
+    for enc_p, dec_p in mixes:
+        for bm_ in (1, beam):
+            o = engines[dec_p].decode(fe[enc_p], ln, bs, forbid, bm_, min_pred, max_pred)
+            outs[(enc_p, dec_p, bm_)] = (_ids(o), o["best_lprobs"].cpu())
+    torch.cuda.synchronize(dev)
+    par = {"clips": n, "checker": "oracle/cpu_ref.py (CPU, stock PyTorch fp32) on the first clips of the same batch" if ora else
+           "library fp32 mode only (no --cpu-clips)"}
+    if ora is not None:
+        vo = {}
+        ofe = ora["frame_embs"]
+        for (enc_p, dec_p, bm_), (ids, lp) in outs.items():
+            key = enc_p if enc_p == dec_p else f"enc_{enc_p}+dec_{dec_p}"
+            d = vo.setdefault(key, {})
+            if bm_ == 1:
+                d["greedy"] = compare_ids(ids, lp, ora["greedy"], None, ora["greedy_margin"])
+            if bm_ == beam:
+                d[f"beam{beam}"] = compare_ids(ids, lp, ora["beam"], ora["beam_lp"], ora["beam_margin"])
+        for name in engines:
+            if ofe is not None:
+                g = fe[name][: ora["n"]].cpu()
+                err = (g - ofe)
+                vo[name]["frame_embs_rel_rms"] = round(float(err.pow(2).mean().sqrt() / ofe.pow(2).mean().sqrt()), 7)
+                vo[name]["frame_embs_max_abs"] = round(float(err.abs().max()), 6)
+        par["vs_oracle"] = vo
+    if "fp32" in engines:  # on all n clips: the library's fp32 mode as the reference (its ids equal the oracle's above)
+        vf = {}
+        r32 = {bm_: outs[("fp32", "fp32", bm_)] for bm_ in (1, beam)}
+        for (enc_p, dec_p, bm_), (ids, lp) in outs.items():
+            if enc_p == dec_p == "fp32":
+                continue
+            key = enc_p if enc_p == dec_p else f"enc_{enc_p}+dec_{dec_p}"
+            vf.setdefault(key, {})["greedy" if bm_ == 1 else f"beam{beam}"] = compare_ids(ids, lp, r32[bm_][0], r32[bm_][1])
+        par["vs_fp32_mode"] = vf
+    # what the other precisions cost: the same two-slot encode + decode loop, un-pipelined (one stream)
+    for name, e in engines.items():
+        if name == args.precision:
+            continue
+        fe_b = [e.decode_input_buffer(n, t_audio, beam, max_pred, slot=i) for i in range(2)]
+        cl_b = [torch.empty((n, 527), dtype=torch.float32, device=dev) for _ in range(2)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        for i in range(3):
+            e.encode(wv, out=(fe_b[i & 1], cl_b[i & 1]))
+            e.decode(fe_b[i & 1], ln, bs, forbid, beam, min_pred, max_pred, clone=False, slot=i & 1)
+        torch.cuda.synchronize(dev)
+        k_ = 4
+        enc_ms = dec_ms = 0.0
+        t1 = time.perf_counter()
+        for i in range(k_):
+            ev[0].record()
+            e.encode(wv, out=(fe_b[i & 1], cl_b[i & 1]))
+            ev[1].record()
+            e.decode(fe_b[i & 1], ln, bs, forbid, beam, min_pred, max_pred, clone=False, slot=i & 1)
+            ev[2].record()
+            torch.cuda.synchronize(dev)
+            enc_ms += ev[0].elapsed_time(ev[1]) / k_
+            dec_ms += ev[1].elapsed_time(ev[2]) / k_
+        result[f"{name}_clips_per_sec"] = round(n * k_ / (time.perf_counter() - t1), 1)
+        result[f"{name}_encode_ms"], result[f"{name}_decode_ms"] = round(enc_ms, 3), round(dec_ms, 3)
+        e.profile_enable(("frontend", "stem", "dwconv_ln", "pw1_gemm", "pw2_gemm", "downsample", "heads"))
+        e.encode(wv, out=(fe_b[0], cl_b[0]))
+        torch.cuda.synchronize(dev)
+        result[f"{name}_stage_ms"] = {k: round(v[0], 4) for k, v in e.profile_read().items()}
+        e.profile_enable(())
+    return par
 
 
 def main() -> None:
@@ -361,18 +513,25 @@ def main() -> None:
     best_tokens = int((best != 0).sum().item())            # tokens of the returned captions (<eos> included)
     beam_tokens = int((out["mult_preds"] != 0).sum().item())  # row-steps of every hypothesis of the search
 
-    # ---- timed region: exactly K steps, events only around the dominant class --------------------------
+    # ---- timed region: R windows of exactly K steps each, events only around the dominant class ---------
+    # (every window is bracketed by barrier + synchronize on both sides; the reported value is the MEDIAN window's)
     eng.profile_enable((dominant,))
     state["i"] = 0
-    n_keep = args.steps if os.environ.get("CN_BENCH_CHECK_ALL", "1") != "0" else 0  # (0: only the last step is compared)
+    n_rep = max(1, args.repeat)
+    n_timed = n_rep * args.steps
+    n_keep = n_timed if os.environ.get("CN_BENCH_CHECK_ALL", "1") != "0" else 0  # (0: only the last step is compared)
     state["keep"] = (torch.zeros((n_keep,) + tuple(solo_preds.shape), dtype=solo_preds.dtype, device=dev),
                      torch.zeros((n_keep,) + tuple(solo_lps.shape), dtype=solo_lps.dtype, device=dev))
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
+    win_dt, own_dt = [], []
+    for _ in range(n_rep):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        own_dt.append(time.perf_counter() - t0)   # this rank's own work (before it waits for the others)
+        fence()
+        win_dt.append(time.perf_counter() - t0)
     # the pipelined steps (encode of batch i next to the decodes of batches i-1, i-2) must reproduce the solo pass bit for bit
     lp_, ll_ = state["last_local"][0][:B0], state["last_local"][1][:B0]
     kp, kl = state["keep"]
@@ -384,7 +543,7 @@ def main() -> None:
     if not pipeline_consistent:
         a_, b_ = lp_[:, : solo_preds.shape[1]], solo_preds[: lp_.shape[0], : lp_.shape[1]]
         rows = (a_ != b_).any(dim=1).nonzero().flatten().tolist()
-        print(f"[bench] rank {rank}: {bad_steps} of {args.steps} pipelined steps returned other captions / scores than the un-pipelined pass of the same batch; last step: rows",
+        print(f"[bench] rank {rank}: {bad_steps} of {n_timed} pipelined steps returned other captions / scores than the un-pipelined pass of the same batch; last step: rows",
               rows[:16], "of", a_.shape[0], "| score diffs:", int((ll_ != solo_lps[: ll_.shape[0]]).sum()), file=sys.stderr, flush=True)
     if world > 1:  # every rank must agree before a number is printed
         flag = torch.tensor([1 if pipeline_consistent else 0], dtype=torch.int32, device=dev)
@@ -394,18 +553,27 @@ def main() -> None:
         raise SystemExit("bench: pipelined and un-pipelined results differ (CN_BENCH_STRICT=0 reports the number anyway, with pipeline_consistent false)")
     prof = eng.profile_read()
     eng.profile_enable(())
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        tot_audio = torch.tensor([audio_seconds], dtype=torch.float64, device=dev)
-        dist.all_reduce(tot_audio)
-        audio_seconds_all = float(tot_audio.item())
+    rank_rates = None
+    if world > 1:  # a window's time is the slowest rank's; per-rank rates show an imbalance between the GPUs
+        mine = torch.tensor(win_dt + own_dt + [float(B), audio_seconds], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        tab = torch.stack(allr).cpu()                       # (world, 2 n_rep + 2)
+        win_dt = [float(v) for v in tab[:, :n_rep].max(dim=0).values.tolist()]
+        audio_seconds_all = float(tab[:, 2 * n_rep + 1].sum())
+        rank_tab = tab
     else:
         audio_seconds_all = audio_seconds
+        rank_tab = None
+    order = sorted(range(n_rep), key=lambda k: win_dt[k])
+    med = order[(n_rep - 1) // 2]          # the median window (lower median for an even count)
+    dt = win_dt[med]
+    if rank_tab is not None:  # clips/s of every rank in the median window (its own clock, its own shard)
+        rr = (rank_tab[:, 2 * n_rep] * args.steps / rank_tab[:, n_rep + med]).tolist()
+        rank_rates = {"min": round(min(rr), 2), "max": round(max(rr), 2), "per_rank": [round(v, 2) for v in rr]}
 
     dom_ms, dom_n = prof[dominant]
-    launches_per_step = dom_n / args.steps
+    launches_per_step = dom_n / n_timed
     avg_launch_s = dom_ms * 1e-3 / dom_n
     roof = {"kernel": dominant, "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches_per_step": launches_per_step,
             "traffic": None}
@@ -443,59 +611,33 @@ def main() -> None:
         result = {
             "metric": "clips_per_sec", "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "warmup_run": warm_used, "ms_per_step": round(dt / args.steps * 1e3, 3), "pipeline_consistent": pipeline_consistent, "pipeline_steps_checked": n_keep if n_keep else 1,
-            "timed_region_s": round(dt, 4),
+            "timed_region_s": round(dt, 4), "repeat": n_rep,
+            "windows": {"clips_per_sec": [round(total_clips * args.steps / w, 2) for w in win_dt], "median_index": med,
+                        "spread": round((max(win_dt) - min(win_dt)) / dt, 4), "timed_total_s": round(sum(win_dt), 4)},
+            "rank_clips_per_sec": rank_rates,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp32": "f32", "exact": "f16x2"}[args.precision], "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": B, "global_batch": total_clips, "beam_size": beam,
                        "parallelism": f"dp{world}", "world_size_observed": world},
             "audio_seconds_per_sec": round(audio_seconds_all * args.steps / dt, 1),
-            "decode_tokens_per_sec": round(world * best_tokens / (decode_ms * 1e-3), 1),
+            "decode_tokens_per_sec": round(world * best_tokens / (decode_ms * 1e-3), 1),   # solo decode (pre-pass)
+            "decode_tokens_per_sec_pipelined": round(total_clips / B0 * best_tokens * args.steps / dt, 1) if args.workload == "fixed" else None,
             "decode_beam_row_steps_per_sec": round(world * beam_tokens / (decode_ms * 1e-3), 1),
             "encode_ms": round(encode_ms, 3), "decode_ms": round(decode_ms, 3), "stage_ms": stage_ms,
             "roofline": roof,
         }
+        if args.workload == "fixed":
+            n_steps = int(out["sizes"][0].item())
+            dby = decode_algorithmic_bytes(B0, beam, t0_, n_steps, eng.vocab_size)
+            result["roofline_decode"] = {
+                "kernel": "conette_decode (whole search, solo pre-pass)", "bound": "hbm", "achieved": round(dby / (decode_ms * 1e-3) / 1e9, 1),
+                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(dby / (decode_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                "algorithmic_bytes_per_search": dby, "search_steps": n_steps, "graph_nodes_per_search": eng.decode_graph_nodes(),
+                "launches_per_step": round(eng.decode_graph_nodes() / max_pred, 1),
+                "traffic": None}
 
-    # ---- bf16 vs fp32 agreement + what exactness costs (rank 0, N = 1, untimed) ----------------------------
-    if rank == 0 and world == 1 and args.parity_clips > 0 and args.precision == "bf16" and args.workload == "fixed":
-        n = min(args.parity_clips, B0)
-        eng32 = Engine(sd, precision="fp32", device=dev)
-        wv, ln, bs = w0[:n].contiguous(), lens0[:n].contiguous(), bos0[:n].contiguous()
-        par = {}
-        outs = {}
-        for name, e in (("bf16", eng), ("fp32", eng32)):
-            fe_, _ = e.encode(wv)
-            for bm_ in (1, 3):
-                o = e.decode(fe_, ln, bs, forbid, bm_, min_pred, max_pred)
-                outs[(name, bm_)] = (o["best_preds"][:, : int(o["sizes"][1].item())].cpu(), o["best_lprobs"].cpu())
-        seq, tok = agreement(outs[("bf16", 1)][0], outs[("fp32", 1)][0])
-        par["greedy_seq_identical"], par["greedy_token_agree"] = seq, tok
-        seq3, tok3 = agreement(outs[("bf16", 3)][0], outs[("fp32", 3)][0])
-        par["beam3_best_identical"], par["beam3_token_agree"] = seq3, tok3
-        same = (outs[("bf16", 3)][0].shape == outs[("fp32", 3)][0].shape)
-        d = (outs[("bf16", 3)][1] - outs[("fp32", 3)][1]).abs()
-        par["max_abs_lprob_diff"] = round(float(d.max()), 4)
-        par["mean_abs_lprob_diff"] = round(float(d.mean()), 4)
-        par["clips"] = n
-        par["note"] = ("bf16 (the timed mode) vs the fp32 mode of the same library, whose ids equal the reference's on every golden "
-                       "fixture (tests/test_gpu_parity.py); the synthetic checkpoint's top candidates are often within 0.1")
-        # fp32-mode throughput of the same pipeline (what bit-exact ids cost)
-        fe_b = [eng32.decode_input_buffer(n, t0_, beam, max_pred, slot=i) for i in range(2)]
-        cl_b = [torch.empty((n, 527), dtype=torch.float32, device=dev) for _ in range(2)]
-        for i in range(3):
-            eng32.encode(wv, out=(fe_b[i & 1], cl_b[i & 1]))
-            eng32.decode(fe_b[i & 1], ln, bs, forbid, beam, min_pred, max_pred, clone=False, slot=i & 1)
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        k32 = 4
-        for i in range(k32):
-            eng32.encode(wv, out=(fe_b[i & 1], cl_b[i & 1]))
-            eng32.decode(fe_b[i & 1], ln, bs, forbid, beam, min_pred, max_pred, clone=False, slot=i & 1)
-        torch.cuda.synchronize(dev)
-        result["parity"] = par
-        result["fp32_clips_per_sec"] = round(n * k32 / (time.perf_counter() - t1), 1)
-        del eng32
-
-    # ---- CPU baseline (rank 0, N = 1 only): the oracle restatement on host cores ------------------------
+    # ---- CPU baseline (rank 0, N = 1 only): the oracle restatement on host cores; its outputs are KEPT as the checker ----
+    ora = None
     if rank == 0 and world == 1 and args.cpu_clips > 0:
         from oracle import cpu_ref as O
 
@@ -506,12 +648,28 @@ def main() -> None:
         xs = w0[:nc].cpu()[:, None, :]
         with torch.no_grad():
             tc = time.perf_counter()
-            O.model_forward(sd, cfg, xs, sr=SR, task="clotho", beam_size=beam)
+            otaps, otrace, gtrace = {}, [], []
+            o3 = O.model_forward(sd, cfg, xs, sr=SR, task="clotho", beam_size=beam, taps=otaps, trace=otrace)
             tc = time.perf_counter() - tc
-        result["cpu_baseline"] = {
-            "value": round(nc / tc, 4), "unit": "clips/s", "cores": n_thr, "kind": "port",
-            "sample": f"{nc} of the same synthetic clips, same checkpoint, beam {beam}: oracle/cpu_ref.py "
-                      f"(stock PyTorch fp32, reference algorithm incl. its no-KV-cache decode), {tc:.1f} s"}
+            ofe = otaps["stage3"].mean(dim=3).transpose(1, 2).contiguous()   # frame_embs (B, T, 768), convnext.py:306
+            omem = otaps["memory"]
+            otaps.clear()
+            result["cpu_baseline"] = {
+                "value": round(nc / tc, 4), "unit": "clips/s", "cores": n_thr, "kind": "port",
+                "sample": f"{nc} of the same synthetic clips, same checkpoint, beam {beam}: oracle/cpu_ref.py "
+                          f"(stock PyTorch fp32, reference algorithm incl. its no-KV-cache decode), {tc:.1f} s"}
+            if args.workload == "fixed" and args.parity_clips > 0:   # (untimed) greedy = beam 1 from the oracle's own memory
+                msk = torch.zeros((nc, omem.shape[-1]), dtype=torch.bool)
+                g1 = O.generate(sd, omem, msk, bos_all[torch.zeros(nc, dtype=torch.long)], vocab_size=eng.vocab_size,
+                                beam_size=1, min_pred_size=min_pred, max_pred_size=max_pred,
+                                forbid_rep_mask=sd["model.forbid_rep_mask"], trace=gtrace)
+                ora = {"n": nc, "greedy": g1[0], "beam": o3["preds"], "beam_lp": o3["lprobs"],
+                       "greedy_margin": clip_min_margins(gtrace, nc), "beam_margin": clip_min_margins(otrace, nc),
+                       "frame_embs": ofe}
+
+    # ---- parity of every precision against the ORACLE + attribution of the bf16 disagreement (rank 0, N = 1, untimed) ----
+    if rank == 0 and world == 1 and args.parity_clips > 0 and args.workload == "fixed":
+        result["parity"] = parity_report(args, Engine, eng, sd, dev, w0, lens0, bos0, forbid, t0_, beam, min_pred, max_pred, ora, result)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

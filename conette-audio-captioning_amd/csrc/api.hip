@@ -197,12 +197,15 @@ struct Builder {
     const float* src = find(name, total);
     void* dst = alloc((size_t)n * ctx->esize);
     if (src) {
-      if (ctx->esize == 2)
-        hipLaunchKernelGGL((pk_copy<bf16_t>), dim3(256), dim3(256), 0, 0, src + first, (bf16_t*)dst, (size_t)n);
-      else
-        hipLaunchKernelGGL((pk_copy<float>), dim3(256), dim3(256), 0, 0, src + first, (float*)dst, (size_t)n);
+      copy_operand(src + first, dst, (size_t)n);
     }
     return dst;
+  }
+  // fp32 -> the context's operand type (bf16 | sp16 = fp16 hi/lo pairs | fp32)
+  void copy_operand(const float* src, void* dst, size_t n) {
+    if (ctx->esize == 2) hipLaunchKernelGGL((pk_copy<bf16_t>), dim3(256), dim3(256), 0, 0, src, (bf16_t*)dst, n);
+    else if (ctx->sp16) hipLaunchKernelGGL((pk_copy<sp16_t>), dim3(256), dim3(256), 0, 0, src, (sp16_t*)dst, n);
+    else hipLaunchKernelGGL((pk_copy<float>), dim3(256), dim3(256), 0, 0, src, (float*)dst, n);
   }
 };
 
@@ -212,7 +215,7 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
     cn_set_error("create: bad argument");
     return CN_ERR_ARG;
   }
-  if (cfg->precision != CONETTE_PREC_F32 && cfg->precision != CONETTE_PREC_BF16) {
+  if (cfg->precision != CONETTE_PREC_F32 && cfg->precision != CONETTE_PREC_BF16 && cfg->precision != CONETTE_PREC_F16X2) {
     cn_set_error("create: unknown precision %d", cfg->precision);
     return CN_ERR_ARG;
   }
@@ -227,6 +230,7 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
   ctx->cfg = *cfg;
   ctx->rt = new CnRuntime();
   ctx->esize = cfg->precision == CONETTE_PREC_BF16 ? 2 : 4;
+  ctx->sp16 = cfg->precision == CONETTE_PREC_F16X2 ? 1 : 0;
   {
     int dev = 0, n_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
@@ -363,6 +367,7 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
     if (w) {
       const unsigned blocks = (unsigned)(((size_t)C2 * C * 4 + 255) / 256);
       if (ctx->esize == 2) hipLaunchKernelGGL((pk_down<bf16_t>), dim3(blocks), dim3(256), 0, 0, w, (bf16_t*)dst, C2, C);
+      else if (ctx->sp16) hipLaunchKernelGGL((pk_down<sp16_t>), dim3(blocks), dim3(256), 0, 0, w, (sp16_t*)dst, C2, C);
       else hipLaunchKernelGGL((pk_down<float>), dim3(blocks), dim3(256), 0, 0, w, (float*)dst, C2, C);
     }
     ctx->down[i].w = dst;
@@ -447,12 +452,7 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
       const float* caw = B.find(p + "multihead_attn.in_proj_weight", (int64_t)3 * d * d);
       if (caw) {
         const size_t n = (size_t)2 * d * d;
-        if (ctx->esize == 2)
-          hipLaunchKernelGGL((pk_copy<bf16_t>), dim3(256), dim3(256), 0, 0, caw + (size_t)d * d,
-                             (bf16_t*)kvw + (size_t)l * n, n);
-        else
-          hipLaunchKernelGGL((pk_copy<float>), dim3(256), dim3(256), 0, 0, caw + (size_t)d * d,
-                             (float*)kvw + (size_t)l * n, n);
+        B.copy_operand(caw + (size_t)d * d, kvw + (size_t)l * n * ctx->esize, n);
       }
       lw.ca_out_w = B.operand(p + "multihead_attn.out_proj.weight", (int64_t)d * d, 0, (int64_t)d * d);
       lw.ca_out_b = B.f32(p + "multihead_attn.out_proj.bias", d);

@@ -33,6 +33,29 @@ __device__ __forceinline__ void cn_dma16_s(const void* src_base, unsigned voff, 
 }
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+// ---- sp16: the operand type of the "exact" precision (CONETTE_PREC_F16X2) -------------------------------------------
+// An fp32 value stored as the unevaluated sum of two fp16 numbers, hi = rn16(x), lo = rn16(x - hi): 22 significant bits
+// (fp32 has 24), 4 bytes per element with hi in the low half of the dword.  A product of two such operands is taken with
+// three fp16 MFMAs -- hi.hi + hi.lo + lo.hi, fp32 accumulation; the dropped lo.lo term is below 2^-22 of the product --
+// so a GEMM in this type costs three bf16-rate MFMAs per k-step where the fp32 MFMA costs sixteen times one, and its error
+// against an fp64 product is that of the fp32 MFMA path (tools/lab/split_probe.hip: mean |err| 1.1e-6 for both at K = 1536;
+// the bf16 pair split is 6.5x worse; v_mfma_f32_16x16x32_f16 keeps subnormal inputs, so a small weight's lo part counts).
+// Values beyond the fp16 range (65504) are clamped: post-LayerNorm activations, GELU outputs and weights stay far below.
+struct sp16_t {
+  _Float16 hi, lo;
+};
+__device__ __forceinline__ unsigned cn_sp16_bits(float x) {
+  x = __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
+  const _Float16 hi = (_Float16)x;
+  const _Float16 lo = (_Float16)(x - (float)hi);
+  return (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+}
+__device__ __forceinline__ float cn_sp16_value(unsigned w) {
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)) + (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
+}
 
 #define CN_OK 0
 #define CN_ERR_ARG 1
@@ -87,8 +110,10 @@ static inline int cn_cdiv(int a, int b) { return (a + b - 1) / b; }
 template <typename T> __device__ __forceinline__ T cn_from_f32(float x);
 template <> __device__ __forceinline__ float cn_from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t cn_from_f32<bf16_t>(float x) { return (bf16_t)x; }
+template <> __device__ __forceinline__ sp16_t cn_from_f32<sp16_t>(float x) { return __builtin_bit_cast(sp16_t, cn_sp16_bits(x)); }
 __device__ __forceinline__ float cn_to_f32(float x) { return x; }
 __device__ __forceinline__ float cn_to_f32(bf16_t x) { return (float)x; }
+__device__ __forceinline__ float cn_to_f32(sp16_t x) { return (float)x.hi + (float)x.lo; }
 
 // exact-erf GELU (torch F.gelu default; reference convnext.py:47, aac_tfmer.py:36)
 __device__ __forceinline__ float cn_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -190,10 +215,17 @@ __device__ __forceinline__ void cn_store4(float* p, float a, float b, float c, f
 __device__ __forceinline__ void cn_store4(bf16_t* p, float a, float b, float c, float d) {
   *(bf16x4*)p = bf16x4{(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
 }
+__device__ __forceinline__ void cn_store4(sp16_t* p, float a, float b, float c, float d) {
+  *(u32x4*)p = u32x4{cn_sp16_bits(a), cn_sp16_bits(b), cn_sp16_bits(c), cn_sp16_bits(d)};
+}
 // store 8 consecutive values as T; p must be 8-element aligned (bf16: ONE 16-byte store)
 __device__ __forceinline__ void cn_store8(float* p, const float (&o)[8]) {
   *(f32x4*)p = f32x4{o[0], o[1], o[2], o[3]};
   *(f32x4*)(p + 4) = f32x4{o[4], o[5], o[6], o[7]};
+}
+__device__ __forceinline__ void cn_store8(sp16_t* p, const float (&o)[8]) {
+  *(u32x4*)p = u32x4{cn_sp16_bits(o[0]), cn_sp16_bits(o[1]), cn_sp16_bits(o[2]), cn_sp16_bits(o[3])};
+  *(u32x4*)(p + 4) = u32x4{cn_sp16_bits(o[4]), cn_sp16_bits(o[5]), cn_sp16_bits(o[6]), cn_sp16_bits(o[7])};
 }
 __device__ __forceinline__ void cn_store8(bf16_t* p, const float (&o)[8]) {
   *(bf16x8*)p = bf16x8{(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3], (bf16_t)o[4], (bf16_t)o[5], (bf16_t)o[6], (bf16_t)o[7]};

@@ -71,6 +71,7 @@ struct conette_ctx {
   uint32_t prof_mask;
   int dec_unfused;  // CONETTE_OPT_DECODE_FUSION = 0: one launch per sub-layer (the cross-check path of the tests)
   int esize;  // operand element size (2 or 4)
+  int sp16;   // CONETTE_PREC_F16X2: operands are sp16_t (fp16 hi/lo pairs, 4 bytes)
   // frontend tables
   const float* window;     // [1024]
   const float2* tw512;     // [512]

@@ -119,6 +119,11 @@ template <> __device__ __forceinline__ f32x4 cn_load4<bf16_t>(const bf16_t* p) {
   return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
 
+template <> __device__ __forceinline__ f32x4 cn_load4<sp16_t>(const sp16_t* p) {
+  const u32x4 v = *(const u32x4*)p;
+  return f32x4{cn_sp16_value(v[0]), cn_sp16_value(v[1]), cn_sp16_value(v[2]), cn_sp16_value(v[3])};
+}
+
 __device__ __forceinline__ float cn_dot8(f32x4 a, f32x4 b) {  // 32-dim head dot: 4 local + 8-lane reduce
   float d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
   d += __shfl_xor(d, 1);
@@ -1078,6 +1083,7 @@ struct DecGraphCache {
   DecGraph g[CN_MAX_DEC_GRAPHS];
   int n;
   int enabled;
+  int last_nodes;  // nodes of the most recently captured graph (conette_decode_graph_nodes)
 };
 static DecGraphCache* graph_cache(conette_ctx* ctx, bool create) {
   if (ctx->dec_graphs == nullptr && create) {
@@ -1170,6 +1176,10 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
       return decode_impl<bf16_t>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, beam, min_pred,
                                  max_pred, best_preds, best_lprobs, mult_preds, mult_lprobs, out_sizes, step0_logits,
                                  trace_sel, trace_val, (char*)workspace, s);
+    if (ctx->cfg.precision == CONETTE_PREC_F16X2)
+      return decode_impl<sp16_t>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, beam, min_pred,
+                              max_pred, best_preds, best_lprobs, mult_preds, mult_lprobs, out_sizes, step0_logits,
+                              trace_sel, trace_val, (char*)workspace, s);
     return decode_impl<float>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, beam, min_pred,
                               max_pred, best_preds, best_lprobs, mult_preds, mult_lprobs, out_sizes, step0_logits,
                               trace_sel, trace_val, (char*)workspace, s);
@@ -1234,8 +1244,18 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
   }
   e->exec = exec;
   e->graph = graph;
+  {
+    size_t n_nodes = 0;
+    if (hipGraphGetNodes(graph, nullptr, &n_nodes) == hipSuccess) cache->last_nodes = (int)n_nodes;
+    else (void)hipGetLastError();
+  }
   CN_HIP(hipGraphLaunch(exec, s));
   return CN_OK;
+}
+
+extern "C" int32_t conette_decode_graph_nodes(const conette_ctx* ctx) {
+  const DecGraphCache* c = ctx ? (const DecGraphCache*)ctx->dec_graphs : nullptr;
+  return c ? c->last_nodes : 0;
 }
 
 // ---- teacher forcing as ONE causal pass (nn/decoding/forcing.py:12-71 is a single decoder forward over the caption) ----
@@ -1420,6 +1440,8 @@ extern "C" int conette_forcing(conette_ctx* ctx, const float* frame_embs, const 
     if (ctx->cfg.precision == CONETTE_PREC_BF16)
       return forcing_prefill_impl<bf16_t>(ctx, frame_embs, frame_lens, caps_in, batch, t_audio, cap_len, logits,
                                           (char*)workspace, s);
+    if (ctx->cfg.precision == CONETTE_PREC_F16X2)
+      return forcing_prefill_impl<sp16_t>(ctx, frame_embs, frame_lens, caps_in, batch, t_audio, cap_len, logits, (char*)workspace, s);
     return forcing_prefill_impl<float>(ctx, frame_embs, frame_lens, caps_in, batch, t_audio, cap_len, logits, (char*)workspace, s);
   }
   // CONETTE_OPT_FORCING_STEPWISE: the KV-cached step kernels fed with the caption (cross-check of the pass above)
@@ -1435,6 +1457,10 @@ extern "C" int conette_forcing(conette_ctx* ctx, const float* frame_embs, const 
     return decode_impl<bf16_t>(ctx, frame_embs, frame_lens, caps_in, nullptr, batch, t_audio, 1, 0, cap_len, mult_preds,
                                mult_lprobs, mult_preds, mult_lprobs, sizes, nullptr, nullptr, nullptr, (char*)workspace, s,
                                caps_in, logits);
+  if (ctx->cfg.precision == CONETTE_PREC_F16X2)
+    return decode_impl<sp16_t>(ctx, frame_embs, frame_lens, caps_in, nullptr, batch, t_audio, 1, 0, cap_len, mult_preds,
+                            mult_lprobs, mult_preds, mult_lprobs, sizes, nullptr, nullptr, nullptr, (char*)workspace, s,
+                            caps_in, logits);
   return decode_impl<float>(ctx, frame_embs, frame_lens, caps_in, nullptr, batch, t_audio, 1, 0, cap_len, mult_preds,
                             mult_lprobs, mult_preds, mult_lprobs, sizes, nullptr, nullptr, nullptr, (char*)workspace, s,
                             caps_in, logits);
@@ -1472,6 +1498,10 @@ extern "C" int conette_greedy(conette_ctx* ctx, const float* frame_embs, const i
     return decode_impl<bf16_t>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, 1, min_pred, max_pred, preds,
                                best_lprobs, mult_preds, mult_lprobs, out_sizes, nullptr, nullptr, nullptr, (char*)workspace,
                                s, nullptr, nullptr, logits);
+  if (ctx->cfg.precision == CONETTE_PREC_F16X2)
+    return decode_impl<sp16_t>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, 1, min_pred, max_pred, preds,
+                            best_lprobs, mult_preds, mult_lprobs, out_sizes, nullptr, nullptr, nullptr, (char*)workspace, s,
+                            nullptr, nullptr, logits);
   return decode_impl<float>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, 1, min_pred, max_pred, preds,
                             best_lprobs, mult_preds, mult_lprobs, out_sizes, nullptr, nullptr, nullptr, (char*)workspace, s,
                             nullptr, nullptr, logits);

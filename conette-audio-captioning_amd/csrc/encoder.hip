@@ -857,6 +857,9 @@ extern "C" int conette_encode(conette_ctx* ctx, const float* wave, int32_t batch
   if (ctx->cfg.precision == CONETTE_PREC_BF16)
     return encode_impl<bf16_t>(ctx, wave, batch, n_samples, frame_embs, clip_probs, taps, (char*)workspace,
                                (hipStream_t)stream);
+  if (ctx->cfg.precision == CONETTE_PREC_F16X2)
+    return encode_impl<sp16_t>(ctx, wave, batch, n_samples, frame_embs, clip_probs, taps, (char*)workspace,
+                               (hipStream_t)stream);
   return encode_impl<float>(ctx, wave, batch, n_samples, frame_embs, clip_probs, taps, (char*)workspace,
                             (hipStream_t)stream);
 }

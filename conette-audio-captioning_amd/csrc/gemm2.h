@@ -89,6 +89,59 @@ __device__ __forceinline__ void cn_g2_compute(const char* sA, const char* sW, in
   }
 }
 
+// The same k-tile for sp16 operands (common.h): the staged rows hold 4-byte {hi, lo} elements, so a tile of BK bf16-sized
+// columns is BK / 2 elements and one MFMA k-step (32 elements) spans 128 bytes of a row: lane group g takes the two
+// neighbouring 16-byte chunks 2 (g + 4 ks) and 2 (g + 4 ks) + 1 (both through the same XOR swizzle as the loader), splits the
+// eight {hi, lo} dwords into a hi and a lo fp16 vector (v_perm_b32) and the product of a pair of fragments is three
+// v_mfma_f32_16x16x32_f16: lo.hi + hi.lo + hi.hi, smallest terms first.
+__device__ __forceinline__ void cn_sp_split(u32x4 c0, u32x4 c1, f16x8& hi, f16x8& lo) {
+  u32x4 h, l;
+  h[0] = __builtin_amdgcn_perm(c0[1], c0[0], 0x05040100u);
+  h[1] = __builtin_amdgcn_perm(c0[3], c0[2], 0x05040100u);
+  h[2] = __builtin_amdgcn_perm(c1[1], c1[0], 0x05040100u);
+  h[3] = __builtin_amdgcn_perm(c1[3], c1[2], 0x05040100u);
+  l[0] = __builtin_amdgcn_perm(c0[1], c0[0], 0x07060302u);
+  l[1] = __builtin_amdgcn_perm(c0[3], c0[2], 0x07060302u);
+  l[2] = __builtin_amdgcn_perm(c1[1], c1[0], 0x07060302u);
+  l[3] = __builtin_amdgcn_perm(c1[3], c1[2], 0x07060302u);
+  hi = __builtin_bit_cast(f16x8, h);
+  lo = __builtin_bit_cast(f16x8, l);
+}
+template <int BM, int BN, int BK, int WM = 2, int WN = 2>
+__device__ __forceinline__ void cn_g2_compute_sp(const char* sA, const char* sW, int lane, int wm, int wn,
+                                                 f32x4 (&acc)[BN / (16 * WN)][BM / (16 * WM)]) {
+  typedef G2Geom<BK> G;
+  static_assert(BK % 64 == 0, "sp16 tiles: a k-step is 32 elements = 64 bf16-sized columns");
+  constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN), KS = BK / 64;
+  const int lr = lane & 15;
+  const int sw = (lr / G::RPB) & G::SWM;
+  const int row_off = lr * G::RBY;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int c0 = ((2 * ((lane >> 4) + 4 * ks)) ^ sw) * 16, c1 = ((2 * ((lane >> 4) + 4 * ks) + 1) ^ sw) * 16;
+    f16x8 wh[TN], wl[TN], ah[TM], al[TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+      const char* r = sW + (wn * (BN / WN) + a * 16) * G::RBY + row_off;
+      cn_sp_split(*(const u32x4*)(r + c0), *(const u32x4*)(r + c1), wh[a], wl[a]);
+    }
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      const char* r = sA + (wm * (BM / WM) + b * 16) * G::RBY + row_off;
+      cn_sp_split(*(const u32x4*)(r + c0), *(const u32x4*)(r + c1), ah[b], al[b]);
+    }
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        f32x4 c = acc[a][b];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[a], ah[b], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[a], al[b], c, 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[a], ah[b], c, 0, 0, 0);
+      }
+  }
+}
+
 __device__ unsigned long long g_g2_prof[16];
 // Phase stamps exist only in a profiling build (CN_G2_PROF=1 python build.py --force; tools/g2prof.py): the
 // accumulators cost 32 registers, which pushed the 128 x 128 tiles from 148 to 180 and broke the co-residency
@@ -186,7 +239,9 @@ __device__ __forceinline__ void cn_g2_epilogue(char* smem, f32x4 (&acc)[BN / (16
   }
 }
 
-template <int BM, int BN, int BK, int NST, class Epi, int WM = 2, int WN = 2>
+// SP: the operands are sp16 matrices handed over as bf16-sized columns (lda, ldw, K, k_slice all doubled by the launcher):
+// staging is byte-for-byte the bf16 path, only the fragment reads / MFMAs of a k-tile differ (cn_g2_compute_sp)
+template <int BM, int BN, int BK, int NST, class Epi, int WM = 2, int WN = 2, bool SP = false>
 __global__ __launch_bounds__(WM * WN * 64) void cn_gemm2_kernel(const bf16_t* __restrict__ A, int lda,
                                                        const bf16_t* __restrict__ W, int ldw, int M, int N, int K,
                                                        int k_slice, Epi epi, int dbg) {
@@ -257,7 +312,8 @@ __global__ __launch_bounds__(WM * WN * 64) void cn_gemm2_kernel(const bf16_t* __
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
-      cn_g2_compute<BM, BN, BK, WM, WN>(smem, smem + A_BYTES, lane, wm, wn, acc);
+      if constexpr (SP) cn_g2_compute_sp<BM, BN, BK, WM, WN>(smem, smem + A_BYTES, lane, wm, wn, acc);
+      else cn_g2_compute<BM, BN, BK, WM, WN>(smem, smem + A_BYTES, lane, wm, wn, acc);
       if (kt + 1 < KT) {
         __syncthreads();
         stage(0, kt + 1);
@@ -297,7 +353,10 @@ __global__ __launch_bounds__(WM * WN * 64) void cn_gemm2_kernel(const bf16_t* __
 #ifdef CN_G2_PROF
       if (!(dbg & 4))
 #endif
-      cn_g2_compute<BM, BN, BK, WM, WN>(sA, sA + A_BYTES, lane, wm, wn, acc);
+      {
+        if constexpr (SP) cn_g2_compute_sp<BM, BN, BK, WM, WN>(sA, sA + A_BYTES, lane, wm, wn, acc);
+        else cn_g2_compute<BM, BN, BK, WM, WN>(sA, sA + A_BYTES, lane, wm, wn, acc);
+      }
       G2_STAMP(3)
     }
     __syncthreads();  // all fragment reads done before the epilogue reuses the LDS
@@ -340,16 +399,16 @@ static inline int g2_debug_skip() { return 0; }
 static inline int g2_debug_epi() { return 0; }
 #endif
 
-template <int BM, int BN, int BK, int NST, class Epi, int WM = 2, int WN = 2>
+template <int BM, int BN, int BK, int NST, class Epi, int WM = 2, int WN = 2, bool SP = false>
 static int cn_launch_gemm2_t(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, int splits,
                              const Epi& epi, hipStream_t stream) {
   constexpr int EPI_BYTES = sizeof(typename Epi::stage_t) == 4 ? 0 : BM * (BN * 2 + 16);
   constexpr int PIPE_BYTES = NST * (BM + BN) * BK * 2;
   constexpr int SMEM = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
-  CN_TRY(cn_configure_lds((const void*)cn_gemm2_kernel<BM, BN, BK, NST, Epi, WM, WN>, SMEM));
+  CN_TRY(cn_configure_lds((const void*)cn_gemm2_kernel<BM, BN, BK, NST, Epi, WM, WN, SP>, SMEM));
   const long blocks = (long)cn_cdiv(M, BM) * cn_cdiv(N, BN);
   const int k_slice = K / splits;
-  hipLaunchKernelGGL((cn_gemm2_kernel<BM, BN, BK, NST, Epi, WM, WN>), dim3((unsigned)blocks, (unsigned)splits), dim3(WM * WN * 64), SMEM,
+  hipLaunchKernelGGL((cn_gemm2_kernel<BM, BN, BK, NST, Epi, WM, WN, SP>), dim3((unsigned)blocks, (unsigned)splits), dim3(WM * WN * 64), SMEM,
                      stream, A, lda, W, ldw, M, N, K, k_slice, epi, (g2_debug_level() == BM + BN && (g2_debug_epi() == 0 || g2_debug_epi() == (int)sizeof(typename Epi::stage_t)) ? 1 : 0) | g2_debug_skip());
   CN_LAUNCH_CHECK();
   return CN_OK;
@@ -405,11 +464,35 @@ static int cn_gemm2(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, i
   return cn_launch_gemm2_t<64, 64, 64, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
 }
 
-// type-generic front end: bf16 -> v2, fp32 -> gemm.h
+// sp16 dispatch ("exact" precision): K elements of 4 bytes = 2 K bf16-sized columns; K % 32 == 0.  128 x 128 (or 128 x 96)
+// tiles with four waves and two blocks per compute unit for the encoder's products, 64 x 64 for the decoder's.
+template <class Epi>
+static int cn_gemm2_sp(const sp16_t* A, int lda, const sp16_t* W, int ldw, int M, int N, int K, const Epi& epi,
+                       hipStream_t stream) {
+  if (K % 32 != 0 || M <= 0 || N <= 0) {
+    cn_set_error("cn_gemm2_sp: bad shape M=%d N=%d K=%d", M, N, K);
+    return CN_ERR_ARG;
+  }
+  const bf16_t* a = (const bf16_t*)A;
+  const bf16_t* w = (const bf16_t*)W;
+  if (M >= 4096) {
+    const bool n96 = (N % 96 == 0) && (N % 128 != 0);
+    if (n96) return cn_launch_gemm2_t<128, 96, 64, 2, Epi, 2, 2, true>(a, 2 * lda, w, 2 * ldw, M, N, 2 * K, 1, epi, stream);
+    return cn_launch_gemm2_t<128, 128, 64, 2, Epi, 2, 2, true>(a, 2 * lda, w, 2 * ldw, M, N, 2 * K, 1, epi, stream);
+  }
+  return cn_launch_gemm2_t<64, 64, 64, 2, Epi, 2, 2, true>(a, 2 * lda, w, 2 * ldw, M, N, 2 * K, 1, epi, stream);
+}
+
+// type-generic front end: bf16 -> v2, sp16 -> v2 with split fragments, fp32 -> gemm.h
 template <class Epi>
 static int cn_mm(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const Epi& epi,
                  hipStream_t stream) {
   return cn_gemm2(A, lda, W, ldw, M, N, K, epi, stream);
+}
+template <class Epi>
+static int cn_mm(const sp16_t* A, int lda, const sp16_t* W, int ldw, int M, int N, int K, const Epi& epi,
+                 hipStream_t stream) {
+  return cn_gemm2_sp(A, lda, W, ldw, M, N, K, epi, stream);
 }
 template <class Epi>
 static int cn_mm(const float* A, int lda, const float* W, int ldw, int M, int N, int K, const Epi& epi,

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libconette_hip.so")
 
 PREC_F32 = 0
 PREC_BF16 = 1
+PREC_F16X2 = 2   # "exact": fp16 hi/lo operand pairs, three MFMAs per product (include/conette_hip.h)
 N_MELS = 224
 FEAT = 768
 N_TAGS = 527
@@ -27,7 +28,7 @@ EXPORTS = (
     "conette_frontend_logmel", "conette_encode", "conette_decode", "conette_resample", "conette_resample_len",
     "conette_set_option", "conette_profile_enable", "conette_profile_read", "conette_stream_create_masked",
     "conette_stream_destroy", "conette_forcing_workspace_bytes", "conette_forcing",
-    "conette_greedy_workspace_bytes", "conette_greedy",
+    "conette_greedy_workspace_bytes", "conette_greedy", "conette_decode_graph_nodes",
 )
 OPT_DECODE_GRAPH = 1
 OPT_DECODE_FUSION = 2
@@ -97,6 +98,8 @@ def load_library() -> C.CDLL:
                                    C.c_void_p]
     lib.conette_set_option.restype = C.c_int
     lib.conette_set_option.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.conette_decode_graph_nodes.restype = C.c_int32
+    lib.conette_decode_graph_nodes.argtypes = [C.c_void_p]
     lib.conette_profile_enable.restype = C.c_int
     lib.conette_profile_enable.argtypes = [C.c_void_p, C.c_uint32]
     lib.conette_profile_read.restype = C.c_int
@@ -168,8 +171,8 @@ class Engine:
             raise RuntimeError("conette_amd.Engine needs a ROCm GPU (no CPU fallback)")
         self.lib = load_library()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.precision = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16}[precision]
-        self.precision_name = "bf16" if self.precision == PREC_BF16 else "fp32"
+        self.precision = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "exact": PREC_F16X2, "f16x2": PREC_F16X2}[precision]
+        self.precision_name = {PREC_BF16: "bf16", PREC_F32: "fp32", PREC_F16X2: "exact"}[self.precision]
         vocab = int(state_dict["model.decoder.classifier.weight"].shape[0])
         self.vocab_size = vocab
         self.d_model, self.nhead, self.n_layers, self.d_ff = d_model, nhead, n_layers, d_ff
@@ -389,6 +392,10 @@ class Engine:
     def set_encode_reserved_cus(self, n: int) -> None:
         """Compute units the encoder's persistent kernels leave free for a decode running on another stream."""
         _check(self.lib.conette_set_option(self._ctx, OPT_ENCODE_RESERVED_CUS, int(n)), "set_option")
+
+    def decode_graph_nodes(self) -> int:
+        """Kernel / copy nodes of the most recently captured decode hipGraph (0 before the first capture)."""
+        return int(self.lib.conette_decode_graph_nodes(self._ctx))
 
     def profile_enable(self, classes=()) -> None:
         mask = 0

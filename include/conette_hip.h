@@ -30,6 +30,9 @@ extern "C" {
  * the residual streams are always fp32) */
 #define CONETTE_PREC_F32 0  /* v_mfma_f32_16x16x4_f32: exact-fp32 parity mode          */
 #define CONETTE_PREC_BF16 1 /* v_mfma_f32_16x16x32_bf16: throughput mode (BASELINE cfg) */
+#define CONETTE_PREC_F16X2 2 /* "exact": every GEMM operand an fp16 hi + lo pair (22 bits), products as three
+                                v_mfma_f32_16x16x32_f16 (hi.hi + hi.lo + lo.hi): fp32-MFMA accuracy at MFMA-f16 rate,
+                                exact-erf GELU; token ids equal the fp32 mode's / the reference's */
 
 typedef struct conette_ctx conette_ctx; /* opaque: packed weights + constant tables */
 
@@ -160,6 +163,10 @@ int conette_stream_destroy(void* stream);
 #define CONETTE_OPT_FORCING_STEPWISE 4 /* default 0: conette_forcing is one causal pass over all caption positions
                                          (forcing.py:12-71); 1: the KV-cached step kernels fed with the caption */
 int conette_set_option(conette_ctx* ctx, int32_t option, int32_t value);
+
+/* Kernel / copy nodes of the decode hipGraph captured most recently by conette_decode on this context (0: none yet):
+ * the launch count of one whole search, for bench.py's decode roofline entry. */
+int32_t conette_decode_graph_nodes(const conette_ctx* ctx);
 
 /* Per-kernel-class timing with HIP events recorded on the caller's stream around each launch
  * of the selected classes (bench.py's roofline leg).  While a decoder class is selected, decode

@@ -5,6 +5,7 @@
 Tolerances:
   fp32 mode : intermediates rtol 1e-3 / atol 2e-4 of an O(1) activation; token ids bit-exact
               (every golden candidate gap is > 6e-4); averaged log-probs abs 1e-4.
+  exact mode: the fp32 tolerances (operands are fp16 hi + lo pairs = 22 bits, products of three fp16 MFMAs).
   bf16 mode : intermediates abs 0.1 (observed max 0.035 at rms ~1.1); every beam decision whose
               reference top-(k+1) candidates are separated by > 0.25 must match for as long as the
               search state is still the reference's; best averaged log-prob abs 0.15.
@@ -22,14 +23,18 @@ pytestmark = pytest.mark.gpu
 
 # share of a scenario's top-k calls that test_topk_decisions_at_reference_states must verify (the rest are near-ties at
 # that precision: reference margin <= the tolerance)
-MIN_SAME = {"fp32": 1.0, "bf16": 0.75}
+MIN_SAME = {"fp32": 1.0, "exact": 1.0, "bf16": 0.75}
+# precisions held to the fp32 tolerances and to bit-exact ids: the fp32-MFMA mode and the "exact" mode (fp16 hi/lo operand
+# pairs, three MFMAs per product: include/conette_hip.h CONETTE_PREC_F16X2)
+EXACT = ("fp32", "exact")
 NCHW_TAPS = ["stem", "stage0_block0", "stage0", "down1", "stage1", "down2", "stage2", "down3", "stage3"]
 
 
 @pytest.fixture(scope="module")
 def engines(synth_weights):
     from conette_amd.engine import Engine
-    return {"fp32": Engine(synth_weights, precision="fp32"), "bf16": Engine(synth_weights, precision="bf16")}
+    return {"fp32": Engine(synth_weights, precision="fp32"), "bf16": Engine(synth_weights, precision="bf16"),
+            "exact": Engine(synth_weights, precision="exact")}
 
 
 def _padded_wave(g):
@@ -38,22 +43,22 @@ def _padded_wave(g):
     return torch.from_numpy(synth.synth_waveforms(len(n), max(n), int(g["seed0"]), lengths=n)), n
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "exact", "bf16"])
 @pytest.mark.parametrize("name", G.SCENARIOS)
 def test_encode_matches_reference_fixture(name, prec, engines):
     g = G.load(name)
     wave, n = _padded_wave(g)
     fe, clip, taps = engines[prec].encode(wave.cuda(), taps=True)
     torch.cuda.synchronize()
-    rtol, atol = (1e-3, 2e-4) if prec == "fp32" else (0.0, 0.1)
+    rtol, atol = (1e-3, 2e-4) if prec in EXACT else (0.0, 0.1)
     np.testing.assert_allclose(G.sub(taps["logmel"]), g["sub_logmel"], rtol=1e-3, atol=2e-3, err_msg="logmel")
     for k in NCHW_TAPS:
         got = G.sub(taps[k].permute(0, 3, 1, 2).contiguous())
         np.testing.assert_allclose(got, g["sub_" + k], rtol=rtol, atol=atol, err_msg=f"{name}/{prec}/{k}")
         if prec == "bf16":  # the bulk must be much closer than the worst element
             assert float(np.abs(got - g["sub_" + k]).mean()) < 0.02, k
-    np.testing.assert_allclose(fe.cpu().numpy(), g["frame_embs"], rtol=rtol, atol=atol if prec == "fp32" else 0.06)
-    np.testing.assert_allclose(clip.cpu().numpy(), g["tags_probs"], rtol=rtol, atol=1e-4 if prec == "fp32" else 0.03)
+    np.testing.assert_allclose(fe.cpu().numpy(), g["frame_embs"], rtol=rtol, atol=atol if prec in EXACT else 0.06)
+    np.testing.assert_allclose(clip.cpu().numpy(), g["tags_probs"], rtol=rtol, atol=1e-4 if prec in EXACT else 0.03)
 
 
 def _ref_calls(g, beam):
@@ -79,7 +84,7 @@ def _ref_calls(g, beam):
     return calls
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "exact", "bf16"])
 @pytest.mark.parametrize("name", G.SCENARIOS)
 def test_decode_matches_reference_fixture(name, prec, engines, synth_weights, synth_cfg):
     """Beam search from the reference's own frame embeddings: per-step decisions and outputs."""
@@ -104,7 +109,7 @@ def test_decode_matches_reference_fixture(name, prec, engines, synth_weights, sy
     val = out["trace_val"].cpu().numpy()
     # Effective margin of a call = smallest gap among its top-(k+1) candidates: the gap to the first
     # rejected candidate (recorded) and the gaps between consecutive picks (order decides row slots).
-    tol = 5e-4 if prec == "fp32" else 0.25
+    tol = 5e-4 if prec in EXACT else 0.25
     diverged = set()
     n_checked = 0
     for step, clip, par, tok, sums, margin in _ref_calls(g, beam):
@@ -120,31 +125,31 @@ def test_decode_matches_reference_fixture(name, prec, engines, synth_weights, sy
                 diverged.add(clip)
             continue
         assert same, (name, prec, step, clip, sel[step, clip, :k].tolist(), par, tok)
-        np.testing.assert_allclose(val[step, clip, :k], sums, atol=2e-4 * (step + 1) if prec == "fp32" else 0.12 * (step + 1))
+        np.testing.assert_allclose(val[step, clip, :k], sums, atol=2e-4 * (step + 1) if prec in EXACT else 0.12 * (step + 1))
         n_checked += 1
     n_calls = len(_ref_calls(g, beam))
     print(f"decode {name}/{prec}: {n_checked} of {n_calls} top-k calls checked, diverged clips {sorted(diverged)}")
     # fp32: every call.  bf16: this sequential comparison stops at a clip's first near-tie that falls the other way, so
     # its count is not a coverage measure -- test_topk_decisions_at_reference_states checks every call independently.
-    if prec == "fp32":
+    if prec in EXACT:
         assert n_checked == n_calls
     ps, bm = (int(x) for x in out["sizes"].tolist())
     if not diverged:
         assert out["mult_preds"][:, :, :ps].cpu().tolist() == g["mult_preds"].tolist()
         assert out["best_preds"][:, :bm].cpu().tolist() == g["preds"].tolist()
-        np.testing.assert_allclose(out["mult_lprobs"].cpu().numpy(), g["mult_lprobs"], atol=1e-4 if prec == "fp32" else 0.05)
+        np.testing.assert_allclose(out["mult_lprobs"].cpu().numpy(), g["mult_lprobs"], atol=1e-4 if prec in EXACT else 0.05)
     # beam log-prob tolerance (north_star): clips whose search never left the reference's state must
     # agree to 1e-4 (fp32) / 0.05 (bf16); a clip that took the other side of a near-tie decodes a
     # different caption, whose length-normalised score is only sanity-bounded
     keep = [b for b in range(bsz) if b not in diverged]
     got_lp = out["best_lprobs"].cpu().numpy()
-    np.testing.assert_allclose(got_lp[keep], g["lprobs"][keep], atol=1e-4 if prec == "fp32" else 0.05)
+    np.testing.assert_allclose(got_lp[keep], g["lprobs"][keep], atol=1e-4 if prec in EXACT else 0.05)
     assert np.all(np.abs(got_lp - g["lprobs"]) < 0.5) and np.all(got_lp < 0)
-    if prec == "fp32":
+    if prec in EXACT:
         assert not diverged  # every golden candidate gap exceeds the fp32 tolerance
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "exact", "bf16"])
 @pytest.mark.parametrize("name", G.SCENARIOS)
 def test_topk_decisions_at_reference_states(name, prec, engines, synth_weights, synth_cfg):
     """Every _select_k_next_toks call of the reference's beam search (beam.py:230-269), checked INDEPENDENTLY: the
@@ -187,7 +192,7 @@ def test_topk_decisions_at_reference_states(name, prec, engines, synth_weights, 
         logits = eng.forcing(fe, lens, caps).cpu()                    # (rows, max_pred, V)
     finally:
         eng.set_forcing_stepwise(False)
-    tol = 5e-4 if prec == "fp32" else 0.25
+    tol = 5e-4 if prec in EXACT else 0.25
     n_checked = n_same = 0
     for (r0, n_rows, sm), (step, clip, par, tok, sums, margin) in zip(items, calls):
         lg = logits[r0 : r0 + n_rows, step].clone()
@@ -203,7 +208,7 @@ def test_topk_decisions_at_reference_states(name, prec, engines, synth_weights, 
         k = len(par)
         vals, flat = torch.topk(cand.reshape(-1), k)
         eff = min([margin] + [sums[i] - sums[i + 1] for i in range(k - 1)])
-        np.testing.assert_allclose(vals.numpy(), sums, atol=2e-4 * (step + 1) if prec == "fp32" else 0.2)
+        np.testing.assert_allclose(vals.numpy(), sums, atol=2e-4 * (step + 1) if prec in EXACT else 0.2)
         same = (flat // v).tolist() == par and (flat % v).tolist() == tok
         n_same += same
         if eff <= tol:
@@ -215,7 +220,7 @@ def test_topk_decisions_at_reference_states(name, prec, engines, synth_weights, 
     # fp32: every call.  bf16: every call whose margin exceeds 0.25 (asserted above; at least one per scenario), and the
     # share of calls that are IDENTICAL to the reference whatever their margin (this synthetic checkpoint's top-3 picks are
     # often within 0.1 of each other) must stay above MIN_SAME
-    assert n_checked >= (len(calls) if prec == "fp32" else 1), (n_checked, len(calls))
+    assert n_checked >= (len(calls) if prec in EXACT else 1), (n_checked, len(calls))
     assert n_same >= MIN_SAME[prec] * len(calls), (n_same, len(calls))
 
 
@@ -280,7 +285,7 @@ def forcing_mode(request, engines):
         e.set_forcing_stepwise(False)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "exact", "bf16"])
 def test_teacher_forcing_matches_reference_fixture(prec, engines, forcing_mode):
     """conette_forcing against logits produced by the reference itself (all caption positions,
     padded ones included: padded positions are masked as keys exactly like tensor_to_pad_mask does)."""
@@ -292,7 +297,7 @@ def test_teacher_forcing_matches_reference_fixture(prec, engines, forcing_mode):
     got = eng.forcing(fe, lens, caps).permute(0, 2, 1).cpu().numpy()  # (B, V, cap_len) like the reference
     ref = g["logits"]
     assert got.shape == ref.shape
-    if prec == "fp32":
+    if prec in EXACT:
         np.testing.assert_allclose(got, ref, rtol=1e-3, atol=2e-3)
     else:
         # bf16 operands: logits span +-40; compare log-probabilities of the reference's top candidates
@@ -310,10 +315,10 @@ def test_teacher_forcing_matches_reference_fixture(prec, engines, forcing_mode):
     again = eng.forcing(fe, lens, caps).permute(0, 2, 1).cpu().numpy()
     assert np.array_equal(got, again)
     one = eng.forcing(fe[1:2].contiguous(), lens[1:2], caps[1:2]).permute(0, 2, 1).cpu().numpy()
-    np.testing.assert_allclose(one[0], got[1], atol=1e-5 if prec == "fp32" else 1e-3)
+    np.testing.assert_allclose(one[0], got[1], atol=1e-5 if prec in EXACT else 1e-3)
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("prec", ["fp32", "exact", "bf16"])
 @pytest.mark.parametrize("name", ["greedy_bos", "greedy_task"])
 def test_greedy_search_matches_reference_fixture(name, prec, engines, synth_weights):
     """conette_greedy against the masked step logits produced by the reference's greedy_search."""
@@ -326,7 +331,7 @@ def test_greedy_search_matches_reference_fixture(name, prec, engines, synth_weig
     out = eng.greedy(fe, lens, bos, fm, int(g["min_pred"]), int(g["max_pred"]))
     got = out["logits"].permute(0, 2, 1).cpu()                      # (B, V, pred_size) like the reference
     ref = torch.from_numpy(g["logits"])
-    if prec == "fp32":
+    if prec in EXACT:
         assert tuple(got.shape) == tuple(ref.shape)
         fin = torch.isfinite(ref)
         assert torch.equal(torch.isfinite(got), fin)                # EOS floor, forbid-repeat, finished-clip fill
