@@ -149,6 +149,31 @@ __device__ __forceinline__ f32x2 cn_gelu_fast2(f32x2 x) {
   const f32x2 h = x * 0.5f;
   return __builtin_elementwise_abs(h) * er + h;
 }
+// The "exact" precision's GELU: the same A&S 7.1.26 erfc (|abs error| <= 1.5e-7 -- about one fp32 ulp of the O(1)
+// values it multiplies) written without the cancellation of 0.5 x + 0.5 |x| erf for negative arguments:
+//     gelu(x) = max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2)
+// ~9 VALU per element in packed form against ~45 for libm's erff (the pw1 epilogue of stage 0 is 347 M elements per
+// launch: erff alone was 380 us of a 620 us launch).
+__device__ __forceinline__ f32x2 cn_gelu_as2(f32x2 x) {
+  const f32x2 ax = __builtin_elementwise_abs(x);
+  const f32x2 d = ax * (0.70710678118654752440f * 0.3275911f) + 1.0f;
+  const f32x2 t = f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  f32x2 p = t * 1.061405429f + (-1.453152027f);
+  p = p * t + 1.421413741f;
+  p = p * t + (-0.284496736f);
+  p = p * t + 0.254829592f;
+  const f32x2 u = x * 0.84932180028801904272f;  // sqrt(0.5 * log2(e)): exp(-x^2/2) = exp2(-u^2)
+  const f32x2 zz = -(u * u);
+  const f32x2 e = f32x2{__builtin_amdgcn_exp2f(zz[0]), __builtin_amdgcn_exp2f(zz[1])};
+  const f32x2 q = (p * t) * e;                  // erfc(|x| / sqrt 2)
+  const f32x2 pos = f32x2{fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+  return pos - (ax * 0.5f) * q;
+}
+__device__ __forceinline__ float cn_gelu_as(float x) { return cn_gelu_as2(f32x2{x, x})[0]; }
+__device__ __forceinline__ f32x4 cn_gelu_as4(f32x4 x) {
+  const f32x2 a = cn_gelu_as2(f32x2{x[0], x[1]}), b = cn_gelu_as2(f32x2{x[2], x[3]});
+  return f32x4{a[0], a[1], b[0], b[1]};
+}
 __device__ __forceinline__ f32x4 cn_gelu_fast4(f32x4 x) {
   const f32x2 a = cn_gelu_fast2(f32x2{x[0], x[1]}), b = cn_gelu_fast2(f32x2{x[2], x[3]});
   return f32x4{a[0], a[1], b[0], b[1]};

@@ -986,7 +986,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
         }
         {
           CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-          EpiBiasAct<T> e1{lw.ff1_b, ffh, dff, std::is_same<T, bf16_t>::value ? ACT_GELU_FAST : ACT_GELU};
+          EpiBiasAct<T, CnGeluAct<T>::value> e1{lw.ff1_b, ffh, dff, CnGeluAct<T>::value};
           CN_TRY(cn_mm(xt, d, (const T*)lw.ff1_w, d, R, dff, d, e1, s));
         }
         if constexpr (std::is_same<T, bf16_t>::value) {
@@ -1386,7 +1386,7 @@ static int forcing_prefill_impl(conette_ctx* ctx, const float* frame_embs, const
     CN_LAUNCH_CHECK();
     {
       CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-      EpiBiasAct<T> e1{lw.ff1_b, ffh, dff, std::is_same<T, bf16_t>::value ? ACT_GELU_FAST : ACT_GELU};
+      EpiBiasAct<T, CnGeluAct<T>::value> e1{lw.ff1_b, ffh, dff, CnGeluAct<T>::value};
       CN_TRY(cn_mm(xt, d, (const T*)lw.ff1_w, d, R, dff, d, e1, s));
     }
     {

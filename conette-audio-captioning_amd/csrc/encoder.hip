@@ -797,7 +797,7 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
 #ifdef CN_G2_NOACT  // timing experiment only (wrong results): how much of the epilogue is the activation?
           constexpr int kAct = ACT_NONE;
 #else
-          constexpr int kAct = std::is_same<T, bf16_t>::value ? ACT_GELU_FAST : ACT_GELU;
+          constexpr int kAct = CnGeluAct<T>::value;
 #endif
           EpiBiasAct<T, kAct> e1{bw.b1, hbuf, 4 * C, kAct};
           CN_TRY(cn_mm(y, C, (const T*)bw.w1, C, (int)P, 4 * C, C, e1, s));

@@ -24,7 +24,12 @@ template <> struct GemmTraits<float> {
   static constexpr int CPR = 8;
 };
 
-enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3, ACT_GELU_FAST = 4 };
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3, ACT_GELU_FAST = 4, ACT_GELU_AS = 5 };
+// GELU of a precision's GEMM epilogues: libm erff in the fp32 parity mode, A&S erfc without cancellation in the "exact"
+// (sp16) mode, the A&S form of cn_gelu_fast in bf16
+template <typename T> struct CnGeluAct { static constexpr int value = ACT_GELU; };
+template <> struct CnGeluAct<bf16_t> { static constexpr int value = ACT_GELU_FAST; };
+template <> struct CnGeluAct<sp16_t> { static constexpr int value = ACT_GELU_AS; };
 
 // out[m][n] = act(acc + bias[n])
 // ACT >= 0 fixes the activation at compile time: with the runtime switch every one of the 16 accumulator tiles of a
@@ -43,6 +48,7 @@ template <typename TOut, int ACT = -1> struct EpiBiasAct {
     if (bias != nullptr && n < N) x += bias[n];
     if (the_act() == ACT_GELU) x = cn_gelu(x);
     else if (the_act() == ACT_GELU_FAST) x = cn_gelu_fast(x);
+    else if (the_act() == ACT_GELU_AS) x = cn_gelu_as(x);
     else if (the_act() == ACT_RELU) x = fmaxf(x, 0.0f);
     else if (the_act() == ACT_SIGMOID) x = 1.0f / (1.0f + __expf(-x));
     return x;
@@ -71,11 +77,21 @@ template <typename TOut, int ACT = -1> struct EpiBiasAct {
   }
   __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int N, int /*ks*/ = 0) const {
     float r[4];
+    if (the_act() == ACT_GELU_AS && n + 3 < N && (ldo & 3) == 0) {  // four columns at once, packed math
+      if (bias != nullptr) {
+        const f32x4 b = *(const f32x4*)(bias + n);
+        v = f32x4{v[0] + b[0], v[1] + b[1], v[2] + b[2], v[3] + b[3]};
+      }
+      const f32x4 g = cn_gelu_as4(v);
+      cn_store4(out + (size_t)m * ldo + n, g[0], g[1], g[2], g[3]);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float x = v[i];
       if (bias != nullptr && n + i < N) x += bias[n + i];
       if (the_act() == ACT_GELU) x = cn_gelu(x);
+      else if (the_act() == ACT_GELU_AS) x = cn_gelu_as(x);
       else if (the_act() == ACT_GELU_FAST) x = cn_gelu_fast(x);
       else if (the_act() == ACT_RELU) x = fmaxf(x, 0.0f);
       else if (the_act() == ACT_SIGMOID) x = 1.0f / (1.0f + __expf(-x));

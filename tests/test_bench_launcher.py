@@ -30,6 +30,21 @@ def test_self_launch_two_ranks_strong_ragged():
     assert d["n_gpus"] == 2 and d["ok"] and d["scaling"] == "strong" and d["global_batch"] == 7 and d["shard"] == [0, 4]
 
 
+def test_self_launch_eight_ranks_config4_shards():
+    """BASELINE config 4: 2048 clips over 8 ranks (shards of 256), and a ragged 2047: every rank's shard bounds, the gathered
+    order of ids + scores (rank r's clips land at rows shard_bounds(G, r, 8)) and the trimmed width are checked on all
+    ranks (gloo; the RCCL run itself needs the 8-GPU node)."""
+    d = _run(["--gpus", "8", "--global-batch", "2048"])
+    assert d["n_gpus"] == 8 and d["world_size_observed"] == 8 and d["ok"] and d["scaling"] == "strong"
+    assert d["global_batch"] == 2048 and d["shard"] == [0, 256]
+    d = _run(["--gpus", "8", "--global-batch", "2047"])
+    assert d["ok"] and d["global_batch"] == 2047 and d["shard"] == [0, 256]
+    from conette_amd.dist import shard_bounds
+    b = [shard_bounds(2047, r, 8) for r in range(8)]
+    assert b[0][0] == 0 and b[-1][1] == 2047 and all(b[i][1] == b[i + 1][0] for i in range(7))
+    assert sorted(hi - lo for lo, hi in b) == [255] + [256] * 7
+
+
 def test_wrong_world_size_is_refused():
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--gpus", "2"], env=env,

@@ -13,6 +13,7 @@
 #include "mlp_rc2.h"
 #include "mlp_rc2_f8.h"
 #include "mlp_rc2_skew.h"
+#include "mlp_rs.h"
 
 void cn_set_error(const char* fmt, ...) {
   va_list ap;
@@ -84,6 +85,7 @@ __global__ void ref_out_f8(const float* H, const float* W2, const float* ls, con
   X[i] = fmaf(a, aux[4 * C + n], aux[6 * C + n]);
 }
 
+static int g_full = 0;
 static uint32_t rng_state = 12345u;
 static float frand() {  // uniform [-1, 1)
   rng_state = rng_state * 1664525u + 1013904223u;
@@ -112,6 +114,8 @@ template <> std::vector<Variant> variants<96>() {
        [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 8, 1>(Y, WS, X, M, nb, s); }, 1},
       {"rc2_resident<96,12,nck1>",
        [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 12, 1>(Y, WS, X, M, nb, s); }, 1},
+      {"rs<96,np8,nst8>",
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<96, 8, 8>(Y, WS, X, M, nb, s); }, 4},
   };
 }
 template <> std::vector<Variant> variants<192>() {
@@ -120,14 +124,26 @@ template <> std::vector<Variant> variants<192>() {
        [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_ring<192, 8, 1, 5>(Y, WS, X, M, nb, s); }, 1},
       {"rc2_ring<192,8,nck2,nst3>",
        [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_ring<192, 8, 2, 3>(Y, WS, X, M, nb, s); }, 2},
+      {"rs<192,np4,nst5>",
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<192, 4, 5>(Y, WS, X, M, nb, s); }, 4},
+      {"rs<192,np8,nst5>",
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<192, 8, 5>(Y, WS, X, M, nb, s); }, 4},
   };
 }
 template <> std::vector<Variant> variants<384>() {
   return {
       {"rc2_ring<384,4,nck1,nst3>",
        [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_ring<384, 4, 1, 3>(Y, WS, X, M, nb, s); }, 1},
-      {"rc2_skew<384,4,nst3>",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_skew<384, 4, 3>(Y, WS, X, M, nb, s); }, 3},
+      {"rs<384,np4,nst3>",
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3>(Y, WS, X, M, nb, s); }, 4},
+      {"ABL rs<384> no DMA",
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 1>(Y, WS, X, M, nb, s); }, 4},
+      {"ABL rs<384> no GELU",
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 2>(Y, WS, X, M, nb, s); }, 4},
+      {"ABL rs<384> no tile I/O",
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 4>(Y, WS, X, M, nb, s); }, 4},
+      {"ABL rs<384> none of the three",
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 7>(Y, WS, X, M, nb, s); }, 4},
   };
 }
 
@@ -152,8 +168,8 @@ template <int C> static int run(int batch, int iters) {
   bf16_t* Y = dalloc<bf16_t>(hY.size());
   float *X = dalloc<float>(hX.size() + 64 * C), *Xref = dalloc<float>((size_t)Mc * C), *Xref2 = dalloc<float>((size_t)Mc * C);
   bf16_t* H = dalloc<bf16_t>((size_t)Mc * 4 * C);
-  bf16_t* WS2[4] = {nullptr, dalloc<bf16_t>(Rc2Geom<C, 1>::TOTAL_BYTES / 2), dalloc<bf16_t>(Rc2Geom<C, 2>::TOTAL_BYTES / 2),
-                    dalloc<bf16_t>(Rc2Geom<C, 1>::TOTAL_BYTES / 2)};  // [3]: NCK = 1, skewed entries
+  bf16_t* WS2[5] = {nullptr, dalloc<bf16_t>(Rc2Geom<C, 1>::TOTAL_BYTES / 2), dalloc<bf16_t>(Rc2Geom<C, 2>::TOTAL_BYTES / 2),
+                    dalloc<bf16_t>(Rc2Geom<C, 1>::TOTAL_BYTES / 2), dalloc<bf16_t>(Rc2Geom<C, 1>::TOTAL_BYTES / 2)};  // [3]: NCK = 1, skewed entries; [4]: role-split entries
   CK(hipMemcpy(W1, hW1.data(), hW1.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(W2, hW2.data(), hW2.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(b1, hb1.data(), 4 * C * 4, hipMemcpyHostToDevice));
@@ -167,6 +183,7 @@ template <int C> static int run(int batch, int iters) {
     }
     const int u3 = (C / 8) * (C / 8 + 1) * 64;
     hipLaunchKernelGGL(pk_mlp_rc2_skew, dim3((u3 + 255) / 256), dim3(256), 0, 0, W1, b1, W2, b2, sc, C, 1, WS2[3], 1);
+    hipLaunchKernelGGL(pk_mlp_rs, dim3((u3 + 255) / 256), dim3(256), 0, 0, W1, b1, W2, b2, sc, C, WS2[4]);
   }
   // reference on the first Mc rows
   CK(hipMemcpy(Xref, hX.data(), (size_t)Mc * C * 4, hipMemcpyHostToDevice));
@@ -199,6 +216,7 @@ template <int C> static int run(int batch, int iters) {
     }
     size_t touched = 0;  // rows beyond Mc must be untouched
     for (size_t i = href.size(); i < hgot.size(); ++i) touched += hgot[i] != hX[i];
+    if (v.name.rfind("ABL", 0) == 0) continue;
     printf("  check nb %3d %-30s max|err| %.3e  mean %.3e  (max |delta| %.3f)  out-of-tol %zu  rows>=M touched %zu  %s\n", nbc, v.name.c_str(),
            max_err, sum_err / href.size(), max_ref, n_bad, touched, (n_bad == 0 && touched == 0) ? "OK" : "FAIL");
     bad += (n_bad != 0 || touched != 0);
@@ -243,8 +261,8 @@ template <int C> static int run(int batch, int iters) {
     for (int i = 0; i < 5; ++i) printf("    %-26s %9.1f\n", nm[i], h[i] / n);
   }
 
-  // ---- FP8 variant --------------------------------------------------------------------------------------------------
-  {
+  // ---- FP8 variant (only with a 4th argument) -----------------------------------------------------------------------
+  if (g_full) {
     typedef Rc2F8Geom<C> G8;
     char* WS8 = dalloc<char>(G8::TOTAL_BYTES);
     if (cn_pack_mlp_f8(W1, b1, W2, b2, sc, C, WS8, 0) != CN_OK) return 1;
@@ -312,6 +330,7 @@ int main(int argc, char** argv) {
   const int C = argc > 1 ? atoi(argv[1]) : 96;
   const int batch = argc > 2 ? atoi(argv[2]) : 64;
   const int iters = argc > 3 ? atoi(argv[3]) : 10;
+  g_full = argc > 4;
   if (C == 96) return run<96>(batch, iters);
   if (C == 192) return run<192>(batch, iters);
   if (C == 384) return run<384>(batch, iters);
