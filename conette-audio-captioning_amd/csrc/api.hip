@@ -10,6 +10,7 @@
 #include "ctx.h"
 #include <algorithm>
 #include "mlp_rc2.h"
+#include "mlp_rs.h"
 #include "down_fused.h"
 
 static thread_local char g_err[512] = "";
@@ -413,7 +414,9 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
           const float* w2 = B.find(p + "pwconv2.weight", (int64_t)4 * C * C);
           if (w1 && w2 && bw.b1 && bw.b2 && bw.scale) {
             const int units = (C / 8) * (C / 8 + 1) * 64;
-            hipLaunchKernelGGL(pk_mlp_rc2, dim3((units + 255) / 256), dim3(256), 0, 0, w1, bw.b1, w2, bw.b2, bw.scale, C, CN_RC2_NCK(C), ms);
+            // C = 384 runs the role-split kernel (mlp_rs.h): same fragments, entry e = [W1 of chunk e | W2 of chunk e - 2]
+            if (C == 384) hipLaunchKernelGGL(pk_mlp_rs, dim3((units + 255) / 256), dim3(256), 0, 0, w1, bw.b1, w2, bw.b2, bw.scale, C, ms);
+            else hipLaunchKernelGGL(pk_mlp_rc2, dim3((units + 255) / 256), dim3(256), 0, 0, w1, bw.b1, w2, bw.b2, bw.scale, C, CN_RC2_NCK(C), ms);
             bw.mlp_stream = ms;
           }
         }

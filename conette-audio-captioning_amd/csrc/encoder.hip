@@ -10,6 +10,7 @@
 
 #include "gemm2.h"
 #include "mlp_rc2.h"
+#include "mlp_rs.h"
 #include "down_fused.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -787,7 +788,7 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
           const bf16_t* wsm = (const bf16_t*)bw.mlp_stream;
           if (C == 96) CN_TRY((cn_launch_mlp_rc2_resident<96, 12, 1>(y, wsm, xc, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
           else if (C == 192) CN_TRY((cn_launch_mlp_rc2_ring<192, 8, CN_RC2_NCK(192), CN_RC2_NCK(192) == 2 ? 3 : 5>(y, wsm, xc, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
-          else CN_TRY((cn_launch_mlp_rc2_ring<384, 4, 1, 3>(y, wsm, xc, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
+          else CN_TRY((cn_launch_mlp_rs<384, 4, 3>(y, wsm, xc, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
           fused = true;
         }
       }

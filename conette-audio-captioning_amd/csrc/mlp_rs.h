@@ -21,8 +21,22 @@
 // step and the ring protocol is the chained kernel's: entry g + NST - 1 is requested at the start of step g.
 //
 // LDS: NST x (C/8 + 1) KB ring + NP x 2 KB hand-over buffers (single-buffered: two barriers per step -- the first
-// publishes entry g and G(g-1), B takes G(g-1) into registers, the second lets A overwrite it).
+// publishes entry g and G(g-1), B takes G(g-1) into registers, the second lets A overwrite it) + bb (C fp32).
+//
+// The ring refill (1 KB LDS-DMA pieces) is issued by the B waves INSIDE their MFMA loop: B has no VALU work, so a piece
+// fits the gap behind one of its MFMAs while the partner's MFMA runs (issued between the barriers instead, with every wave
+// taking a share, the refill cost 60 us of a 209 us launch at C = 384; inside B's loop 15).
+// Tile boundaries are software-pipelined into the steps around them:
+//   * A re-loads y fragment s of the NEXT tile in place, right behind the last MFMA of the tile that reads fragment s
+//     (the first step of the next tile meets them one step later);
+//   * B keeps O transposed -- GEMM2 as W2c' . G^T: lane = position, four consecutive channels per register quad, so the
+//     residual moves in 16-byte pieces (48 loads + 48 stores per tile instead of 192 + 192: the per-wave queue of 63
+//     outstanding operations no longer throttles it) -- and runs its MFMAs tile by tile (k 0, k 1 of one 32-channel tile
+//     back to back), so that in a tile's last step the store of channel tile t and the load of the next position tile's
+//     residual into the same registers follow the tile's last MFMA, one tile behind.
 #pragma once
+#include <type_traits>
+
 #include "mlp_rc2.h"
 
 static __global__ void pk_mlp_rs(const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
@@ -63,11 +77,16 @@ static __global__ void pk_mlp_rs(const float* __restrict__ W1, const float* __re
 
 // ABL (kernel lab only, wrong results): 1 = no ring refill after the prologue, 2 = GELU replaced by a copy, 4 = no residual / y
 // traffic at tile boundaries
-template <int C, int ABL = 0> struct RsWave {
+template <int C, int NP, int ABL = 0> struct RsWave {
   typedef Rc2Geom<C, 1> G;
   typedef Rc2Wave<C, 1> W;
-  static constexpr int KS1 = G::KS1, NT2 = G::NT2, F1 = G::F1, F2 = G::F2;
-  static constexpr int PRE = 4, R = PRE + 1;
+  static constexpr int KS1 = G::KS1, NT2 = G::NT2, F1 = G::F1, F2 = G::F2, FR = G::FRAGS;
+#ifndef CN_RS_PRE
+#define CN_RS_PRE 4
+#endif
+  static constexpr int PRE = CN_RS_PRE, R = PRE + 1;
+  static constexpr int NPW = (FR + NP - 1) / NP;  // ring pieces a B wave issues per step
+  static_assert(NPW <= F2, "one piece per MFMA gap at most");
 
   // ---- A: GEMM1 of this step's chunk into Xn, interleaved with the GELU of the previous chunk's Xp -> H ----------------
   // GELU element pair (e, e + 1) rides behind MFMA (e * F1) / 16
@@ -85,59 +104,201 @@ template <int C, int ABL = 0> struct RsWave {
     }
     if constexpr (E + 2 < 16) a_gelu<Q, E + 2>(Xp, st);
   }
-  template <int Q>
-  static __device__ __forceinline__ void a_mstep(const char* wc, const bf16x8 (&fy)[KS1], const bf16x8 ones, const f32x16& Xp,
-                                                 f32x16& Xn, AState& st) {
+  // RELOAD: the tile's last step -- fragment s of the next tile's y replaces fy[s] behind the MFMA that read it
+  template <int Q, bool RELOAD>
+  static __device__ __forceinline__ void a_mstep(const char* wc, bf16x8 (&fy)[KS1], const bf16x8 ones, const f32x16& Xp,
+                                                 f32x16& Xn, AState& st, const bf16_t* ynext) {
     if constexpr (Q + PRE < F1) st.F[(Q + PRE) % R] = W::frag(wc, Q + PRE);
     if constexpr (Q == 0) Xn = W::mma(st.F[0], fy[0], W::zero16());
     else if constexpr (Q < KS1) Xn = W::mma(st.F[Q % R], fy[Q], Xn);
     else Xn = W::mma(st.F[Q % R], ones, Xn);
     a_gelu<Q, 0>(Xp, st);
+    if constexpr (RELOAD && Q >= 1 && Q <= KS1) fy[Q - 1] = *(const bf16x8*)(ynext + 16 * (Q - 1));  // (one MFMA behind its last reader)
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (Q + 1 < F1) a_mstep<Q + 1>(wc, fy, ones, Xp, Xn, st);
+    if constexpr (Q + 1 < F1) a_mstep<Q + 1, RELOAD>(wc, fy, ones, Xp, Xn, st, ynext);
   }
   template <int Q>
   static __device__ __forceinline__ void a_prefetch(const char* wc, AState& st) {
     st.F[Q % R] = W::frag(wc, Q);
     if constexpr (Q + 1 < PRE) a_prefetch<Q + 1>(wc, st);
   }
-  // wc: this step's entry (lane offset applied); gdst: this pair's hand-over buffer (lane offset applied)
-  static __device__ __forceinline__ void a_step(const char* wc, const bf16x8 (&fy)[KS1], const bf16x8 ones, const f32x16& Xp,
-                                                f32x16& Xn, char* gdst) {
+  // wc: this step's entry (lane offset applied); gdst: this pair's hand-over buffer (lane offset applied);
+  // ynext: the next tile's y rows with this lane's offset applied (RELOAD only)
+  template <bool RELOAD>
+  static __device__ __forceinline__ void a_step(const char* wc, bf16x8 (&fy)[KS1], const bf16x8 ones, const f32x16& Xp,
+                                                f32x16& Xn, char* gdst, const bf16_t* ynext) {
     AState st;
     a_prefetch<0>(wc, st);
     __builtin_amdgcn_sched_barrier(0);
-    a_mstep<0>(wc, fy, ones, Xp, Xn, st);
+    a_mstep<0, RELOAD>(wc, fy, ones, Xp, Xn, st, ynext);
     *(bf16x8*)gdst = bf16x8{(bf16_t)st.g[0], (bf16_t)st.g[1], (bf16_t)st.g[2],  (bf16_t)st.g[3],
                             (bf16_t)st.g[4], (bf16_t)st.g[5], (bf16_t)st.g[6],  (bf16_t)st.g[7]};
     *(bf16x8*)(gdst + 1024) = bf16x8{(bf16_t)st.g[8],  (bf16_t)st.g[9],  (bf16_t)st.g[10], (bf16_t)st.g[11],
                                      (bf16_t)st.g[12], (bf16_t)st.g[13], (bf16_t)st.g[14], (bf16_t)st.g[15]};
   }
 
-  // ---- B: O += G . W2c'^T, fragments PRE ahead -----------------------------------------------------------------------
+  // ---- B: O^T += W2c' . G^T; lane = position m0 + (l & 31), register 4 q + e of tile t = channel 32 t + 8 q + 4 (l >> 5) + e
+  struct Dma {
+    const char* src;   // entry to fetch (wave-uniform)
+    unsigned dst;      // LDS byte address of its slot
+    unsigned voff;     // lane * 16
+    int first;         // this wave's first piece; the others follow at stride NP
+    int n_pieces;      // pieces of the entry (0: nothing to issue)
+  };
+  template <int I>
+  static __device__ __forceinline__ void dma_piece(const Dma& d) {
+    const int piece = d.first + I * NP;
+    if (piece < d.n_pieces) cn_dma16_s(d.src + piece * 1024, d.voff, d.dst + piece * 1024);
+  }
+  // the residual rows of a tile: row pointers carry the lane's position and channel-quad offset, (t, q) are immediates
+  static __device__ __forceinline__ void load_tile(const float* xrow, int t, f32x16& Ot) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *(const f32x4*)(xrow + 32 * t + 8 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Ot[4 * q + e] = v[e];
+    }
+  }
+  // (bb is added IN PLACE: the tile's registers are dead after the store -- the next tile's residual is loaded over them)
+  static __device__ __forceinline__ void store_tile(float* xrow, const char* bbl, int t, bool in_range, f32x16& Ot) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b = *(const f32x4*)(bbl + (32 * t + 8 * q) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Ot[4 * q + e] += b[e];
+      if (in_range) *(f32x4*)(xrow + 32 * t + 8 * q) = f32x4{Ot[4 * q], Ot[4 * q + 1], Ot[4 * q + 2], Ot[4 * q + 3]};
+    }
+  }
   struct BState {
     bf16x8 F[R];
   };
-  template <int Q>
-  static __device__ __forceinline__ void b_mstep(const char* w2, const bf16x8 (&H)[2], f32x16 (&O)[NT2], BState& st) {
-    if constexpr (Q + PRE < F2) st.F[(Q + PRE) % R] = W::frag(w2, Q + PRE);
-    constexpr int k = Q / NT2, t = Q % NT2;
-    O[t] = W::mma(H[k], st.F[Q % R], O[t]);
+  // MFMA order: Q = 2 t + k (the k-steps of one channel tile back to back); fragment (k, t) sits at k * NT2 + t of the W2 part.
+  // LAST: the tile's last chunk -- one tile behind the MFMAs, O[t] (+ bb) is stored and, if there is a next position
+  // tile for this pair, its residual is loaded into the same registers.
+  static constexpr int fidx(int q) { return (q & 1) * NT2 + (q >> 1); }
+  static constexpr int piece_at(int i) { return (i * F2) / NPW; }  // piece i rides behind MFMA piece_at(i)
+  template <int Q, int I>
+  static __device__ __forceinline__ void b_dma(const Dma& d) {
+    if constexpr (I < NPW) {
+      if constexpr (piece_at(I) == Q) dma_piece<I>(d);
+      else b_dma<Q, I + 1>(d);
+    }
+  }
+  // LAST: the tile's last chunk -- one channel tile behind the MFMAs, O[t] (+ bb) is stored and the residual of the pair's
+  // next position tile is loaded into the same registers.  Both are UNCONDITIONAL instruction streams (rows outside the
+  // tensor are masked per lane; a pair without a next tile re-loads rows it never uses): a branch around them, or a
+  // run-time choice between two instantiations of the step, made the register allocator give O different registers on
+  // the two paths and shuffle all 192 of them through scratch at the join.
+  template <int Q, bool LAST>
+  static __device__ __forceinline__ void b_mstep(const char* w2, const bf16x8 (&H)[2], f32x16 (&O)[NT2], BState& st, const Dma& d,
+                                                 float* xrow, const float* xnext, const char* bbl, bool in_range) {
+    if constexpr (Q + PRE < F2) st.F[(Q + PRE) % R] = W::frag(w2, fidx(Q + PRE));
+    constexpr int k = Q & 1, t = Q >> 1;
+    O[t] = W::mma(st.F[Q % R], H[k], O[t]);
+    b_dma<Q, 0>(d);
+    if constexpr (LAST && k == 1 && t >= 1) {
+      store_tile(xrow, bbl, t - 1, in_range, O[t - 1]);
+      load_tile(xnext, t - 1, O[t - 1]);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (Q + 1 < F2) b_mstep<Q + 1>(w2, H, O, st);
+    if constexpr (Q + 1 < F2) b_mstep<Q + 1, LAST>(w2, H, O, st, d, xrow, xnext, bbl, in_range);
   }
   template <int Q>
   static __device__ __forceinline__ void b_prefetch(const char* w2, BState& st) {
-    st.F[Q % R] = W::frag(w2, Q);
+    st.F[Q % R] = W::frag(w2, fidx(Q));
     if constexpr (Q + 1 < PRE) b_prefetch<Q + 1>(w2, st);
   }
-  static __device__ __forceinline__ void b_step(const char* w2, const bf16x8 (&H)[2], f32x16 (&O)[NT2]) {
+  template <bool LAST>
+  static __device__ __forceinline__ void b_step(const char* w2, const bf16x8 (&H)[2], f32x16 (&O)[NT2], const Dma& d, float* xrow,
+                                                const float* xnext, const char* bbl, bool in_range) {
     BState st;
     b_prefetch<0>(w2, st);
     __builtin_amdgcn_sched_barrier(0);
-    b_mstep<0>(w2, H, O, st);
+    b_mstep<0, LAST>(w2, H, O, st, d, xrow, xnext, bbl, in_range);
+    if constexpr (LAST) {
+      store_tile(xrow, bbl, NT2 - 1, in_range, O[NT2 - 1]);
+      load_tile(xnext, NT2 - 1, O[NT2 - 1]);
+    }
+  }
+  static __device__ __forceinline__ void issue_all(const Dma& d) {  // a step without a tile still owes the refill
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+      const int piece = d.first + i * NP;
+      if (piece < d.n_pieces) cn_dma16_s(d.src + piece * 1024, d.voff, d.dst + piece * 1024);
+    }
   }
 };
+
+// s_waitcnt vmcnt(n) for a wave-uniform n (the immediate must be a constant); n >= 63: nothing to wait for (a wave never
+// has more than 63 vector-memory operations outstanding)
+__device__ __forceinline__ void cn_vm_wait(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+    case 22: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+    case 23: asm volatile("s_waitcnt vmcnt(23)" ::: "memory"); break;
+    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    case 25: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+    case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
+    case 27: asm volatile("s_waitcnt vmcnt(27)" ::: "memory"); break;
+    case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
+    case 29: asm volatile("s_waitcnt vmcnt(29)" ::: "memory"); break;
+    case 30: asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); break;
+    case 31: asm volatile("s_waitcnt vmcnt(31)" ::: "memory"); break;
+    case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+    case 33: asm volatile("s_waitcnt vmcnt(33)" ::: "memory"); break;
+    case 34: asm volatile("s_waitcnt vmcnt(34)" ::: "memory"); break;
+    case 35: asm volatile("s_waitcnt vmcnt(35)" ::: "memory"); break;
+    case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+    case 37: asm volatile("s_waitcnt vmcnt(37)" ::: "memory"); break;
+    case 38: asm volatile("s_waitcnt vmcnt(38)" ::: "memory"); break;
+    case 39: asm volatile("s_waitcnt vmcnt(39)" ::: "memory"); break;
+    case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+    case 41: asm volatile("s_waitcnt vmcnt(41)" ::: "memory"); break;
+    case 42: asm volatile("s_waitcnt vmcnt(42)" ::: "memory"); break;
+    case 43: asm volatile("s_waitcnt vmcnt(43)" ::: "memory"); break;
+    case 44: asm volatile("s_waitcnt vmcnt(44)" ::: "memory"); break;
+    case 45: asm volatile("s_waitcnt vmcnt(45)" ::: "memory"); break;
+    case 46: asm volatile("s_waitcnt vmcnt(46)" ::: "memory"); break;
+    case 47: asm volatile("s_waitcnt vmcnt(47)" ::: "memory"); break;
+    case 48: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+    case 49: asm volatile("s_waitcnt vmcnt(49)" ::: "memory"); break;
+    case 50: asm volatile("s_waitcnt vmcnt(50)" ::: "memory"); break;
+    case 51: asm volatile("s_waitcnt vmcnt(51)" ::: "memory"); break;
+    case 52: asm volatile("s_waitcnt vmcnt(52)" ::: "memory"); break;
+    case 53: asm volatile("s_waitcnt vmcnt(53)" ::: "memory"); break;
+    case 54: asm volatile("s_waitcnt vmcnt(54)" ::: "memory"); break;
+    case 55: asm volatile("s_waitcnt vmcnt(55)" ::: "memory"); break;
+    case 56: asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); break;
+    case 57: asm volatile("s_waitcnt vmcnt(57)" ::: "memory"); break;
+    case 58: asm volatile("s_waitcnt vmcnt(58)" ::: "memory"); break;
+    case 59: asm volatile("s_waitcnt vmcnt(59)" ::: "memory"); break;
+    case 60: asm volatile("s_waitcnt vmcnt(60)" ::: "memory"); break;
+    case 61: asm volatile("s_waitcnt vmcnt(61)" ::: "memory"); break;
+    case 62: asm volatile("s_waitcnt vmcnt(62)" ::: "memory"); break;
+    default: break;
+  }
+}
 
 // NP pairs per block (2 NP waves: waves [0, NP) are the A roles, [NP, 2 NP) the B roles: with waves dealt round-robin over the
 // four SIMDs a pair shares its SIMD when NP is a multiple of 4); pair p owns tiles t_lo + p + it * NP of the block's range.
@@ -146,11 +307,11 @@ __global__ __launch_bounds__(2 * NP * 64) void cn_mlp_rs_kernel(const bf16_t* __
                                                                 float* __restrict__ X, int M) {
   typedef Rc2Geom<C, 1> G;
   typedef Rc2Wave<C, 1> W;
-  typedef RsWave<C, ABL> RW;
-  constexpr int NW = 2 * NP, NCH = G::NSTEP, FR = G::FRAGS, SB = G::STEP_BYTES;
-  constexpr int DPW_LO = FR / NW, N_HI = FR % NW;  // waves < N_HI issue DPW_LO + 1 pieces per entry
+  typedef RsWave<C, NP, ABL> RW;
+  constexpr int NCH = G::NSTEP, FR = G::FRAGS, SB = G::STEP_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* gbuf = smem + NST * SB;  // NP x 2 KB hand-over buffers
+  char* gbuf = smem + NST * SB;          // NP x 2 KB hand-over buffers
+  char* bbuf = gbuf + NP * 2048;         // bb = s b2 (fp32, C)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool role_b = wave >= NP;
@@ -160,29 +321,28 @@ __global__ __launch_bounds__(2 * NP * 64) void cn_mlp_rs_kernel(const bf16_t* __
   const int n_tiles = (M + 31) >> 5;
   const int t_lo = (int)((long)blockIdx.x * n_tiles / gridDim.x), t_hi = (int)((long)(blockIdx.x + 1) * n_tiles / gridDim.x);
   const int max_it = (t_hi - t_lo + NP - 1) / NP;  // block-uniform
-  const int n_steps = max_it * NCH + 2;            // + 2: B runs two chunks behind A
 
   const unsigned voff = lane * 16;
   const unsigned lds0 = cn_lds_addr(smem);
-  auto stage = [&](int g) {  // stream entry g % NCH -> slot g % NST (this wave's pieces)
-    if ((ABL & 1) && g >= NST - 1) return;
-    const char* src = (const char*)WS + (size_t)(g % NCH) * SB;  // wave-uniform
-    const unsigned dst = lds0 + (unsigned)((g % NST) * SB);
-#pragma unroll
-    for (int i = 0; i < DPW_LO + 1; ++i) {
-      const int piece = wave + i * NW;
-      if (i < DPW_LO || wave < N_HI) cn_dma16_s(src + piece * 1024, voff, dst + piece * 1024);
-    }
+  const int n_mine = role_b ? (FR - pair + NP - 1) / NP : 0;  // ring pieces of this wave per entry
+  auto entry = [&](int g) {
+    typename RW::Dma d;
+    d.src = (const char*)WS + (size_t)(g % NCH) * SB, d.dst = lds0 + (unsigned)((g % NST) * SB);
+    d.voff = voff, d.first = pair, d.n_pieces = (!role_b || ((ABL & 1) && g >= NST - 1)) ? 0 : FR;
+    return d;
   };
-  auto ring_wait = [&]() {  // this wave's pieces of the entry about to be consumed have landed (NST - 2 younger entries may fly)
-    if (N_HI > 0 && wave < N_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (DPW_LO + 1)) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * DPW_LO) : "memory");
-  };
+  for (int i = tid; i < C; i += 2 * NP * 64) ((float*)bbuf)[i] = aux[i];
 #pragma unroll
-  for (int g = 0; g < NST - 1; ++g) stage(g);
+  for (int g = 0; g < NST - 1; ++g) RW::issue_all(entry(g));
   const char* wl = smem + lane * 16;
   char* gl = gbuf + pair * 2048 + lane * 16;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // bb is in LDS before the first barrier
 
+  // Both roles run max_it * NCH + 2 steps of two barriers each; their loops have NO run-time choice between step variants
+  // (see b_mstep): the last step of a tile is peeled behind the loop over the others.
+  if constexpr ((ABL & 24) != 0) {  // lab: static wave priority for one of the roles (8: B, 16: A)
+    if (role_b == ((ABL & 8) != 0)) __builtin_amdgcn_s_setprio(1);
+  }
   if (!role_b) {
     // ================================================= A ==============================================================
     bf16x8 ones;
@@ -190,66 +350,76 @@ __global__ __launch_bounds__(2 * NP * 64) void cn_mlp_rs_kernel(const bf16_t* __
     for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)((lane < 32 && i < 2) ? 1.0f : 0.0f);
     bf16x8 fy[G::KS1];
     f32x16 Xa = W::zero16(), Xb = W::zero16();
-    if (t_lo + pair < t_hi) W::load_y(Y, (t_lo + pair) * 32, lane, fy);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): y (and the first entries; once per block)
+    const int yoff = (lane & 31) * C + 8 * (lane >> 5);  // elements: fy[s] = y[m0 + (l & 31)][16 s + 8 (l >> 5) .. + 8]
+    const int tile0 = t_lo + pair < t_hi ? t_lo + pair : t_lo;  // (a pair without a tile multiplies rows nobody stores)
+    W::load_y(Y, tile0 * 32, lane, fy);
     int g = 0;
-    for (int it = 0; it <= max_it; ++it) {  // (+ one trailing pass: steps max_it * NCH and + 1 only finish the last chunk's GELU)
+    auto step2 = [&](auto reload_tag, const bf16_t* ynext) {  // two steps: the roles of the two X accumulators swap
+      constexpr bool RELOAD = decltype(reload_tag)::value;
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
+      RW::template a_step<false>(wl + (g % NST) * SB, fy, ones, Xb, Xa, gl, ynext);  // GEMM1(g) -> Xa, GELU of Xb (chunk g - 1) -> G
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ++g;
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();
+      RW::template a_step<RELOAD>(wl + (g % NST) * SB, fy, ones, Xa, Xb, gl, ynext);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ++g;
+    };
+    for (int it = 0; it < max_it; ++it) {
       const int tile = t_lo + pair + it * NP;
-      const bool last_pass = it == max_it;
-      for (int j = 0; j < (last_pass ? 2 : NCH); j += 2) {
-        // two steps per trip: the roles of the two X accumulators swap
-        ring_wait();
-        __builtin_amdgcn_s_barrier();
-        stage(g + NST - 1);
-        __builtin_amdgcn_s_barrier();
-        RW::a_step(wl + (g % NST) * SB, fy, ones, Xb, Xa, gl);  // GEMM1(g) -> Xa, GELU of Xb (chunk g - 1) -> G
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        ++g;
-        ring_wait();
-        __builtin_amdgcn_s_barrier();
-        stage(g + NST - 1);
-        __builtin_amdgcn_s_barrier();
-        RW::a_step(wl + (g % NST) * SB, fy, ones, Xa, Xb, gl);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        ++g;
-      }
-      if (!last_pass && tile + NP < t_hi && !(ABL & 4)) {
-        W::load_y(Y, (tile + NP) * 32, lane, fy);
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-      }
+      const int tnext = (tile + NP < t_hi && !(ABL & 4)) ? tile + NP : tile0;  // (no next tile: rows it never uses)
+      const bf16_t* ynext = Y + (size_t)tnext * 32 * C + yoff;
+      for (int j = 0; j < NCH - 2; j += 2) step2(std::false_type{}, ynext);
+      step2(std::true_type{}, ynext);  // the tile's last two steps: the second re-loads y in place
     }
+    step2(std::false_type{}, Y);  // trailing: the GELU of the last chunk (B is two chunks behind)
   } else {
     // ================================================= B ==============================================================
     f32x16 O[G::NT2];
+    const int xoff = (lane & 31) * C + 4 * (lane >> 5);  // elements: this lane's position row and channel-quad offset
+    const char* bbl = bbuf + 16 * (lane >> 5);
+    const int tile0 = t_lo + pair < t_hi ? t_lo + pair : t_lo;
+    {
+      const float* x0 = X + (size_t)tile0 * 32 * C + xoff;
+#pragma unroll
+      for (int t = 0; t < G::NT2; ++t) RW::load_tile(x0, t, O[t]);
+    }
     int g = 0;
-    for (int it = 0; it <= max_it; ++it) {
-      const bool last_pass = it == max_it;
-      for (int j = 0; j < (last_pass ? 2 : NCH); ++j, ++g) {
-        ring_wait();
-        __builtin_amdgcn_s_barrier();
-        stage(g + NST - 1);
-        const int gb = g - 2;                       // the chunk step B works on
-        const int itb = gb < 0 ? 0 : gb / NCH, cb = gb < 0 ? 0 : gb % NCH;
-        const int tile = t_lo + pair + itb * NP;
-        const bool valid = gb >= 0 && tile < t_hi;
-        bf16x8 H[2];
-        H[0] = *(const bf16x8*)gl;
-        H[1] = *(const bf16x8*)(gl + 1024);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (valid) {
-          if (cb == 0 && !(ABL & 4)) {
-            W::init_o(X, tile * 32, lane, O);
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-          }
-          RW::b_step(wl + (g % NST) * SB + RW::F1 * 1024, H, O);
-          if (cb == NCH - 1 && (!(ABL & 4) || it == max_it)) {
-            const float* bbv = aux;
-            asm volatile("" : "+s"(bbv));
-            W::store_o(X, bbv, tile * 32, M, lane, O);
-          }
-        }
+    int io_step = -1000;  // the last step in which this wave stored a tile and loaded the next one (2 x 4 NT2 operations)
+    bf16x8 H[2];
+    auto head = [&]() {  // ring wait, first barrier, G(g - 2) -> registers, second barrier
+      // Own pieces of the entry about to be consumed have landed.  They were issued in step g - (NST - 1); younger than them
+      // (the counter retires in order) are the pieces of NST - 2 later entries and, if a tile boundary fell strictly
+      // between, its stores and loads.
+      cn_vm_wait((NST - 2) * n_mine + ((io_step > g - (NST - 1) && io_step < g) ? 8 * G::NT2 : 0));
+      __builtin_amdgcn_s_barrier();
+      H[0] = *(const bf16x8*)gl;
+      H[1] = *(const bf16x8*)(gl + 1024);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+    for (int i = 0; i < 2; ++i, ++g) {  // B runs two chunks behind A: nothing to multiply yet, the refill is still owed
+      head();
+      RW::issue_all(entry(g + NST - 1));
+    }
+    for (int it = 0; it < max_it; ++it) {
+      const int tile = t_lo + pair + it * NP;
+      const bool valid = tile < t_hi;
+      const int tcur = valid ? tile : tile0;
+      const int tnext = (valid && tile + NP < t_hi && !(ABL & 4)) ? tile + NP : tile0;
+      float* xrow = X + (size_t)tcur * 32 * C + xoff;
+      const float* xnext = X + (size_t)tnext * 32 * C + xoff;
+      const bool in_range = valid && tile * 32 + (lane & 31) < M && (!(ABL & 4) || it == max_it - 1);
+      for (int cb = 0; cb < NCH - 1; ++cb, ++g) {
+        head();
+        RW::template b_step<false>(wl + (g % NST) * SB + RW::F1 * 1024, H, O, entry(g + NST - 1), xrow, xnext, bbl, false);
       }
+      head();
+      RW::template b_step<true>(wl + (g % NST) * SB + RW::F1 * 1024, H, O, entry(g + NST - 1), xrow, xnext, bbl, in_range);
+      io_step = g;
+      ++g;
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring was filled NST - 1 entries past the end
@@ -257,7 +427,7 @@ __global__ __launch_bounds__(2 * NP * 64) void cn_mlp_rs_kernel(const bf16_t* __
 
 template <int C, int NP, int NST, int ABL = 0>
 static int cn_launch_mlp_rs(const bf16_t* Y, const bf16_t* WS, float* X, int M, int n_blocks, hipStream_t s) {
-  constexpr int SMEM = NST * Rc2Geom<C, 1>::STEP_BYTES + NP * 2048;
+  constexpr int SMEM = NST * Rc2Geom<C, 1>::STEP_BYTES + NP * 2048 + C * 4;
   static_assert(SMEM <= 160 * 1024, "ring + hand-over buffers must fit in LDS");
   CN_TRY(cn_configure_lds((const void*)cn_mlp_rs_kernel<C, NP, NST, ABL>, SMEM));
   const int grid = cn_rc2_grid((M + 31) / 32, NP, n_blocks);
