@@ -41,7 +41,7 @@ PEAK_HBM_GBS = 8000.0                        # HBM3E spec (MI355X_MICROARCH.md)
 FUSED_STAGES = (0, 1, 2)                     # pw1 + GELU + pw2 run as ONE kernel (mlp_rc2.h), timed under "pw1_gemm"
 # kernel-name fragments of each profiling class in the committed PMC tables (profiles/*_pmc_*.csv)
 PMC_KERNELS = {
-    "pw1_gemm": ("cn_mlp_rc2_", "EpiBiasActIDF16bLi4"),
+    "pw1_gemm": ("cn_mlp_rc2_", "cn_mlp_rs_", "EpiBiasActIDF16bLi4"),
     "pw2_gemm": ("EpiResid",),
     "dwconv_ln": ("cn_dwconv_ln",),
 }
@@ -93,6 +93,21 @@ def pmc_table(suffix: str):
     return files[-1] if files else None
 
 
+def pmc_is_current(path: str):
+    """True / False: the PMC table was measured on the library that is running now (tools/profile_round.sh writes the
+    library's sha256 next to the tables); None: no record (tables of earlier rounds)."""
+    import hashlib
+    meta = path.rsplit("_pmc_", 1)[0] + "_pmc_meta.json"
+    lib = os.path.join(ROOT, "conette-audio-captioning_amd", "libconette_hip.so")
+    if not os.path.exists(meta) or not os.path.exists(lib):
+        return None
+    try:
+        want = json.load(open(meta)).get("library_sha256")
+    except (OSError, ValueError):
+        return None
+    return hashlib.sha256(open(lib, "rb").read()).hexdigest() == want
+
+
 def pmc_traffic(cls: str, batch: int, launches_per_step: float):
     """HBM bytes per launch of a kernel class from the newest committed rocprofv3 PMC table (separate FETCH_SIZE and
     WRITE_SIZE passes of this benchmark at B = 64, bf16; FETCH_SIZE doubled: gfx950 tallies wide streaming reads at
@@ -119,7 +134,7 @@ def pmc_traffic(cls: str, batch: int, launches_per_step: float):
 
 def pmc_mfma_busy(cls: str):
     """MFMA-busy share of the class's kernels from the newest committed profiles/*_pmc_mfma.csv
-    (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), tools/pmc_summary.py); None when absent."""
+    (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), tools/pmc_mfma_summary.py); None when absent."""
     import csv
     path = pmc_table("pmc_mfma")
     if path is None:
@@ -435,6 +450,11 @@ def main() -> None:
     n_dec = max(1, min(int(os.environ.get("CN_DEC_STREAMS", "2")), 3))
     s_decs = [torch.cuda.Stream(dev, priority=prio) for _ in range(n_dec)]
     n_slot = n_dec + 1
+    from conette_amd.engine import MAX_DECODE_GRAPHS
+    if len(batches) * n_slot > MAX_DECODE_GRAPHS:
+        raise SystemExit(f"bench: {len(batches)} length buckets x {n_slot} pipeline slots = {len(batches) * n_slot} decode keys exceed the "
+                         f"library's {MAX_DECODE_GRAPHS} cached hipGraphs: every decode would run eagerly (~300 launches); raise "
+                         f"CN_BUCKET_SECONDS or lower --batch")
     slots = []
     for k, (w_, lens_, t_) in enumerate(batches):
         for sl in range(n_slot):
@@ -593,11 +613,13 @@ def main() -> None:
                 roof["traffic"] = round(tr)            # HBM bytes per launch (class average), PMC
                 roof["traffic_unit"] = "bytes/launch"
                 roof["traffic_source"] = "profiles/" + src
+                roof["traffic_measured_on_this_build"] = pmc_is_current(os.path.join(ROOT, "profiles", src))
                 roof["algorithmic_bytes_per_launch"] = round(by / launches_per_step)
             mb, src = pmc_mfma_busy(dominant)
             if mb is not None:
                 roof["mfma_busy"] = mb                 # share of SIMD cycles with the matrix pipe busy, PMC
                 roof["mfma_busy_source"] = "profiles/" + src
+                roof["mfma_busy_measured_on_this_build"] = pmc_is_current(os.path.join(ROOT, "profiles", src))
 
     result = None
     if rank == 0:

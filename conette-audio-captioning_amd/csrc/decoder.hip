@@ -1078,7 +1078,7 @@ struct DecGraph {
   hipGraph_t graph;
   int seen;
 };
-#define CN_MAX_DEC_GRAPHS 32
+#define CN_MAX_DEC_GRAPHS 64  // (bucket, pipeline slot) keys: conette_amd.engine sizes its buffer cache from the same number
 struct DecGraphCache {
   DecGraph g[CN_MAX_DEC_GRAPHS];
   int n;
@@ -1198,14 +1198,25 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
   key.B = batch, key.Ta = t_audio, key.beam = beam, key.min_pred = min_pred, key.maxp = max_pred;
   DecGraph* e = nullptr;
   for (int i = 0; i < cache->n; ++i)
-    if (cache->g[i].key == key) e = &cache->g[i];
+    if (cache->g[i].key == key) {  // least recently used first: a hit moves to the back
+      const DecGraph hit = cache->g[i];
+      memmove(&cache->g[i], &cache->g[i + 1], sizeof(DecGraph) * (cache->n - 1 - i));
+      cache->g[cache->n - 1] = hit;
+      e = &cache->g[cache->n - 1];
+      break;
+    }
   if (e && e->exec) {
     CN_HIP(hipGraphLaunch(e->exec, s));
     return CN_OK;
   }
   if (!e) {  // first sighting: run eagerly (also performs the one-time kernel attribute setup)
-    if (cache->n == CN_MAX_DEC_GRAPHS) {  // evict the oldest
+    if (cache->n == CN_MAX_DEC_GRAPHS) {
+      // Evict the least recently used entry.  Its graph may still be executing on another stream (two or three decode
+      // streams replay graphs side by side), and destroying an executable graph under a running launch is undefined: the
+      // device is drained first.  This is the one place an entry point synchronises, and it is off the steady state (more
+      // than CN_MAX_DEC_GRAPHS distinct (shape, buffer) keys alive at once); conette_set_option(DECODE_GRAPH, 0) avoids it.
       if (cache->g[0].exec) {
+        (void)hipDeviceSynchronize();
         (void)hipGraphExecDestroy(cache->g[0].exec);
         (void)hipGraphDestroy(cache->g[0].graph);
       }

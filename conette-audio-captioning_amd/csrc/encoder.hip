@@ -5,6 +5,8 @@
 // with H = time, W = frequency; the residual stream stays fp32, GEMM operands are the context's
 // operand type (bf16 or fp32).  Depthwise 7x7 + LayerNorm run on the VALU, the pointwise and
 // downsample contractions on MFMA through cn_gemm (north_star).
+#include <stddef.h>
+
 #include "ctx.h"
 #include <type_traits>
 
@@ -810,7 +812,8 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
         }
       }
       if (taps && b == 0) CN_TRY(tap_copy(taps->stage_block0[st], xc, (size_t)P * C, s));
-      if (taps) CN_TRY(tap_copy(taps->block[blk], xc, (size_t)P * C, s));
+      if (taps && taps->struct_bytes >= offsetof(conette_encode_taps, block) + (size_t)(blk + 1) * sizeof(float*))
+        CN_TRY(tap_copy(taps->block[blk], xc, (size_t)P * C, s));
     }
     if (taps) CN_TRY(tap_copy(taps->stage[st], xc, (size_t)P * C, s));
   }
@@ -848,6 +851,11 @@ extern "C" int conette_encode(conette_ctx* ctx, const float* wave, int32_t batch
   }
   if (!ctx || !wave || !frame_embs || !workspace || batch <= 0) {
     cn_set_error("encode: bad argument");
+    return CN_ERR_ARG;
+  }
+  if (taps && taps->struct_bytes < offsetof(conette_encode_taps, block)) {
+    cn_set_error("encode: conette_encode_taps.struct_bytes = %zu is smaller than the version-1 members (%zu): set it to "
+                 "sizeof(conette_encode_taps)", taps->struct_bytes, offsetof(conette_encode_taps, block));
     return CN_ERR_ARG;
   }
   const size_t need = conette_encode_workspace_bytes(ctx, batch, n_samples);

@@ -50,8 +50,17 @@ __device__ __forceinline__ void cn_wave_sync() { __builtin_amdgcn_wave_barrier()
 #ifndef FE_NW
 #define FE_NW 16  // waves (= frames in flight) per block
 #endif
-#define FE_FILL_BYTES (16 * 1024)  // dynamic LDS on top of the 117 KB of static arrays: the block owns >= 132 KB of the CU's 160
-#define FE_MEL_LDS_MAX (40 * 1024)  // the band-compact mel matrix lives in that dynamic LDS when it fits (it does: ~16 rows x 224)
+// Static LDS of cn_logmel_kernel (the five arrays below) and the dynamic LDS its launch adds on top: together they are the
+// WHOLE 160 KB of a compute unit (minus < 768 bytes of rounding and alignment slack), so that no workgroup that allocates any LDS at all can
+// start beside a log-mel block -- not "most of them" (round 2 reserved 132.5 KB, which still admitted workgroups of up to
+// 27.5 KB: the register-staged 64 x 96 GEMM tile of gemm.h is 25 KB).  The mechanism of the corruption this avoids is not
+// understood (profiles/r02_notes.md); the exclusion is by allocation, not by timing.
+#define FE_STATIC_BYTES ((512 + 513) * 8 + 1024 * 4 + FE_NW * 8 * FE_PITCH * 8 + FE_NW * 520 * 4)
+#define FE_LDS_TOTAL (160 * 1024)
+#define FE_FILL_BYTES ((FE_LDS_TOTAL - FE_STATIC_BYTES - 256) / 256 * 256)  // (256 bytes of slack for the arrays' alignment padding)
+#define FE_MEL_LDS_MAX FE_FILL_BYTES  // the band-compact mel matrix lives in that dynamic LDS when it fits (it does: ~16 rows x 224)
+static_assert(FE_STATIC_BYTES + FE_FILL_BYTES > FE_LDS_TOTAL - 768 && FE_STATIC_BYTES + FE_FILL_BYTES <= FE_LDS_TOTAL,
+              "the log-mel block must own its compute unit's LDS");
 template <bool MEL_LDS>
 __global__ __launch_bounds__(FE_NW * 64) void cn_logmel_kernel(const float* __restrict__ wave, int L, int F, int total, int mel_rows,
                                                         const float* __restrict__ window,
@@ -65,7 +74,7 @@ __global__ __launch_bounds__(FE_NW * 64) void cn_logmel_kernel(const float* __re
   __shared__ __attribute__((aligned(16))) float s_win[1024];
   __shared__ float2 s_x[FE_NW][8 * FE_PITCH];
   __shared__ float s_p[FE_NW][520];
-  // A block takes a compute unit's LDS for itself (>= 132 KB of 160): nothing that needs an LDS tile can start beside it.
+  // A block takes a compute unit's LDS for itself (all 160 KB): nothing that allocates LDS can start beside it.
   // (Frames came out wrong, a 16-lane quarter of one VALU result at a time, whenever the decoder's small GEMM workgroups
   // shared a CU with this kernel on another stream: profiles/r02_notes.md, tools/pipeline_probe3.py.)
   // (the launch adds >= FE_FILL_BYTES of dynamic LDS; it holds the mel matrix when that fits)
@@ -211,7 +220,7 @@ int cn_frontend(conette_ctx* ctx, const float* wave, int B, int L, float* out, h
   if (grid > ctx->n_cu) grid = ctx->n_cu;  // one block per compute unit (its LDS), each walking its share of the frames
   const int mel_bytes = ctx->mel_rows * CN_N_MELS * 4;
   if (mel_bytes <= FE_MEL_LDS_MAX) {
-    const int dyn = mel_bytes > FE_FILL_BYTES ? mel_bytes : FE_FILL_BYTES;
+    const int dyn = FE_FILL_BYTES;
     CN_TRY(cn_configure_lds((const void*)cn_logmel_kernel<true>, dyn));
     hipLaunchKernelGGL(cn_logmel_kernel<true>, dim3(grid), dim3(FE_NW * 64), dyn, s, wave, L, F, (int)total, ctx->mel_rows,
                        ctx->window, ctx->tw512, ctx->tw1024, ctx->melC, ctx->band, ctx->bn_scale, ctx->bn_shift, out);

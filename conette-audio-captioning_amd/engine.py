@@ -34,6 +34,7 @@ OPT_DECODE_GRAPH = 1
 OPT_DECODE_FUSION = 2
 OPT_ENCODE_RESERVED_CUS = 3
 OPT_FORCING_STEPWISE = 4
+MAX_DECODE_GRAPHS = 64   # CONETTE_MAX_DECODE_GRAPHS: decode hipGraphs (= persistent buffer sets) kept per context
 PROF_CLASSES = ("frontend", "stem", "dwconv_ln", "pw1_gemm", "pw2_gemm", "downsample", "heads", "dec_prepare",
                 "dec_gemm", "dec_attn", "dec_misc", "search")
 
@@ -44,7 +45,7 @@ class ConetteConfigC(C.Structure):
 
 
 class EncodeTapsC(C.Structure):
-    _fields_ = [("logmel", C.c_void_p), ("stem", C.c_void_p), ("stage_block0", C.c_void_p * 4),
+    _fields_ = [("struct_bytes", C.c_size_t), ("logmel", C.c_void_p), ("stem", C.c_void_p), ("stage_block0", C.c_void_p * 4),
                 ("stage", C.c_void_p * 4), ("down", C.c_void_p * 4), ("block", C.c_void_p * 18)]
 
 
@@ -112,7 +113,7 @@ def load_library() -> C.CDLL:
     lib.conette_resample.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.conette_resample_len.restype = C.c_int32
     lib.conette_resample_len.argtypes = [C.c_int32, C.c_int32, C.c_int32]
-    if lib.conette_abi_version() != 1:
+    if lib.conette_abi_version() != 2:
         raise RuntimeError("libconette_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -255,6 +256,7 @@ class Engine:
                 if i > 0:
                     tap_out[f"down{i}"] = e(b, hs[i], ws_[i], dims[i])
             tap_struct = EncodeTapsC()
+            tap_struct.struct_bytes = C.sizeof(EncodeTapsC)
             tap_struct.logmel = tap_out["logmel"].data_ptr()
             tap_struct.stem = tap_out["stem"].data_ptr()
             for i in range(4):
@@ -282,7 +284,9 @@ class Engine:
         """Persistent I/O buffers per shape (and pipeline slot): identical pointers let the library
         replay its hipGraph."""
         key = (b, t, beam, max_pred, s0, trace, slot)
-        buf = self._dec_bufs.get(key)
+        buf = self._dec_bufs.pop(key, None)
+        if buf is not None:
+            self._dec_bufs[key] = buf           # least recently used first: a hit moves to the back
         if buf is None:
             dev = self.device
             ldv = (self.vocab_size + 7) // 8 * 8
@@ -297,7 +301,9 @@ class Engine:
                 "trace_sel": e((max_pred, b, beam, 2), torch.int32) if trace else None,
                 "trace_val": e((max_pred, b, beam), torch.float32) if trace else None,
             }
-            if len(self._dec_bufs) >= 64:
+            if len(self._dec_bufs) >= MAX_DECODE_GRAPHS:
+                # the evicted buffers may still be written by a decode running on another stream: drain before they are freed
+                torch.cuda.synchronize(self.device)
                 self._dec_bufs.pop(next(iter(self._dec_bufs)))
             self._dec_bufs[key] = buf
         return buf

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CONETTE_ABI_VERSION 1
+#define CONETTE_ABI_VERSION 2 /* 2: conette_encode_taps carries its size; CONETTE_PREC_F16X2; conette_decode_graph_nodes */
 
 /* precision of GEMM operands / intermediate activations (accumulation is always fp32,
  * the residual streams are always fp32) */
@@ -54,6 +54,8 @@ typedef struct conette_config {
 /* Optional per-stage outputs of conette_encode for parity tests: fp32, channels-last
  * (B, H, W, C) unless noted; any pointer may be NULL. */
 typedef struct conette_encode_taps {
+  size_t struct_bytes;  /* sizeof(conette_encode_taps) of the CALLER's header: members beyond it are never read, so a caller
+                           built against an older (shorter) layout stays valid when members are appended */
   float* logmel;        /* (B, F, 224)  bn0 output (convnext.py:276-292) */
   float* stem;          /* (B, 252, 56, 96)  downsample_layers[0] output */
   float* stage_block0[4]; /* output of the first block of stage i */
@@ -167,6 +169,9 @@ int conette_set_option(conette_ctx* ctx, int32_t option, int32_t value);
 /* Kernel / copy nodes of the decode hipGraph captured most recently by conette_decode on this context (0: none yet):
  * the launch count of one whole search, for bench.py's decode roofline entry. */
 int32_t conette_decode_graph_nodes(const conette_ctx* ctx);
+/* Decode graphs a context keeps (least recently used evicted beyond it; an eviction drains the device once before the
+ * graph is destroyed).  A caller that cycles through more (shape, buffer) keys than this replays nothing. */
+#define CONETTE_MAX_DECODE_GRAPHS 64
 
 /* Per-kernel-class timing with HIP events recorded on the caller's stream around each launch
  * of the selected classes (bench.py's roofline leg).  While a decoder class is selected, decode

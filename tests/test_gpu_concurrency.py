@@ -55,6 +55,34 @@ def test_frontend_beside_a_decode_is_bit_stable(eng, batch):
         eng.set_decode_fusion(True)
 
 
+def test_every_encoder_tap_beside_decodes_is_bit_stable(eng, batch):
+    """Every intermediate of the encoder (log-mel, stem, the output of each of the 18 blocks, the three downsample layers,
+    frame_embs, clip_probs) alone and while decodes run on two other streams: the front end was the kernel that broke, but
+    the stem, depthwise-conv and MLP kernels share compute units with the same decode kernels."""
+    dev, wave, t, lens, bos = batch
+    nb = 16
+    w16 = wave[:nb].contiguous()
+    fe_ref, clip_ref, taps_ref = eng.encode(w16, taps="blocks")
+    fe64, _ = eng.encode(wave)
+    torch.cuda.synchronize()
+    s_enc = torch.cuda.Stream(dev)
+    s_decs = [torch.cuda.Stream(dev, priority=-1) for _ in range(2)]
+    bad = {}
+    for rnd in range(8):
+        for k, sd in enumerate(s_decs):
+            with torch.cuda.stream(sd):
+                eng.decode(fe64, lens, bos, None, BEAM, MIN_PRED, MAX_PRED, slot=30 + k)
+        with torch.cuda.stream(s_enc):
+            fe, clip, taps = eng.encode(w16, taps="blocks", slot=1)
+        torch.cuda.synchronize()
+        for name, ref in list(taps_ref.items()) + [("frame_embs", fe_ref), ("clip_probs", clip_ref)]:
+            got = fe if name == "frame_embs" else clip if name == "clip_probs" else taps[name]
+            if not torch.equal(got, ref):
+                bad[name] = bad.get(name, 0) + 1
+        del fe, clip, taps
+    assert bad == {}, bad
+
+
 @pytest.mark.parametrize("n_slot", [2, 3])
 def test_pipelined_steps_equal_the_solo_pass(n_slot, eng, batch):
     """bench.py's pipeline (one encode stream, n_slot - 1 decode streams, per-slot buffers): every step's frame embeddings,

@@ -1,3 +1,5 @@
+"""Phase stamps of the depthwise-conv + LN kernel (profiling build only: conette_debug_dwprof).  The fused-MLP phase
+profile lives in the kernel lab (tools/lab/mlp_lab.hip, PROF = 1 instantiation of cn_mlp_rc2_ring_kernel)."""
 import ctypes as C, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import conette_amd
@@ -15,12 +17,3 @@ v = list(buf)[:5]; tot = sum(v)
 names = ["weights", "conv(loads+fma)+lds write", "barrier", "LN phase A", "LN phase B + stores"]
 for n, x in zip(names, v): print(f"{n:28s} {x/1e6:10.1f} Mcycles  {100*x/max(tot,1):5.1f}%")
 
-buf2 = (C.c_ulonglong * 8)()
-pass
-eng.encode(wave); torch.cuda.synchronize()
-pass
-v = list(buf2)[:7]; tot = sum(v); nblk = max(list(buf2)[7], 1)
-names = ["prologue (A frags, stage0)", "wait DMA + barrier", "GEMM1", "epilogue1 (GELU, H write)", "barrier H", "GEMM2", "final epilogue"]
-print("--- fused MLP")
-for n, x in zip(names, v): print(f"{n:28s} {x / nblk * 10:10.1f} ns/block  {100*x/max(tot,1):5.1f}%")
-print(f"per block: {tot / nblk * 10:.0f} ns over {nblk} blocks (profiling build, CN_MLP_DEBUG=C)")
