@@ -11,6 +11,7 @@
 #include <algorithm>
 #include "mlp_rc2.h"
 #include "mlp_rs.h"
+#include "mlp_f8.h"
 #include "down_fused.h"
 
 static thread_local char g_err[512] = "";
@@ -216,7 +217,8 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
     cn_set_error("create: bad argument");
     return CN_ERR_ARG;
   }
-  if (cfg->precision != CONETTE_PREC_F32 && cfg->precision != CONETTE_PREC_BF16 && cfg->precision != CONETTE_PREC_F16X2) {
+  if (cfg->precision != CONETTE_PREC_F32 && cfg->precision != CONETTE_PREC_BF16 && cfg->precision != CONETTE_PREC_F16X2 &&
+      cfg->precision != CONETTE_PREC_FP8) {
     cn_set_error("create: unknown precision %d", cfg->precision);
     return CN_ERR_ARG;
   }
@@ -230,7 +232,8 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
   memset(ctx, 0, sizeof(*ctx));
   ctx->cfg = *cfg;
   ctx->rt = new CnRuntime();
-  ctx->esize = cfg->precision == CONETTE_PREC_BF16 ? 2 : 4;
+  ctx->esize = (cfg->precision == CONETTE_PREC_BF16 || cfg->precision == CONETTE_PREC_FP8) ? 2 : 4;
+  ctx->fp8 = cfg->precision == CONETTE_PREC_FP8 ? 1 : 0;
   ctx->sp16 = cfg->precision == CONETTE_PREC_F16X2 ? 1 : 0;
   {
     int dev = 0, n_cu = 0;
@@ -241,6 +244,7 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
   }
   size_t total = (1 << 20) + (size_t)CN_N_BINS * CN_N_MELS * 4;  // (+ the band-compact mel matrix, at most a dense copy)
   for (int i = 0; i < n_tensors; ++i) total += cn_align((size_t)numel[i] * 4) + 256;
+  if (cfg->precision == CONETTE_PREC_FP8) total += 16u << 20;  // the e4m3 streams of the 15 fused blocks (~8.6 MB)
   ctx->arena_bytes = total;
   hipError_t e = hipMalloc((void**)&ctx->arena, total);
   if (e != hipSuccess) {
@@ -407,6 +411,14 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
         bw.w2 = B.operand(p + "pwconv2.weight", (int64_t)4 * C * C, 0, (int64_t)4 * C * C);
         bw.b2 = B.f32(p + "pwconv2.bias", C);
         bw.mlp_stream = nullptr;
+        bw.mlp_f8 = nullptr;
+        if (ctx->fp8 && C <= 384) {
+          const size_t bytes = C == 96 ? Rc2F8Geom<96>::TOTAL_BYTES : C == 192 ? Rc2F8Geom<192>::TOTAL_BYTES : Rc2F8Geom<384>::TOTAL_BYTES;
+          void* ms = B.alloc(bytes);
+          const float* w1 = B.find(p + "pwconv1.weight", (int64_t)4 * C * C);
+          const float* w2 = B.find(p + "pwconv2.weight", (int64_t)4 * C * C);
+          if (w1 && w2 && bw.b1 && bw.b2 && bw.scale && cn_pack_mlp_f8(w1, bw.b1, w2, bw.b2, bw.scale, C, ms, 0) == CN_OK) bw.mlp_f8 = ms;
+        }
         if (ctx->esize == 2 && C <= 384) {
           const size_t bytes = (size_t)(C / 8) * (C / 8 + 1) * 1024 + (size_t)C * 4;  // Rc2Geom<C, 1>::TOTAL_BYTES
           bf16_t* ms = (bf16_t*)B.alloc(bytes);

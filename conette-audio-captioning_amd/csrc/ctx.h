@@ -28,6 +28,8 @@ struct CnBlockW {
   // bf16, C <= 384: pwconv1 / pwconv2 (+ b1, LayerScale, b2) as the MFMA-fragment stream of mlp_rc2.h:
   // [hidden chunk C/8][fragment C/8 + 1][lane 64][8 bf16] followed by s * b2 (fp32, C)
   const void* mlp_stream;
+  // CONETTE_PREC_FP8, C <= 384: the same block as the e4m3 fragment stream + scales of mlp_f8.h (else nullptr)
+  const void* mlp_f8;
 };
 
 struct CnDownW {
@@ -71,6 +73,7 @@ struct conette_ctx {
   uint32_t prof_mask;
   int dec_unfused;  // CONETTE_OPT_DECODE_FUSION = 0: one launch per sub-layer (the cross-check path of the tests)
   int esize;  // operand element size (2 or 4)
+  int fp8;    // CONETTE_PREC_FP8: bf16 everywhere except the pointwise convolutions of stages 0-2 (e4m3 operands)
   int sp16;   // CONETTE_PREC_F16X2: operands are sp16_t (fp16 hi/lo pairs, 4 bytes)
   // frontend tables
   const float* window;     // [1024]

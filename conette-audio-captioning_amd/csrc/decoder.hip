@@ -1172,7 +1172,7 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
   }
   hipStream_t s = (hipStream_t)stream;
   auto run = [&]() -> int {
-    if (ctx->cfg.precision == CONETTE_PREC_BF16)
+    if (ctx->cfg.precision == CONETTE_PREC_BF16 || ctx->cfg.precision == CONETTE_PREC_FP8)
       return decode_impl<bf16_t>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, beam, min_pred,
                                  max_pred, best_preds, best_lprobs, mult_preds, mult_lprobs, out_sizes, step0_logits,
                                  trace_sel, trace_val, (char*)workspace, s);
@@ -1448,7 +1448,7 @@ extern "C" int conette_forcing(conette_ctx* ctx, const float* frame_embs, const 
   }
   hipStream_t s = (hipStream_t)stream;
   if (!ctx->forcing_stepwise) {  // default: one causal pass over all caption positions
-    if (ctx->cfg.precision == CONETTE_PREC_BF16)
+    if (ctx->cfg.precision == CONETTE_PREC_BF16 || ctx->cfg.precision == CONETTE_PREC_FP8)
       return forcing_prefill_impl<bf16_t>(ctx, frame_embs, frame_lens, caps_in, batch, t_audio, cap_len, logits,
                                           (char*)workspace, s);
     if (ctx->cfg.precision == CONETTE_PREC_F16X2)
@@ -1464,7 +1464,7 @@ extern "C" int conette_forcing(conette_ctx* ctx, const float* frame_embs, const 
   int32_t* sizes = (int32_t*)tail;
   int32_t* bos = sizes + 2;  // init kernel input; any valid ids: column 0 of the captions
   (void)bos;
-  if (ctx->cfg.precision == CONETTE_PREC_BF16)
+  if (ctx->cfg.precision == CONETTE_PREC_BF16 || ctx->cfg.precision == CONETTE_PREC_FP8)
     return decode_impl<bf16_t>(ctx, frame_embs, frame_lens, caps_in, nullptr, batch, t_audio, 1, 0, cap_len, mult_preds,
                                mult_lprobs, mult_preds, mult_lprobs, sizes, nullptr, nullptr, nullptr, (char*)workspace, s,
                                caps_in, logits);
@@ -1505,7 +1505,7 @@ extern "C" int conette_greedy(conette_ctx* ctx, const float* frame_embs, const i
   int32_t* mult_preds = (int32_t*)tail;  // beam 1: the single hypothesis of every clip
   float* mult_lprobs = (float*)(tail + cn_align((size_t)batch * max_pred * 4));
   float* best_lprobs = (float*)(tail + cn_align((size_t)batch * max_pred * 4) + cn_align((size_t)batch * 4));
-  if (ctx->cfg.precision == CONETTE_PREC_BF16)
+  if (ctx->cfg.precision == CONETTE_PREC_BF16 || ctx->cfg.precision == CONETTE_PREC_FP8)
     return decode_impl<bf16_t>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, 1, min_pred, max_pred, preds,
                                best_lprobs, mult_preds, mult_lprobs, out_sizes, nullptr, nullptr, nullptr, (char*)workspace,
                                s, nullptr, nullptr, logits);

@@ -13,6 +13,7 @@
 #include "gemm2.h"
 #include "mlp_rc2.h"
 #include "mlp_rs.h"
+#include "mlp_f8.h"
 #include "down_fused.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -778,12 +779,23 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
     }
     for (int b = 0; b < CN_DEPTHS[st]; ++b, ++blk) {
       const CnBlockW& bw = ctx->blocks[blk];
+      const bool f8 = std::is_same<T, bf16_t>::value && ctx->fp8 && bw.mlp_f8 != nullptr && C <= 384;
       {
         CnProfScope ps(ctx, CONETTE_PROF_DWCONV_LN, s);
-        CN_TRY(dwconv_dispatch<T>(C, xc, B, H, W, bw, y, s));
+        if (f8) CN_TRY(dwconv_dispatch<f8_t>(C, xc, B, H, W, bw, (f8_t*)ws.y, s));  // y as e4m3 (scale 1)
+        else CN_TRY(dwconv_dispatch<T>(C, xc, B, H, W, bw, y, s));
       }
       bool fused = false;
-      if constexpr (std::is_same<T, bf16_t>::value) {
+      if (f8) {  // CONETTE_PREC_FP8: pw1 + GELU + pw2 + residual with e4m3 operands (mlp_f8.h)
+        CnProfScope ps(ctx, CONETTE_PROF_PW1_GEMM, s);
+        const unsigned char* y8 = (const unsigned char*)ws.y;
+        const int nb = ctx->n_cu - ctx->enc_reserved_cus;
+        if (C == 96) CN_TRY((cn_launch_mlp_f8_resident<96, 12>(y8, bw.mlp_f8, xc, (int)P, nb, s)));
+        else if (C == 192) CN_TRY((cn_launch_mlp_f8_ring<192, 8, 5>(y8, bw.mlp_f8, xc, (int)P, nb, s)));
+        else CN_TRY((cn_launch_mlp_f8_ring<384, 4, 4>(y8, bw.mlp_f8, xc, (int)P, nb, s)));
+        fused = true;
+      }
+      if constexpr (std::is_same<T, bf16_t>::value) if (!fused) {
         // stages 0-2: register-chained fused MLP (mlp_rc2.h): the 4C hidden never leaves the registers; timed under PW1
         if (bw.mlp_stream != nullptr && C <= 384) {
           CnProfScope ps(ctx, CONETTE_PROF_PW1_GEMM, s);
@@ -863,7 +875,7 @@ extern "C" int conette_encode(conette_ctx* ctx, const float* wave, int32_t batch
     cn_set_error("encode: workspace %zu < %zu", workspace_bytes, need);
     return CN_ERR_WORKSPACE;
   }
-  if (ctx->cfg.precision == CONETTE_PREC_BF16)
+  if (ctx->cfg.precision == CONETTE_PREC_BF16 || ctx->cfg.precision == CONETTE_PREC_FP8)
     return encode_impl<bf16_t>(ctx, wave, batch, n_samples, frame_embs, clip_probs, taps, (char*)workspace,
                                (hipStream_t)stream);
   if (ctx->cfg.precision == CONETTE_PREC_F16X2)

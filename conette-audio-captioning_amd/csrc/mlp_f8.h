@@ -1,5 +1,8 @@
-// EXPERIMENT (kernel lab only, not part of the library): see profiles/r02_notes.md "FP8 operands".
-// Register-chained fused ConvNeXt MLP with FP8 (OCP e4m3) operands -- the precision = fp8 variant of mlp_rc2.h:
+// Register-chained fused ConvNeXt MLP with FP8 (OCP e4m3) operands -- CONETTE_PREC_FP8's variant of mlp_rc2.h for the
+// pointwise convolutions of stages 0-2 (BASELINE.json configs[4]: "fp8 MFMA pointwise GEMMs"; everything else of that
+// precision runs the bf16 kernels).  Accuracy: 4.5-4.8 % of a block's mean |update| off the bf16 kernel per block (lab,
+// profiles/r02_notes.md "FP8 operands"); tests/test_gpu_fp8.py pins it against oracle/fp8_ref.py, which quantises at the
+// same points.
 //
 //     x[m][:] += scale * ( W2 . gelu( W1 . y[m][:] + b1 ) + b2 )          (convnext.py:66-74)
 //

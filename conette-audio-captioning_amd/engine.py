@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libconette_hip.so")
 PREC_F32 = 0
 PREC_BF16 = 1
 PREC_F16X2 = 2   # "exact": fp16 hi/lo operand pairs, three MFMAs per product (include/conette_hip.h)
+PREC_FP8 = 3     # bf16 mode with the stage 0-2 pointwise convolutions on fp8 (e4m3) MFMAs
 N_MELS = 224
 FEAT = 768
 N_TAGS = 527
@@ -172,8 +173,8 @@ class Engine:
             raise RuntimeError("conette_amd.Engine needs a ROCm GPU (no CPU fallback)")
         self.lib = load_library()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.precision = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "exact": PREC_F16X2, "f16x2": PREC_F16X2}[precision]
-        self.precision_name = {PREC_BF16: "bf16", PREC_F32: "fp32", PREC_F16X2: "exact"}[self.precision]
+        self.precision = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "exact": PREC_F16X2, "f16x2": PREC_F16X2, "fp8": PREC_FP8}[precision]
+        self.precision_name = {PREC_BF16: "bf16", PREC_F32: "fp32", PREC_F16X2: "exact", PREC_FP8: "fp8"}[self.precision]
         vocab = int(state_dict["model.decoder.classifier.weight"].shape[0])
         self.vocab_size = vocab
         self.d_model, self.nhead, self.n_layers, self.d_ff = d_model, nhead, n_layers, d_ff

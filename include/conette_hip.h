@@ -34,6 +34,10 @@ extern "C" {
                                 v_mfma_f32_16x16x32_f16 (hi.hi + hi.lo + lo.hi): fp32-MFMA accuracy at MFMA-f16 rate,
                                 exact-erf GELU; token ids equal the fp32 mode's / the reference's */
 
+#define CONETTE_PREC_FP8 3 /* BASELINE.json configs[4]: bf16 mode with the pointwise convolutions of ConvNeXt stages 0-2 on
+                              v_mfma_f32_32x32x16_fp8_fp8 (OCP e4m3 operands, per-tensor / per-output-channel scales,
+                              fp32 accumulation and residual stream); ~5 % of a block's update off the bf16 mode per block */
+
 typedef struct conette_ctx conette_ctx; /* opaque: packed weights + constant tables */
 
 /* Hyper-parameters; mirrors CoNeTTEConfig (huggingface/config.py:13-88) + tokenizer ids

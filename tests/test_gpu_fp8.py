@@ -1,0 +1,77 @@
+"""GPU: CONETTE_PREC_FP8 (BASELINE.json configs[4]: "fp8 MFMA pointwise GEMMs") -- the bf16 mode with the pointwise
+convolutions of ConvNeXt stages 0-2 on e4m3 MFMAs (csrc/mlp_f8.h).
+
+Tolerance line of this precision:
+  * every fp8 block (blocks 0-14), on the GPU's own input of that block, against oracle/fp8_ref.py (same quantisation points):
+    |err| <= 2e-3 + 2e-3 |ref| for all but 4e-3 of the elements (a y value whose LayerNorm straddles an e4m3 rounding
+    boundary moves every output of its position by ~5e-3: about 1e-3 of the positions), mean |err| < 2e-4;
+  * the blocks it does not touch (stage 3) and the downsample layers stay on the bf16 kernels: pinned against the bf16 oracle
+    like in bf16 mode;
+  * end to end it is a LOSSY mode: frame embeddings within 0.25 of the reference fixture's (measured max 0.13; bf16: 0.014),
+    relative rms error < 6 % (measured 4.3 %; bf16: 0.44 %); token ids are not expected to equal the reference's (bench.py's
+    parity block reports the agreement)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng_fp8(synth_weights):
+    from conette_amd.engine import Engine
+    return Engine(synth_weights, precision="fp8")
+
+
+def _wave(g):
+    from conette_amd import synth
+    n = [int(v) for v in g["lengths"]]
+    return torch.from_numpy(synth.synth_waveforms(len(n), max(n), int(g["seed0"]), lengths=n))
+
+
+def _nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def test_every_fp8_block_against_the_fp8_operand_oracle(eng_fp8, synth_weights):
+    from oracle import bf16_ref as Bf
+    from oracle import fp8_ref as F8
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    g = G.load("b3_mixed_beam3_none")
+    fe, clip, taps = eng_fp8.encode(_wave(g).cuda(), taps="blocks")
+    torch.cuda.synchronize()
+    worst = {}
+    blk = 0
+    for st, depth in enumerate((3, 3, 9, 3)):
+        for b in range(depth):
+            src = taps["stem"] if blk == 0 else (taps[f"down{st}"] if b == 0 else taps[f"block{blk - 1}"])
+            got = _nchw(taps[f"block{blk}"])
+            with torch.no_grad():
+                if st < 3:
+                    ref = F8.convnext_block_fp8(synth_weights, Bf.block_prefix(blk), _nchw(src))
+                else:
+                    ref = Bf.convnext_block_bf16(synth_weights, Bf.block_prefix(blk), _nchw(src), folded=False)
+            err = (got - ref).abs()
+            bound = 2e-3 + 2e-3 * ref.abs()
+            share = float((err > bound).float().mean())
+            worst[blk] = (round(float(err.max()), 4), round(float(err.mean()), 7), round(share, 6))
+            assert share <= (4e-3 if st < 3 else 1e-5), (blk, worst[blk])
+            assert float(err.mean()) < 2e-4, (blk, worst[blk])
+            assert torch.isfinite(got).all()
+            blk += 1
+    print("fp8: max / mean |err| / share beyond tolerance per block:", worst)
+
+
+def test_fp8_end_to_end_stays_near_the_reference(eng_fp8):
+    g = G.load("b8_10s_beam3_all")
+    fe, clip = eng_fp8.encode(_wave(g).cuda())
+    ref = torch.from_numpy(g["frame_embs"])
+    err = fe.cpu() - ref
+    rel = float(err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    print("fp8 frame_embs: max |err|", float(err.abs().max()), "relative rms", rel)
+    assert float(err.abs().max()) < 0.25 and rel < 0.06
+    np.testing.assert_allclose(clip.cpu().numpy(), g["tags_probs"], atol=0.08)

@@ -11,7 +11,7 @@
 #include <algorithm>
 
 #include "mlp_rc2.h"
-#include "mlp_rc2_f8.h"
+#include "mlp_f8.h"
 #include "mlp_rc2_skew.h"
 #include "mlp_rs.h"
 
