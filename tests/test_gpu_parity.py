@@ -58,6 +58,12 @@ def test_encode_matches_reference_fixture(name, prec, engines):
         if prec == "bf16":  # the bulk must be much closer than the worst element
             assert float(np.abs(got - g["sub_" + k]).mean()) < 0.02, k
     np.testing.assert_allclose(fe.cpu().numpy(), g["frame_embs"], rtol=rtol, atol=atol if prec in EXACT else 0.06)
+    # accumulated drift of the whole encoder (18 blocks + 3 downsample layers) in relative-rms terms: the element-wise bounds
+    # above are worst cases; this is the number the id agreement depends on (bench.py reports it next to the agreement:
+    # 4.4e-3 in bf16 with 72 % of the beam-3 captions identical, 1e-6 in the exact modes with 100 %)
+    ref_fe = torch.from_numpy(g["frame_embs"])
+    rel = float((fe.cpu() - ref_fe).pow(2).mean().sqrt() / ref_fe.pow(2).mean().sqrt())
+    assert rel < (1e-5 if prec in EXACT else 8e-3), (name, prec, rel)
     np.testing.assert_allclose(clip.cpu().numpy(), g["tags_probs"], rtol=rtol, atol=1e-4 if prec in EXACT else 0.03)
 
 

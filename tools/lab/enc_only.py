@@ -1,4 +1,4 @@
-"""Encoder alone (no decode beside it), for a kernel trace: python tools/lab/enc_only.py [passes] [reserved_cus]"""
+"""Encoder alone (no decode beside it), for a kernel trace: python tools/lab/enc_only.py [passes] [reserved_cus] [precision]"""
 import os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import conette_amd
@@ -6,7 +6,7 @@ from conette_amd import synth
 from conette_amd.engine import Engine
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict().items()}
-eng = Engine(sd, precision="bf16")
+eng = Engine(sd, precision=sys.argv[3] if len(sys.argv) > 3 else "bf16")
 eng.set_encode_reserved_cus(int(sys.argv[2]) if len(sys.argv) > 2 else 24)
 wave = torch.from_numpy(synth.synth_waveforms(64, 320000, 1234)).cuda()
 fe = eng.decode_input_buffer(64, eng.lib.conette_num_audio_frames(320000), 3, 20, slot=0)
