@@ -447,7 +447,8 @@ def main() -> None:
     # CN_DEC_STREAMS decode chains in flight (default 2): a decode is a serial chain of ~300 latency-bound launches that
     # stretches to the length of an encode when it shares the chip with one; with two chains (batches i-1 and i-2 decode
     # while batch i encodes) a chain may take two steps, and the step is bounded by the encoder again.
-    n_dec = max(1, min(int(os.environ.get("CN_DEC_STREAMS", "2")), 3))
+    # (the exact precision's decode is the one-launch-per-sub-layer path, 12 ms alone at B = 64: three chains in flight)
+    n_dec = max(1, min(int(os.environ.get("CN_DEC_STREAMS", "3" if args.precision == "exact" else "2")), 3))
     s_decs = [torch.cuda.Stream(dev, priority=prio) for _ in range(n_dec)]
     n_slot = n_dec + 1
     from conette_amd.engine import MAX_DECODE_GRAPHS

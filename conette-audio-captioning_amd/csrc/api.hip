@@ -12,6 +12,7 @@
 #include "mlp_rc2.h"
 #include "mlp_rs.h"
 #include "mlp_f8.h"
+#include "mlp_sp.h"
 #include "down_fused.h"
 
 static thread_local char g_err[512] = "";
@@ -244,7 +245,8 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
   }
   size_t total = (1 << 20) + (size_t)CN_N_BINS * CN_N_MELS * 4;  // (+ the band-compact mel matrix, at most a dense copy)
   for (int i = 0; i < n_tensors; ++i) total += cn_align((size_t)numel[i] * 4) + 256;
-  if (cfg->precision == CONETTE_PREC_FP8) total += 16u << 20;  // the e4m3 streams of the 15 fused blocks (~8.6 MB)
+  if (cfg->precision == CONETTE_PREC_FP8) total += 16u << 20;
+  if (cfg->precision == CONETTE_PREC_F16X2) total += 8u << 20;   // the fp16 hi / lo streams of the 6 fused blocks (~3.4 MB)  // the e4m3 streams of the 15 fused blocks (~8.6 MB)
   ctx->arena_bytes = total;
   hipError_t e = hipMalloc((void**)&ctx->arena, total);
   if (e != hipSuccess) {
@@ -412,6 +414,13 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
         bw.b2 = B.f32(p + "pwconv2.bias", C);
         bw.mlp_stream = nullptr;
         bw.mlp_f8 = nullptr;
+        bw.mlp_sp = nullptr;
+        if (ctx->sp16 && C <= 192) {
+          void* ms = B.alloc(C == 96 ? SpGeom<96>::TOTAL_BYTES : SpGeom<192>::TOTAL_BYTES);
+          const float* w1 = B.find(p + "pwconv1.weight", (int64_t)4 * C * C);
+          const float* w2 = B.find(p + "pwconv2.weight", (int64_t)4 * C * C);
+          if (w1 && w2 && bw.b1 && bw.b2 && bw.scale && cn_pack_mlp_sp(w1, bw.b1, w2, bw.b2, bw.scale, C, ms, 0) == CN_OK) bw.mlp_sp = ms;
+        }
         if (ctx->fp8 && C <= 384) {
           const size_t bytes = C == 96 ? Rc2F8Geom<96>::TOTAL_BYTES : C == 192 ? Rc2F8Geom<192>::TOTAL_BYTES : Rc2F8Geom<384>::TOTAL_BYTES;
           void* ms = B.alloc(bytes);

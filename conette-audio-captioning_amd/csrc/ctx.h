@@ -30,6 +30,8 @@ struct CnBlockW {
   const void* mlp_stream;
   // CONETTE_PREC_FP8, C <= 384: the same block as the e4m3 fragment stream + scales of mlp_f8.h (else nullptr)
   const void* mlp_f8;
+  // CONETTE_PREC_F16X2, C <= 192: the block as the fp16 hi / lo fragment stream of mlp_sp.h (else nullptr)
+  const void* mlp_sp;
 };
 
 struct CnDownW {

@@ -14,6 +14,7 @@
 #include "mlp_rc2.h"
 #include "mlp_rs.h"
 #include "mlp_f8.h"
+#include "mlp_sp.h"
 #include "down_fused.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -648,6 +649,11 @@ __global__ __launch_bounds__(256) void cn_clip_pool_ln_kernel(const float* __res
 // ---------------------------------------------------------------------------------------------
 // orchestration
 // ---------------------------------------------------------------------------------------------
+#ifndef CN_SP_NW96
+#define CN_SP_NW96 12  // waves per block / ring depth of the exact-precision fused MLP at C = 96
+#define CN_SP_NST96 4
+#endif
+
 struct EncGeom {
   int F, H[4], W[4];
 };
@@ -794,6 +800,16 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
         else if (C == 192) CN_TRY((cn_launch_mlp_f8_ring<192, 8, 5>(y8, bw.mlp_f8, xc, (int)P, nb, s)));
         else CN_TRY((cn_launch_mlp_f8_ring<384, 4, 4>(y8, bw.mlp_f8, xc, (int)P, nb, s)));
         fused = true;
+      }
+      if constexpr (std::is_same<T, sp16_t>::value) {
+        // exact precision, stages 0-1: the same fused block with fp16 hi / lo operand pairs (mlp_sp.h); timed under PW1
+        if (bw.mlp_sp != nullptr && C <= 192) {
+          CnProfScope ps(ctx, CONETTE_PROF_PW1_GEMM, s);
+          const int nb = ctx->n_cu - ctx->enc_reserved_cus;
+          if (C == 96) CN_TRY((cn_launch_mlp_sp_ring<96, CN_SP_NW96, CN_SP_NST96>(y, bw.mlp_sp, xc, (int)P, nb, s)));
+          else CN_TRY((cn_launch_mlp_sp_ring<192, 8, 3>(y, bw.mlp_sp, xc, (int)P, nb, s)));
+          fused = true;
+        }
       }
       if constexpr (std::is_same<T, bf16_t>::value) if (!fused) {
         // stages 0-2: register-chained fused MLP (mlp_rc2.h): the 4C hidden never leaves the registers; timed under PW1
