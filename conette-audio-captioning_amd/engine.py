@@ -173,12 +173,15 @@ class Engine:
             raise RuntimeError("conette_amd.Engine needs a ROCm GPU (no CPU fallback)")
         self.lib = load_library()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.precision = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "exact": PREC_F16X2, "f16x2": PREC_F16X2, "fp8": PREC_FP8}[precision]
-        self.precision_name = {PREC_BF16: "bf16", PREC_F32: "fp32", PREC_F16X2: "exact", PREC_FP8: "fp8"}[self.precision]
+        table = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "exact": PREC_F16X2, "f16x2": PREC_F16X2, "fp8": PREC_FP8}
+        if precision == "mixed":     # bf16 encoder + exact (fp16 hi/lo pairs) decoder
+            self.precision, self.precision_dec = PREC_BF16, PREC_F16X2
+        else:
+            self.precision = self.precision_dec = table[precision]
+        self.precision_name = "mixed" if precision == "mixed" else {PREC_BF16: "bf16", PREC_F32: "fp32", PREC_F16X2: "exact", PREC_FP8: "fp8"}[self.precision]
         vocab = int(state_dict["model.decoder.classifier.weight"].shape[0])
         self.vocab_size = vocab
         self.d_model, self.nhead, self.n_layers, self.d_ff = d_model, nhead, n_layers, d_ff
-        cfg = ConetteConfigC(self.precision, vocab, d_model, nhead, n_layers, d_ff, pad_id, bos_id, eos_id)
         keep, names, ptrs, numel = [], [], [], []
         with torch.cuda.device(self.device):
             for k, v in state_dict.items():
@@ -194,25 +197,34 @@ class Engine:
                 ptrs.append(v.data_ptr())
                 numel.append(v.numel())
             n = len(names)
-            handle = C.c_void_p()
-            torch.cuda.synchronize(self.device)
-            st = self.lib.conette_create(C.byref(cfg), n, (C.c_char_p * n)(*names), (C.c_void_p * n)(*ptrs),
-                                         (C.c_int64 * n)(*numel), C.byref(handle))
-            _check(st, "conette_create")
-            torch.cuda.synchronize(self.device)
-        self._ctx = handle
+
+            def create(prec: int) -> C.c_void_p:
+                cfg = ConetteConfigC(prec, vocab, d_model, nhead, n_layers, d_ff, pad_id, bos_id, eos_id)
+                handle = C.c_void_p()
+                torch.cuda.synchronize(self.device)
+                st = self.lib.conette_create(C.byref(cfg), n, (C.c_char_p * n)(*names), (C.c_void_p * n)(*ptrs),
+                                             (C.c_int64 * n)(*numel), C.byref(handle))
+                _check(st, "conette_create")
+                torch.cuda.synchronize(self.device)
+                return handle
+
+            self._ctx = create(self.precision)
+            # "mixed": frame_embs (B, T, 768) fp32 is the interface between the two halves of the path, so the encoder and the
+            # decoder may run at different precisions -- here the bf16 encoder (the throughput mode's) feeds an exact decoder
+            self._ctx_dec = create(self.precision_dec) if self.precision_dec != self.precision else self._ctx
         self._ws: Dict[str, torch.Tensor] = {}
         self._dec_bufs: Dict[Any, Dict[str, Any]] = {}
         del keep
 
     def __del__(self) -> None:
-        ctx = getattr(self, "_ctx", None)
-        if ctx:
-            try:
-                self.lib.conette_destroy(ctx)
-            except Exception:
-                pass
-            self._ctx = None
+        ctx, ctx_dec = getattr(self, "_ctx", None), getattr(self, "_ctx_dec", None)
+        for c in ([ctx] if ctx_dec is ctx else [ctx, ctx_dec]):
+            if c:
+                try:
+                    self.lib.conette_destroy(c)
+                except Exception:
+                    pass
+        self._ctx = self._ctx_dec = None
 
     def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
         ws = self._ws.get(key)
@@ -328,9 +340,9 @@ class Engine:
                 raise ValueError("forbid_mask must have vocab_size entries")
             buf["forbid"].copy_(forbid_mask.to(torch.uint8), non_blocking=True)
             forbid_ptr = buf["forbid"]
-        need = self.lib.conette_decode_workspace_bytes(self._ctx, b, t, beam, max_pred)
+        need = self.lib.conette_decode_workspace_bytes(self._ctx_dec, b, t, beam, max_pred)
         wsb = self._workspace("dec" if slot == 0 else f"dec{slot}", need)  # per slot: decodes of different slots may run on different streams
-        st = self.lib.conette_decode(self._ctx, _ptr(buf["fe"]), _ptr(buf["lens"]), _ptr(buf["bos"]), _ptr(forbid_ptr),
+        st = self.lib.conette_decode(self._ctx_dec, _ptr(buf["fe"]), _ptr(buf["lens"]), _ptr(buf["bos"]), _ptr(forbid_ptr),
                                      b, t, beam, min_pred, max_pred, _ptr(buf["best_preds"]), _ptr(buf["best_lprobs"]),
                                      _ptr(buf["mult_preds"]), _ptr(buf["mult_lprobs"]), _ptr(buf["sizes"]),
                                      _ptr(buf["step0"]), _ptr(buf["trace_sel"]), _ptr(buf["trace_val"]), _ptr(wsb),
@@ -354,9 +366,9 @@ class Engine:
         lens = frame_lens.to(self.device, torch.int32).contiguous()
         caps = caps_in.to(self.device, torch.int32).contiguous()
         out = torch.empty((b, cap_len, self.vocab_size), dtype=torch.float32, device=self.device)
-        need = self.lib.conette_forcing_workspace_bytes(self._ctx, b, t, cap_len)
+        need = self.lib.conette_forcing_workspace_bytes(self._ctx_dec, b, t, cap_len)
         wsb = self._workspace("dec", need)
-        st = self.lib.conette_forcing(self._ctx, _ptr(fe), _ptr(lens), _ptr(caps), b, t, cap_len, _ptr(out), _ptr(wsb),
+        st = self.lib.conette_forcing(self._ctx_dec, _ptr(fe), _ptr(lens), _ptr(caps), b, t, cap_len, _ptr(out), _ptr(wsb),
                                       wsb.numel(), _stream())
         _check(st, "conette_forcing")
         return out
@@ -372,9 +384,9 @@ class Engine:
         logits = torch.empty((b, max_pred, self.vocab_size), dtype=torch.float32, device=self.device)
         preds = torch.empty((b, max_pred), dtype=torch.int32, device=self.device)
         sizes = torch.zeros((2,), dtype=torch.int32, device=self.device)
-        need = self.lib.conette_greedy_workspace_bytes(self._ctx, b, t, max_pred)
+        need = self.lib.conette_greedy_workspace_bytes(self._ctx_dec, b, t, max_pred)
         wsb = self._workspace("dec", need)
-        st = self.lib.conette_greedy(self._ctx, _ptr(fe), _ptr(lens), _ptr(bos), _ptr(fm), b, t, int(min_pred), int(max_pred),
+        st = self.lib.conette_greedy(self._ctx_dec, _ptr(fe), _ptr(lens), _ptr(bos), _ptr(fm), b, t, int(min_pred), int(max_pred),
                                      _ptr(logits), _ptr(preds), _ptr(sizes), _ptr(wsb), wsb.numel(), _stream())
         _check(st, "conette_greedy")
         ps = int(sizes[0].item())
@@ -386,15 +398,15 @@ class Engine:
 
     # ---- options / profiling ------------------------------------------------------------------
     def set_decode_graph(self, enabled: bool) -> None:
-        _check(self.lib.conette_set_option(self._ctx, OPT_DECODE_GRAPH, int(bool(enabled))), "set_option")
+        _check(self.lib.conette_set_option(self._ctx_dec, OPT_DECODE_GRAPH, int(bool(enabled))), "set_option")
 
     def set_decode_fusion(self, enabled: bool) -> None:
         """bf16: fused decoder-layer kernels (default) or one launch per sub-layer (cross-check path)."""
-        _check(self.lib.conette_set_option(self._ctx, OPT_DECODE_FUSION, int(bool(enabled))), "set_option")
+        _check(self.lib.conette_set_option(self._ctx_dec, OPT_DECODE_FUSION, int(bool(enabled))), "set_option")
 
     def set_forcing_stepwise(self, enabled: bool) -> None:
         """Teacher forcing through the KV-cached step kernels (cross-check) instead of the one-pass kernels (default)."""
-        _check(self.lib.conette_set_option(self._ctx, OPT_FORCING_STEPWISE, int(bool(enabled))), "set_option")
+        _check(self.lib.conette_set_option(self._ctx_dec, OPT_FORCING_STEPWISE, int(bool(enabled))), "set_option")
 
     def set_encode_reserved_cus(self, n: int) -> None:
         """Compute units the encoder's persistent kernels leave free for a decode running on another stream."""
@@ -402,7 +414,7 @@ class Engine:
 
     def decode_graph_nodes(self) -> int:
         """Kernel / copy nodes of the most recently captured decode hipGraph (0 before the first capture)."""
-        return int(self.lib.conette_decode_graph_nodes(self._ctx))
+        return int(self.lib.conette_decode_graph_nodes(self._ctx_dec))
 
     def profile_enable(self, classes=()) -> None:
         mask = 0
