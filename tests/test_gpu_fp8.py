@@ -75,3 +75,15 @@ def test_fp8_end_to_end_stays_near_the_reference(eng_fp8):
     print("fp8 frame_embs: max |err|", float(err.abs().max()), "relative rms", rel)
     assert float(err.abs().max()) < 0.25 and rel < 0.06
     np.testing.assert_allclose(clip.cpu().numpy(), g["tags_probs"], atol=0.08)
+
+
+def test_fp8_is_batch_invariant(eng_fp8):
+    """8 copies of the fixture batch (B = 64, the benchmark's shape): every copy reproduces copy 0 bit for bit (persistent
+    kernels walk many tiles per wave; tiles straddle clip boundaries at stages 1-2)."""
+    g = G.load("b8_10s_beam3_all")
+    w8 = _wave(g)
+    fe, clip = eng_fp8.encode(w8.repeat(8, 1).cuda())
+    fe8, clip8 = eng_fp8.encode(w8.cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(fe.view(8, 8, *fe.shape[1:]), fe8[None].expand(8, *fe8.shape))
+    assert torch.equal(clip.view(8, 8, -1), clip8[None].expand(8, *clip8.shape))
