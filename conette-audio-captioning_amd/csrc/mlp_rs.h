@@ -357,12 +357,12 @@ __global__ __launch_bounds__(2 * NP * 64) void cn_mlp_rs_kernel(const bf16_t* __
     auto step2 = [&](auto reload_tag, const bf16_t* ynext) {  // two steps: the roles of the two X accumulators swap
       constexpr bool RELOAD = decltype(reload_tag)::value;
       __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_barrier();
+      if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
       RW::template a_step<false>(wl + (g % NST) * SB, fy, ones, Xb, Xa, gl, ynext);  // GEMM1(g) -> Xa, GELU of Xb (chunk g - 1) -> G
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       ++g;
       __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_barrier();
+      if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
       RW::template a_step<RELOAD>(wl + (g % NST) * SB, fy, ones, Xa, Xb, gl, ynext);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       ++g;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(2 * NP * 64) void cn_mlp_rs_kernel(const bf16_t* __
       H[0] = *(const bf16x8*)gl;
       H[1] = *(const bf16x8*)(gl + 1024);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();  // (32: lab ablation, racy: what the second barrier costs)
     };
     for (int i = 0; i < 2; ++i, ++g) {  // B runs two chunks behind A: nothing to multiply yet, the refill is still owed
       head();

@@ -28,16 +28,24 @@ def model_fp32(model_dir):
 
 
 @pytest.fixture(scope="module")
+def model_exact(model_dir):
+    from conette_amd import CoNeTTEModel
+    return CoNeTTEModel.from_pretrained(model_dir, precision="exact", offline=True, audioset_idx_to_name=TAGS)
+
+
+@pytest.fixture(scope="module")
 def model_bf16(model_dir):
     from conette_amd import CoNeTTEModel
     return CoNeTTEModel.from_pretrained(model_dir, precision="bf16", offline=True, audioset_idx_to_name=TAGS)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "exact"])
 @pytest.mark.parametrize("name", G.SCENARIOS)
-def test_model_forward_matches_reference_fixture(name, model_fp32):
+def test_model_forward_matches_reference_fixture(name, prec, model_fp32, model_exact):
+    """the whole operator API in both precisions whose ids must equal the reference's: fp32 MFMA and "exact" (fp16 hi / lo pairs)"""
     g = G.load(name)
     x, kw = G.inputs(g)
-    out = model_fp32(x, sr=32000, **kw)
+    out = (model_fp32 if prec == "fp32" else model_exact)(x, sr=32000, **kw)
     assert out["preds"].dtype == torch.long and out["mult_preds"].dtype == torch.long
     assert out["preds"].cpu().tolist() == g["preds"].tolist()
     assert out["mult_preds"].cpu().tolist() == g["mult_preds"].tolist()

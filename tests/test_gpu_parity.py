@@ -430,5 +430,8 @@ def test_encode_short_and_odd_lengths(engines):
         f16, c16 = engines["bf16"].encode(wave)
         assert f32.shape == f16.shape and f32.shape[1] == engines["fp32"].lib.conette_num_audio_frames(L)
         assert torch.isfinite(f32).all() and torch.isfinite(f16).all()
+        fx, cx = engines["exact"].encode(wave)   # (ragged tiles of the fused hi / lo blocks and the split GEMMs)
+        np.testing.assert_allclose(fx.cpu().numpy(), f32.cpu().numpy(), rtol=1e-3, atol=2e-4)
+        np.testing.assert_allclose(cx.cpu().numpy(), c32.cpu().numpy(), rtol=1e-3, atol=1e-4)
         np.testing.assert_allclose(f16.float().cpu().numpy(), f32.cpu().numpy(), atol=0.1, rtol=0.1)
         np.testing.assert_allclose(c16.cpu().numpy(), c32.cpu().numpy(), atol=0.05)

@@ -140,6 +140,8 @@ template <> std::vector<Variant> variants<384>() {
        [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 8>(Y, WS, X, M, nb, s); }, 4},
       {"rs<384> prio A",
        [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 16>(Y, WS, X, M, nb, s); }, 4},
+      {"ABL rs<384> one barrier per step (racy)",
+       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 32>(Y, WS, X, M, nb, s); }, 4},
       {"ABL rs<384> no DMA",
        [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 1>(Y, WS, X, M, nb, s); }, 4},
       {"ABL rs<384> no GELU",
