@@ -12,7 +12,8 @@
 //   * GELU on the fp32 accumulator: A&S erfc without cancellation (common.h cn_gelu_as2, 1.5e-7), then hi / lo split.
 // Unfused, the exact mode moves the 4C hidden through HBM at 4 bytes per element -- 1.39 GB per stage-0 block at B = 64,
 // written by pw1 and read back by pw2: 1.22 ms per block (profiles/r03_exact_encoder_by_grid.csv); here it stays in the
-// registers.  Stage 2 (C = 384: y pairs + O = 384 registers) and stage 3 keep the unfused sp16 GEMMs of gemm2.h.
+// registers.  Stage 2 (C = 384: y pairs + O = 384 registers) and stage 3 keep the unfused sp16 GEMMs of gemm2.h: a one-wave-
+// per-SIMD version with half entries in the ring (tools/lab/mlp_sp_split.h) took 553 us per launch against 311 + 217 unfused.
 //
 // Ring entry of hidden chunk j (1 KB fragments, lane l reads 16 B at 16 l; packed by pk_mlp_sp):
 //   [W1 hi k-step 0, W1 lo k-step 0, W1 hi 1, W1 lo 1, ...] [bias] [W2' hi (k 0, t 0), lo (k 0, t 0), hi (k 0, t 1), ...]
@@ -107,30 +108,40 @@ template <int C> struct SpWave {
     }
   }
 
-  // one hidden chunk: fragments at wc (LDS, lane offset applied)
-  static __device__ __forceinline__ void step(const char* wc, const f16x8 (&yh)[KS1], const f16x8 (&yl)[KS1], const f16x8 ones,
-                                              f32x16 (&O)[NT2]) {
-    f32x16 X = W::zero16();
-    f16x8 wh = frag(wc, 0), wl = frag(wc, 1);
-#pragma unroll
-    for (int s = 0; s < KS1; ++s) {
-      const f16x8 ch = wh, cl = wl;
-      if (s + 1 < KS1) {
-        wh = frag(wc, 2 * s + 2);
-        wl = frag(wc, 2 * s + 3);
-      } else {
-        wh = frag(wc, 2 * KS1);  // the bias fragment
-      }
-      X = mma(ch, yl[s], X);
-      X = mma(cl, yh[s], X);
-      X = mma(ch, yh[s], X);
-      __builtin_amdgcn_sched_barrier(0);
+  // one hidden chunk in two halves (the split-entry kernel puts a barrier between them; the ring kernel calls both):
+  // step_a: GEMM1 + bias + GELU + hi / lo split from the W1 fragments at wc; step_b: GEMM2 from the W2 fragments at w2.
+  // Fragment pairs (hi, lo) are read PRE pairs ahead of the MFMAs that consume them (a pair feeds three MFMAs = 96 cycles;
+  // an LDS read takes longer than that to come back).
+  static constexpr int PRE = 3, RB = PRE + 1;
+  template <int S>
+  static __device__ __forceinline__ void a_k(const char* wc, const f16x8 (&yh)[KS1], const f16x8 (&yl)[KS1], f16x8 (&Fh)[RB],
+                                             f16x8 (&Fl)[RB], f32x16& X) {
+    if constexpr (S + PRE < KS1) {
+      Fh[(S + PRE) % RB] = frag(wc, 2 * (S + PRE));
+      Fl[(S + PRE) % RB] = frag(wc, 2 * (S + PRE) + 1);
+    } else if constexpr (S + PRE == KS1) {
+      Fh[(S + PRE) % RB] = frag(wc, 2 * KS1);  // the bias fragment
     }
-    X = mma(wh, ones, X);
-    const char* w2 = wc + F1 * 1024;
-    f16x8 vh = frag(w2, 0), vl = frag(w2, 1);
+    X = mma(Fh[S % RB], yl[S], X);
+    X = mma(Fl[S % RB], yh[S], X);
+    X = mma(Fh[S % RB], yh[S], X);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S + 1 < KS1) a_k<S + 1>(wc, yh, yl, Fh, Fl, X);
+  }
+  static __device__ __forceinline__ void step_a(const char* wc, const f16x8 (&yh)[KS1], const f16x8 (&yl)[KS1], const f16x8 ones,
+                                                f16x8 (&Gh)[2], f16x8 (&Gl)[2]) {
+    static_assert(KS1 > PRE, "prefetch depth");
+    f32x16 X = W::zero16();
+    f16x8 Fh[RB], Fl[RB];
+#pragma unroll
+    for (int i = 0; i < PRE; ++i) {
+      Fh[i] = frag(wc, 2 * i);
+      Fl[i] = frag(wc, 2 * i + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    a_k<0>(wc, yh, yl, Fh, Fl, X);
+    X = mma(Fh[KS1 % RB], ones, X);
     // GELU (A&S erfc, cancellation free) and the hi / lo split of the chunk: registers 8 k .. 8 k + 7 are k-step k of GEMM2
-    f16x8 Gh[2], Gl[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       float g[8];
@@ -143,20 +154,38 @@ template <int C> struct SpWave {
       Gh[k] = pack16(g, false);
       Gl[k] = pack16(g, true);
     }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kt = 0; kt < 2 * NT2; ++kt) {
-      const int k = kt / NT2, t = kt % NT2;
-      const f16x8 ch = vh, cl = vl;
-      if (kt + 1 < 2 * NT2) {
-        vh = frag(w2, 2 * kt + 2);
-        vl = frag(w2, 2 * kt + 3);
-      }
-      O[t] = mma(Gl[k], ch, O[t]);
-      O[t] = mma(Gh[k], cl, O[t]);
-      O[t] = mma(Gh[k], ch, O[t]);
-      __builtin_amdgcn_sched_barrier(0);
+  }
+  template <int KT>
+  static __device__ __forceinline__ void b_k(const char* w2, const f16x8 (&Gh)[2], const f16x8 (&Gl)[2], f16x8 (&Fh)[RB],
+                                             f16x8 (&Fl)[RB], f32x16 (&O)[NT2]) {
+    if constexpr (KT + PRE < 2 * NT2) {
+      Fh[(KT + PRE) % RB] = frag(w2, 2 * (KT + PRE));
+      Fl[(KT + PRE) % RB] = frag(w2, 2 * (KT + PRE) + 1);
     }
+    constexpr int k = KT / NT2, t = KT % NT2;
+    O[t] = mma(Gl[k], Fh[KT % RB], O[t]);
+    O[t] = mma(Gh[k], Fl[KT % RB], O[t]);
+    O[t] = mma(Gh[k], Fh[KT % RB], O[t]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (KT + 1 < 2 * NT2) b_k<KT + 1>(w2, Gh, Gl, Fh, Fl, O);
+  }
+  static __device__ __forceinline__ void step_b(const char* w2, const f16x8 (&Gh)[2], const f16x8 (&Gl)[2], f32x16 (&O)[NT2]) {
+    static_assert(2 * NT2 > PRE, "prefetch depth");
+    f16x8 Fh[RB], Fl[RB];
+#pragma unroll
+    for (int i = 0; i < PRE; ++i) {
+      Fh[i] = frag(w2, 2 * i);
+      Fl[i] = frag(w2, 2 * i + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    b_k<0>(w2, Gh, Gl, Fh, Fl, O);
+  }
+  static __device__ __forceinline__ void step(const char* wc, const f16x8 (&yh)[KS1], const f16x8 (&yl)[KS1], const f16x8 ones,
+                                              f32x16 (&O)[NT2]) {
+    f16x8 Gh[2], Gl[2];
+    step_a(wc, yh, yl, ones, Gh, Gl);
+    __builtin_amdgcn_sched_barrier(0);
+    step_b(wc + F1 * 1024, Gh, Gl, O);
   }
 };
 
