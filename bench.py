@@ -390,11 +390,21 @@ def main() -> None:
     from conette_amd import synth
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # CN_BENCH_SHARE_GPU=1 (development aid, NOT a measurement): all ranks on cuda:0 with gloo collectives through host memory --
+    # the only way to run the N > 1 code path (sharding, per-window timing tables, the gather, the consistency vote) on a
+    # one-GPU box; RCCL refuses two ranks on one device
+    share = os.environ.get("CN_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if share else dev   # where the small collective tensors of this file live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from conette_amd.dist import gather_captions, shard_bounds, trim_captions
     from conette_amd.engine import Engine
@@ -567,7 +577,7 @@ def main() -> None:
         print(f"[bench] rank {rank}: {bad_steps} of {n_timed} pipelined steps returned other captions / scores than the un-pipelined pass of the same batch; last step: rows",
               rows[:16], "of", a_.shape[0], "| score diffs:", int((ll_ != solo_lps[: ll_.shape[0]]).sum()), file=sys.stderr, flush=True)
     if world > 1:  # every rank must agree before a number is printed
-        flag = torch.tensor([1 if pipeline_consistent else 0], dtype=torch.int32, device=dev)
+        flag = torch.tensor([1 if pipeline_consistent else 0], dtype=torch.int32, device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         pipeline_consistent = bool(flag.item())
     if not pipeline_consistent and os.environ.get("CN_BENCH_STRICT", "1") != "0":
@@ -576,7 +586,7 @@ def main() -> None:
     eng.profile_enable(())
     rank_rates = None
     if world > 1:  # a window's time is the slowest rank's; per-rank rates show an imbalance between the GPUs
-        mine = torch.tensor(win_dt + own_dt + [float(B), audio_seconds], dtype=torch.float64, device=dev)
+        mine = torch.tensor(win_dt + own_dt + [float(B), audio_seconds], dtype=torch.float64, device=cdev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         tab = torch.stack(allr).cpu()                       # (world, 2 n_rep + 2)
@@ -641,7 +651,8 @@ def main() -> None:
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": {"bf16": "bf16", "fp8": "fp8 (e4m3 pointwise convolutions of stages 0-2) + bf16", "fp32": "f32", "exact": "f16x2", "mixed": "bf16 encoder + f16x2 decoder"}[args.precision], "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": B, "global_batch": total_clips, "beam_size": beam,
-                       "parallelism": f"dp{world}", "world_size_observed": world},
+                       "parallelism": f"dp{world}", "world_size_observed": world,
+                       **({"share_gpu_selftest": True} if share else {})},
             "audio_seconds_per_sec": round(audio_seconds_all * args.steps / dt, 1),
             "decode_tokens_per_sec": round(world * best_tokens / (decode_ms * 1e-3), 1),   # solo decode (pre-pass)
             "decode_tokens_per_sec_pipelined": round(total_clips / B0 * best_tokens * args.steps / dt, 1) if args.workload == "fixed" else None,

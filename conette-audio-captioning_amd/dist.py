@@ -36,11 +36,14 @@ def gather_captions(preds: torch.Tensor, lprobs: torch.Tensor, n_total: int, pad
     l = torch.zeros((per,), dtype=lprobs.dtype, device=lprobs.device)
     p[: preds.shape[0]] = preds
     l[: lprobs.shape[0]] = lprobs
-    all_p = torch.empty((world * per, width), dtype=preds.dtype, device=preds.device)
-    all_l = torch.empty((world * per,), dtype=lprobs.dtype, device=lprobs.device)
+    dev = preds.device
+    if dist.get_backend(group) == "gloo" and dev.type != "cpu":  # (gloo moves host memory: the N > 1 self-test on one GPU)
+        p, l = p.cpu(), l.cpu()
+    all_p = torch.empty((world * per, width), dtype=preds.dtype, device=p.device)
+    all_l = torch.empty((world * per,), dtype=lprobs.dtype, device=l.device)
     dist.all_gather_into_tensor(all_p, p, group=group)
     dist.all_gather_into_tensor(all_l, l, group=group)
-    return all_p[:n_total], all_l[:n_total]
+    return all_p[:n_total].to(dev), all_l[:n_total].to(dev)
 
 
 def trim_captions(preds: torch.Tensor, eos_id: int = 2) -> torch.Tensor:
