@@ -387,13 +387,15 @@ __global__ __launch_bounds__(2 * NP * 64) void cn_mlp_rs_kernel(const bf16_t* __
       for (int t = 0; t < G::NT2; ++t) RW::load_tile(x0, t, O[t]);
     }
     int g = 0;
-    int io_step = -1000;  // the last step in which this wave stored a tile and loaded the next one (2 x 4 NT2 operations)
+    // the last step in which this wave ran a tile boundary, and the vector-memory operations it really issued there: the
+    // 4 NT2 loads always, the 4 NT2 stores only if some lane's row is inside the tensor (an all-masked store is branched over)
+    int io_step = -1000, io_n = 0;
     bf16x8 H[2];
     auto head = [&]() {  // ring wait, first barrier, G(g - 2) -> registers, second barrier
       // Own pieces of the entry about to be consumed have landed.  They were issued in step g - (NST - 1); younger than them
       // (the counter retires in order) are the pieces of NST - 2 later entries and, if a tile boundary fell strictly
       // between, its stores and loads.
-      cn_vm_wait((NST - 2) * n_mine + ((io_step > g - (NST - 1) && io_step < g) ? 8 * G::NT2 : 0));
+      cn_vm_wait((NST - 2) * n_mine + ((io_step > g - (NST - 1) && io_step < g) ? io_n : 0));
       __builtin_amdgcn_s_barrier();
       H[0] = *(const bf16x8*)gl;
       H[1] = *(const bf16x8*)(gl + 1024);
@@ -419,6 +421,7 @@ __global__ __launch_bounds__(2 * NP * 64) void cn_mlp_rs_kernel(const bf16_t* __
       head();
       RW::template b_step<true>(wl + (g % NST) * SB + RW::F1 * 1024, H, O, entry(g + NST - 1), xrow, xnext, bbl, in_range);
       io_step = g;
+      io_n = 4 * G::NT2 + ((valid && (!(ABL & 4) || it == max_it - 1)) ? 4 * G::NT2 : 0);  // (lane 0's row of a valid tile is in range)
       ++g;
     }
   }
