@@ -14,6 +14,8 @@ SOURCES = ["api.hip", "frontend.hip", "encoder.hip", "decoder.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-DCN_RC2_GELU_PK"]
 if os.environ.get("CN_G2_PROF"):  # profiling build: phase stamps inside the encoder GEMM (tools/g2prof.py)
     FLAGS.append("-DCN_G2_PROF")
+if os.environ.get("CN_NO_RS"):     # A/B build: the chained stage-2 kernel of round 2 instead of the role-split one
+    FLAGS.append("-DCN_NO_RS")
 if os.environ.get("CN_G2_NOACT"):
     FLAGS.append("-DCN_G2_NOACT")
 

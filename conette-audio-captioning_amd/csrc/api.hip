@@ -436,8 +436,11 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
           if (w1 && w2 && bw.b1 && bw.b2 && bw.scale) {
             const int units = (C / 8) * (C / 8 + 1) * 64;
             // C = 384 runs the role-split kernel (mlp_rs.h): same fragments, entry e = [W1 of chunk e | W2 of chunk e - 2]
+#ifndef CN_NO_RS
             if (C == 384) hipLaunchKernelGGL(pk_mlp_rs, dim3((units + 255) / 256), dim3(256), 0, 0, w1, bw.b1, w2, bw.b2, bw.scale, C, ms);
-            else hipLaunchKernelGGL(pk_mlp_rc2, dim3((units + 255) / 256), dim3(256), 0, 0, w1, bw.b1, w2, bw.b2, bw.scale, C, CN_RC2_NCK(C), ms);
+            else
+#endif
+            hipLaunchKernelGGL(pk_mlp_rc2, dim3((units + 255) / 256), dim3(256), 0, 0, w1, bw.b1, w2, bw.b2, bw.scale, C, CN_RC2_NCK(C), ms);
             bw.mlp_stream = ms;
           }
         }

@@ -818,7 +818,11 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
           const bf16_t* wsm = (const bf16_t*)bw.mlp_stream;
           if (C == 96) CN_TRY((cn_launch_mlp_rc2_resident<96, 12, 1>(y, wsm, xc, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
           else if (C == 192) CN_TRY((cn_launch_mlp_rc2_ring<192, 8, CN_RC2_NCK(192), CN_RC2_NCK(192) == 2 ? 3 : 5>(y, wsm, xc, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
+#ifdef CN_NO_RS  // A/B builds only (tools/lab/ab.sh): round 2's chained kernel at stage 2
+          else CN_TRY((cn_launch_mlp_rc2_ring<384, 4, 1, 3>(y, wsm, xc, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
+#else
           else CN_TRY((cn_launch_mlp_rs<384, 4, 3>(y, wsm, xc, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
+#endif
           fused = true;
         }
       }
