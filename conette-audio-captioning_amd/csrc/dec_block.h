@@ -36,7 +36,10 @@
 #pragma once
 #include "gemm2.h"
 
-#define DB_ROWS 4   // rows (= waves) per block: many small blocks spread the K/V and weight streams over more CUs
+#ifndef DB_ROWS
+#define DB_ROWS 4   // rows (= row waves) per block: many small blocks spread the K/V and weight streams over more CUs
+#endif
+#define DB_THREADS (256 + 64 * DB_ROWS)  // 4 GEMM waves + DB_ROWS row waves
 
 // Wave-per-row attention: lane l owns dims 4l..4l+3 (head l >> 3); keys in batches of NB with all
 // loads of a batch in flight; fp32 online softmax.  kp(s) / vp(s): this lane's 4 bf16 of key / value s.
@@ -237,7 +240,7 @@ __device__ unsigned long long g_db_prof[16];
 #define DB_NB_CROSS 8      // cross-attention frames per batch
 #define DB_DEPTH_CROSS 2   // requested right after the self-attention; the rest roll while the first are consumed
 
-__global__ __launch_bounds__(512, 1) void cn_dec_block_kernel(
+__global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
     DbPrologue pro, DbWeights wt,
     bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,    // self K/V cache of this layer [step][R][256]
     const int* __restrict__ anc, int step, int R, int beam, int maxp,
@@ -344,8 +347,8 @@ __global__ __launch_bounds__(512, 1) void cn_dec_block_kernel(
   if (rt < 32) ((uint4*)(sA + DB_ROWS * 512))[rt] = uint4{0, 0, 0, 0};  // the zero row
   // parameters -> LDS, 10 pieces of 1 KB by LDS-DMA (landed before this wave's younger P0 loads, i.e. before b1)
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const int piece = rw + 4 * c;
+  for (int c = 0; c < (10 + DB_ROWS - 1) / DB_ROWS; ++c) {
+    const int piece = rw + DB_ROWS * c;
     if (piece < 10)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt.params + piece * 256 + lane * 4),
                                        (__attribute__((address_space(3))) void*)((char*)sP + piece * 1024), 16, 0, 0);

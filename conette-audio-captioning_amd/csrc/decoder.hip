@@ -899,7 +899,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
           wt.stream = (const bf16_t*)lw.blk_w;
           wt.params = lw.blk_p;
           CN_TRY(cn_dec_block_setup());
-          hipLaunchKernelGGL(cn_dec_block_kernel, dim3(cn_cdiv(R, DB_ROWS)), dim3(512), DB_LDS_BYTES, s, pro, wt, kc, vc,
+          hipLaunchKernelGGL(cn_dec_block_kernel, dim3(cn_cdiv(R, DB_ROWS)), dim3(DB_THREADS), DB_LDS_BYTES, s, pro, wt, kc, vc,
                              w.anc, step, R, beam, maxp, (const bf16_t*)kvc, kv_ld, l * 2 * d, frame_lens, Ta, w.x, xt,
                              scale, kvalid, db_debug, gate);
           CN_LAUNCH_CHECK();
