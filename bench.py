@@ -409,7 +409,7 @@ def main() -> None:
     from conette_amd.dist import gather_captions, shard_bounds, trim_captions
     from conette_amd.engine import Engine
 
-    beam, min_pred, max_pred = args.beam, 3, 20
+    beam, min_pred, max_pred = args.beam, 3, int(os.environ.get("CN_MAX_PRED", "20"))  # (CN_MAX_PRED: interference experiments only)
     strong = args.global_batch > 0
     if strong:
         lo, hi = shard_bounds(args.global_batch, rank, world)
