@@ -6,6 +6,7 @@ reference's ``CoNeTTEModel`` and records inputs + outputs of the hot path per sc
 The fixtures are data (numbers / strings), never reference source.
 
     python -m oracle.gen_golden            # writes tests/golden/*.npz + api_cases.json
+    python -m oracle.gen_golden --only=a,b # only the named scenarios
 """
 from __future__ import annotations
 
@@ -34,6 +35,13 @@ SCENARIOS = {
     "b2_1s_beam3": dict(secs=[1, 1], seed0=3000, kw=dict(task="macs", min_pred_size=1, max_pred_size=12), form="tensor3"),
     "b1_30s_beam3": dict(secs=[30], seed0=4000, kw=dict(task="wavcaps_freesound"), form="tensor1"),
     "b8_10s_beam3_all": dict(secs=[10] * 8, seed0=5000, kw=dict(task="clotho", forbid_rep_mode="all"), form="tensor3"),
+    # round 3: odd lengths (no multiple of the hop or of the 32x reduction), wide beams, min_pred 0, long max_pred, the
+    # content_words mask; beam 8 is the library's CN_MAX_BEAM
+    "b4_odd_beam5_minpred0": dict(secs=[7.013, 3.3, 12.47, 5.5], seed0=6000,
+                                  kw=dict(task=["clotho", "macs", "audiocaps", "wavcaps_soundbible"], beam_size=5, min_pred_size=0,
+                                          max_pred_size=30), form="list"),
+    "b2_4s_beam8_content_words": dict(secs=[4, 4], seed0=7000, kw=dict(task="audiocaps", beam_size=8, forbid_rep_mode="content_words",
+                                                                        max_pred_size=16), form="tensor3"),
 }
 
 
@@ -103,7 +111,10 @@ def main() -> None:
     model.model.projection.register_forward_hook(hook("memory"))
     model.preprocessor.register_forward_hook(lambda m, i, o: taps.__setitem__("pre", {k: v.detach() for k, v in o.items()}))
 
+    only = [a.split("=", 1)[1].split(",") for a in sys.argv[1:] if a.startswith("--only=")]
     for name, sc in SCENARIOS.items():
+        if only and name not in only[0]:
+            continue
         x, wav, n = make_inputs(sc)
         trace.clear()
         taps.clear()
@@ -131,6 +142,8 @@ def main() -> None:
         np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
         print(name, out["preds"].shape, out["lprobs"].numpy().round(4), "min margin %.4g" % min(t[3] for t in trace))
 
+    if only:
+        return
     # ---- API-shape cases (model.py:185-261, preprocessor.py:89-114) ---------------------------
     api = {}
     wav = torch.from_numpy(synth.synth_waveforms(2, 2 * SR, 7000))

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 import torch
 
+from conette_amd import synth
 from tests import golden_util as G
 
 pytestmark = pytest.mark.gpu
@@ -23,14 +24,16 @@ def model_dir(tmp_path_factory):
 def model_fp32(model_dir):
     from conette_amd import CoNeTTEConfig, CoNeTTEModel
     config = CoNeTTEConfig.from_pretrained(model_dir)
+    # (stop-words of the synthetic vocabulary: what the golden generator's NLTK stand-in hands the reference)
     return CoNeTTEModel.from_pretrained(model_dir, config=config, precision="fp32", offline=True,
-                                        audioset_idx_to_name=TAGS)
+                                        audioset_idx_to_name=TAGS, stopwords=synth.synth_stopwords())
 
 
 @pytest.fixture(scope="module")
 def model_exact(model_dir):
     from conette_amd import CoNeTTEModel
-    return CoNeTTEModel.from_pretrained(model_dir, precision="exact", offline=True, audioset_idx_to_name=TAGS)
+    return CoNeTTEModel.from_pretrained(model_dir, precision="exact", offline=True, audioset_idx_to_name=TAGS,
+                                        stopwords=synth.synth_stopwords())
 
 
 @pytest.fixture(scope="module")
