@@ -453,7 +453,7 @@ def main() -> None:
     prio = int(os.environ.get("CN_DEC_PRIO", "-1"))  # decode stream priority (negative = higher)
     n_enc = int(os.environ.get("CN_ENC_STREAMS", "1"))   # 2: encodes of consecutive batches on alternating streams (the blocks
     # of one batch start on the CUs the previous batch has left; measured 3 % slower than one stream, kept as a knob)
-    s_encs = [torch.cuda.Stream(dev) for _ in range(max(1, min(n_enc, 2)))]
+    s_encs = [torch.cuda.Stream(dev, priority=int(os.environ.get("CN_ENC_PRIO", "0"))) for _ in range(max(1, min(n_enc, 2)))]
     # CN_DEC_STREAMS decode chains in flight (default 2): a decode is a serial chain of ~300 latency-bound launches that
     # stretches to the length of an encode when it shares the chip with one; with two chains (batches i-1 and i-2 decode
     # while batch i encodes) a chain may take two steps, and the step is bounded by the encoder again.
