@@ -358,7 +358,7 @@ def parity_report(args, Engine, eng, sd, dev, w0, lens0, bos0, forbid, t_audio, 
             torch.cuda.synchronize(dev)
             enc_ms += ev[0].elapsed_time(ev[1]) / k_
             dec_ms += ev[1].elapsed_time(ev[2]) / k_
-        result[f"{name}_clips_per_sec"] = round(n * k_ / (time.perf_counter() - t1), 1)
+        result[f"{name}_clips_per_sec_unpipelined"] = round(n * k_ / (time.perf_counter() - t1), 1)   # (encode then decode on one stream; `bench.py --precision NAME` is the pipelined number)
         result[f"{name}_encode_ms"], result[f"{name}_decode_ms"] = round(enc_ms, 3), round(dec_ms, 3)
         e.profile_enable(("frontend", "stem", "dwconv_ln", "pw1_gemm", "pw2_gemm", "downsample", "heads"))
         e.encode(wv, out=(fe_b[0], cl_b[0]))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The bench lines DESIGN.md quotes besides the default one ("keep the evidence you quote"):
-#   bash tools/evidence_round.sh TAG   -> gpurun_out/TAG_{b256,b16,mixed,shard256,soak,exact,fp8,default}.json (one JSON line each)
+#   bash tools/evidence_round.sh TAG   -> gpurun_out/TAG_{b256,b16,mixedlen,shard256,soak,exact,fp8,default}.json (one JSON line each)
 TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
@@ -13,7 +13,7 @@ print('$name', d['value'], d['unit'], 'ms/step', d['ms_per_step'], 'windows', d[
 run default
 run b256 --batch 256 --steps 30 --cpu-clips 0 --parity-clips 0
 run b16 --batch 16 --steps 200 --cpu-clips 0 --parity-clips 0
-run mixed --workload mixed --steps 30 --cpu-clips 0 --parity-clips 0
+run mixedlen --workload mixed --steps 30 --cpu-clips 0 --parity-clips 0
 run shard256 --global-batch 256 --steps 30 --cpu-clips 0 --parity-clips 0
 run soak --steps 300 --repeat 5 --cpu-clips 0 --parity-clips 0
 run exact --precision exact --steps 30 --cpu-clips 0 --parity-clips 0
