@@ -431,7 +431,7 @@ def main() -> None:
         from conette_amd.bucketing import plan_buckets
         rng = np.random.default_rng(1234 + clip0)
         lengths = rng.integers(1 * SR, 30 * SR + 1, size=B)
-        buckets = plan_buckets(lengths.tolist(), max_padded_seconds=float(os.environ.get("CN_BUCKET_SECONDS", "640")), sr=SR)
+        buckets = plan_buckets(lengths.tolist(), max_padded_seconds=float(os.environ.get("CN_BUCKET_SECONDS", "960")), sr=SR)
         batches = []
         for idx in buckets:
             ls = [int(lengths[i]) for i in idx]
