@@ -1002,6 +1002,19 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
           hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.slabs, splits, (size_t)R * d,
                              lw.ff2_b, w.x, lw.n3w, lw.n3b, R, w.x, xt);
           CN_LAUNCH_CHECK();
+        } else if constexpr (std::is_same<T, sp16_t>::value) {
+          // exact precision: the same split-K as bf16 (M = R rows, K = d_ff: 12 blocks looping over 64 k-tiles took 30 us,
+          // a quarter of the whole decode) -- partial slabs, summed in a fixed order with bias + residual by the LayerNorm
+          const int splits = (dff % (FF2_SPLITS * 32) == 0) ? FF2_SPLITS : 1;
+          {
+            CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
+            EpiSlab e2{w.slabs, d, (size_t)R * d};
+            CN_TRY(cn_gemm2_sp((const sp16_t*)ffh, dff, (const sp16_t*)lw.ff2_w, dff, R, d, dff, e2, s, splits));
+          }
+          CnProfScope ps(ctx, CONETTE_PROF_DEC_MISC, s);
+          hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.slabs, splits, (size_t)R * d,
+                             lw.ff2_b, w.x, lw.n3w, lw.n3b, R, w.x, xt);
+          CN_LAUNCH_CHECK();
         } else {
           {
             CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);

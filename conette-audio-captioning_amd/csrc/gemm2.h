@@ -466,11 +466,12 @@ static int cn_gemm2(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, i
 
 // sp16 dispatch ("exact" precision): K elements of 4 bytes = 2 K bf16-sized columns; K % 32 == 0.  128 x 128 (or 128 x 96)
 // tiles with four waves and two blocks per compute unit for the encoder's products, 64 x 64 for the decoder's.
+// splits > 1 (slab epilogue only): split K over blockIdx.y; K / splits must be a multiple of 32 elements.
 template <class Epi>
 static int cn_gemm2_sp(const sp16_t* A, int lda, const sp16_t* W, int ldw, int M, int N, int K, const Epi& epi,
-                       hipStream_t stream) {
-  if (K % 32 != 0 || M <= 0 || N <= 0) {
-    cn_set_error("cn_gemm2_sp: bad shape M=%d N=%d K=%d", M, N, K);
+                       hipStream_t stream, int splits = 1) {
+  if (K % 32 != 0 || M <= 0 || N <= 0 || splits < 1 || (K / splits) % 32 != 0) {
+    cn_set_error("cn_gemm2_sp: bad shape M=%d N=%d K=%d splits=%d", M, N, K, splits);
     return CN_ERR_ARG;
   }
   const bf16_t* a = (const bf16_t*)A;
@@ -480,7 +481,7 @@ static int cn_gemm2_sp(const sp16_t* A, int lda, const sp16_t* W, int ldw, int M
     if (n96) return cn_launch_gemm2_t<128, 96, 64, 2, Epi, 2, 2, true>(a, 2 * lda, w, 2 * ldw, M, N, 2 * K, 1, epi, stream);
     return cn_launch_gemm2_t<128, 128, 64, 2, Epi, 2, 2, true>(a, 2 * lda, w, 2 * ldw, M, N, 2 * K, 1, epi, stream);
   }
-  return cn_launch_gemm2_t<64, 64, 64, 2, Epi, 2, 2, true>(a, 2 * lda, w, 2 * ldw, M, N, 2 * K, 1, epi, stream);
+  return cn_launch_gemm2_t<64, 64, 64, 2, Epi, 2, 2, true>(a, 2 * lda, w, 2 * ldw, M, N, 2 * K, splits, epi, stream);
 }
 
 // type-generic front end: bf16 -> v2, sp16 -> v2 with split fragments, fp32 -> gemm.h
