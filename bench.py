@@ -55,7 +55,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=0, help="total clips, sharded over the GPUs (strong scaling)")
     ap.add_argument("--beam", type=int, default=3)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp8", "mixed", "fp32", "exact"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "fp8", "mixed", "mixed16", "fp32", "exact"])
     ap.add_argument("--repeat", type=int, default=5,
                     help="timed windows of --steps steps each (barrier + synchronize around every window); `value` and "
                          "`ms_per_step` are the MEDIAN window's, every window's clips/s is listed under `windows`")
@@ -288,7 +288,7 @@ def parity_report(args, Engine, eng, sd, dev, w0, lens0, bos0, forbid, t_audio, 
     n = min(args.parity_clips, w0.shape[0])
     wv, ln, bs = w0[:n].contiguous(), lens0[:n].contiguous(), bos0[:n].contiguous()
     engines = {args.precision: eng}
-    for name in ("bf16", "fp8", "mixed", "exact", "fp32"):
+    for name in ("bf16", "f16", "fp8", "mixed", "mixed16", "exact", "fp32"):
         if name not in engines:
             try:
                 engines[name] = Engine(sd, precision=name, device=dev)
@@ -301,7 +301,7 @@ def parity_report(args, Engine, eng, sd, dev, w0, lens0, bos0, forbid, t_audio, 
         for bm_ in (1, beam):
             o = e.decode(fe[name], ln, bs, forbid, bm_, min_pred, max_pred)
             outs[(name, name, bm_)] = (_ids(o), o["best_lprobs"].cpu())
-    mixes = [(a, b) for a in engines for b in engines if a != b and {a, b} <= {"bf16", "fp32"}]
+    mixes = [(a, b) for a in engines for b in engines if a != b and ({a, b} == {"bf16", "fp32"} or {a, b} == {"f16", "fp32"})]
     for enc_p, dec_p in mixes:
         for bm_ in (1, beam):
             o = engines[dec_p].decode(fe[enc_p], ln, bs, forbid, bm_, min_pred, max_pred)
@@ -458,7 +458,7 @@ def main() -> None:
     # stretches to the length of an encode when it shares the chip with one; with two chains (batches i-1 and i-2 decode
     # while batch i encodes) a chain may take two steps, and the step is bounded by the encoder again.
     # (the exact precision's decode is the one-launch-per-sub-layer path, 12 ms alone at B = 64: three chains in flight)
-    n_dec = max(1, min(int(os.environ.get("CN_DEC_STREAMS", "3" if args.precision in ("exact", "mixed") else "2")), 3))  # (four and more chains: 2x slower, measured)
+    n_dec = max(1, min(int(os.environ.get("CN_DEC_STREAMS", "3" if args.precision in ("exact", "mixed", "mixed16") else "2")), 3))  # (four and more chains: 2x slower, measured)
     s_decs = [torch.cuda.Stream(dev, priority=prio) for _ in range(n_dec)]
     n_slot = n_dec + 1
     from conette_amd.engine import MAX_DECODE_GRAPHS
@@ -649,7 +649,8 @@ def main() -> None:
                         "spread": round((max(win_dt) - min(win_dt)) / dt, 4), "timed_total_s": round(sum(win_dt), 4)},
             "rank_clips_per_sec": rank_rates,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "fp8": "fp8 (e4m3 pointwise convolutions of stages 0-2) + bf16", "fp32": "f32", "exact": "f16x2", "mixed": "bf16 encoder + f16x2 decoder"}[args.precision], "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp8": "fp8 (e4m3 pointwise convolutions of stages 0-2) + bf16", "fp32": "f32", "exact": "f16x2", "mixed": "bf16 encoder + f16x2 decoder", "f16": "f16",
+                      "mixed16": "f16 encoder + f16x2 decoder"}[args.precision], "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": B, "global_batch": total_clips, "beam_size": beam,
                        "parallelism": f"dp{world}", "world_size_observed": world,
                        **({"share_gpu_selftest": True} if share else {})},

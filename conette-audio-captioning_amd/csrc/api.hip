@@ -118,18 +118,20 @@ __global__ void pk_down(const float* __restrict__ src, T* __restrict__ dst, int 
 // decoder block stream (dec_block.h): 16-byte unit u = ((((m*4 + w)*4 + qd)*4 + a)*2 + kk)*64 + lane holds
 // W_m[64w + 16a + (lane & 15)][32(2qd + kk) + 8(lane >> 4) .. +8]
 struct PkBlockSrc { const float* W[6]; };
-__global__ void pk_block_stream(PkBlockSrc src, bf16_t* __restrict__ dst) {
+template <typename HT>
+__global__ void pk_block_stream(PkBlockSrc src, HT* __restrict__ dst) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= 6 * 4 * 4 * 4 * 2 * 64) return;
   const int lane = u & 63, kk = (u >> 6) & 1, a = (u >> 7) & 3, qd = (u >> 9) & 3, w = (u >> 11) & 3, m = u >> 13;
   const float* s = src.W[m] + (size_t)(64 * w + 16 * a + (lane & 15)) * 256 + 32 * (2 * qd + kk) + 8 * (lane >> 4);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) dst[(size_t)u * 8 + i] = (bf16_t)s[i];
+  for (int i = 0; i < 8; ++i) dst[(size_t)u * 8 + i] = cn_from_f32<HT>(s[i]);
 }
 // decoder FFN stream (dec_ffn.h): unit u = (((((c*2 + t)*4 + w)*4 + qd)*4 + a)*2 + kk)*64 + lane;
 // t = 0: W1[c*256 + 64w + 16a + (lane & 15)][32(2qd + kk) + 8(lane >> 4) .. +8]        (W1: [dff][256])
 // t = 1: W2[64w + 16a + (lane & 15)][c*256 + 32(2qd + kk) + 8(lane >> 4) .. +8]        (W2: [256][dff])
-__global__ void pk_ffn_stream(const float* __restrict__ W1, const float* __restrict__ W2, int dff, bf16_t* __restrict__ dst) {
+template <typename HT>
+__global__ void pk_ffn_stream(const float* __restrict__ W1, const float* __restrict__ W2, int dff, HT* __restrict__ dst) {
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= (dff / 256) * 2 * 8192) return;
   const int lane = u & 63, kk = (u >> 6) & 1, a = (u >> 7) & 3, qd = (u >> 9) & 3, w = (u >> 11) & 3, t = (u >> 13) & 1,
@@ -137,7 +139,7 @@ __global__ void pk_ffn_stream(const float* __restrict__ W1, const float* __restr
   const int r = 64 * w + 16 * a + (lane & 15), k = 32 * (2 * qd + kk) + 8 * (lane >> 4);
   const float* s = t == 0 ? W1 + (size_t)(c * 256 + r) * 256 + k : W2 + (size_t)r * dff + c * 256 + k;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) dst[(size_t)u * 8 + i] = (bf16_t)s[i];
+  for (int i = 0; i < 8; ++i) dst[(size_t)u * 8 + i] = cn_from_f32<HT>(s[i]);
 }
 __global__ void pk_bn(const float* w, const float* b, const float* mean, const float* var, float* scale, float* shift,
                       int n) {
@@ -204,9 +206,9 @@ struct Builder {
     }
     return dst;
   }
-  // fp32 -> the context's operand type (bf16 | sp16 = fp16 hi/lo pairs | fp32)
+  // fp32 -> the context's operand type (bf16 | fp16 | sp16 = fp16 hi/lo pairs | fp32)
   void copy_operand(const float* src, void* dst, size_t n) {
-    if (ctx->esize == 2) hipLaunchKernelGGL((pk_copy<bf16_t>), dim3(256), dim3(256), 0, 0, src, (bf16_t*)dst, n);
+    if (ctx->esize == 2) CN_H16_CALL(ctx, hipLaunchKernelGGL((pk_copy<HT>), dim3(256), dim3(256), 0, 0, src, (HT*)dst, n));
     else if (ctx->sp16) hipLaunchKernelGGL((pk_copy<sp16_t>), dim3(256), dim3(256), 0, 0, src, (sp16_t*)dst, n);
     else hipLaunchKernelGGL((pk_copy<float>), dim3(256), dim3(256), 0, 0, src, (float*)dst, n);
   }
@@ -219,7 +221,7 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
     return CN_ERR_ARG;
   }
   if (cfg->precision != CONETTE_PREC_F32 && cfg->precision != CONETTE_PREC_BF16 && cfg->precision != CONETTE_PREC_F16X2 &&
-      cfg->precision != CONETTE_PREC_FP8) {
+      cfg->precision != CONETTE_PREC_FP8 && cfg->precision != CONETTE_PREC_F16) {
     cn_set_error("create: unknown precision %d", cfg->precision);
     return CN_ERR_ARG;
   }
@@ -233,7 +235,8 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
   memset(ctx, 0, sizeof(*ctx));
   ctx->cfg = *cfg;
   ctx->rt = new CnRuntime();
-  ctx->esize = (cfg->precision == CONETTE_PREC_BF16 || cfg->precision == CONETTE_PREC_FP8) ? 2 : 4;
+  ctx->esize = (cfg->precision == CONETTE_PREC_BF16 || cfg->precision == CONETTE_PREC_FP8 || cfg->precision == CONETTE_PREC_F16) ? 2 : 4;
+  ctx->f16 = cfg->precision == CONETTE_PREC_F16 ? 1 : 0;
   ctx->fp8 = cfg->precision == CONETTE_PREC_FP8 ? 1 : 0;
   ctx->sp16 = cfg->precision == CONETTE_PREC_F16X2 ? 1 : 0;
   {
@@ -373,7 +376,7 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
     void* dst = B.alloc((size_t)C2 * C * 4 * ctx->esize);
     if (w) {
       const unsigned blocks = (unsigned)(((size_t)C2 * C * 4 + 255) / 256);
-      if (ctx->esize == 2) hipLaunchKernelGGL((pk_down<bf16_t>), dim3(blocks), dim3(256), 0, 0, w, (bf16_t*)dst, C2, C);
+      if (ctx->esize == 2) CN_H16_CALL(ctx, hipLaunchKernelGGL((pk_down<HT>), dim3(blocks), dim3(256), 0, 0, w, (HT*)dst, C2, C));
       else if (ctx->sp16) hipLaunchKernelGGL((pk_down<sp16_t>), dim3(blocks), dim3(256), 0, 0, w, (sp16_t*)dst, C2, C);
       else hipLaunchKernelGGL((pk_down<float>), dim3(blocks), dim3(256), 0, 0, w, (float*)dst, C2, C);
     }
@@ -385,7 +388,7 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
       void* fs = B.alloc(i == 0 ? DownGeom<96>::TOTAL_BYTES : DownGeom<192>::TOTAL_BYTES);
       if (w && g && bt && cb) {
         const int n = (4 * C / 16) * (C2 / 32) * 64;
-        hipLaunchKernelGGL(pk_down_fused, dim3((n + 255) / 256), dim3(256), 0, 0, w, g, bt, cb, C2, C, (bf16_t*)fs);
+        CN_H16_CALL(ctx, hipLaunchKernelGGL(pk_down_fused<HT>, dim3((n + 255) / 256), dim3(256), 0, 0, w, g, bt, cb, C2, C, (HT*)fs));
         ctx->down[i].fused = fs;
       }
     }
@@ -430,17 +433,17 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
         }
         if (ctx->esize == 2 && C <= 384) {
           const size_t bytes = (size_t)(C / 8) * (C / 8 + 1) * 1024 + (size_t)C * 4;  // Rc2Geom<C, 1>::TOTAL_BYTES
-          bf16_t* ms = (bf16_t*)B.alloc(bytes);
+          void* ms = B.alloc(bytes);
           const float* w1 = B.find(p + "pwconv1.weight", (int64_t)4 * C * C);
           const float* w2 = B.find(p + "pwconv2.weight", (int64_t)4 * C * C);
           if (w1 && w2 && bw.b1 && bw.b2 && bw.scale) {
             const int units = (C / 8) * (C / 8 + 1) * 64;
             // C = 384 runs the role-split kernel (mlp_rs.h): same fragments, entry e = [W1 of chunk e | W2 of chunk e - 2]
 #ifndef CN_NO_RS
-            if (C == 384) hipLaunchKernelGGL(pk_mlp_rs, dim3((units + 255) / 256), dim3(256), 0, 0, w1, bw.b1, w2, bw.b2, bw.scale, C, ms);
+            if (C == 384) CN_H16_CALL(ctx, hipLaunchKernelGGL(pk_mlp_rs<HT>, dim3((units + 255) / 256), dim3(256), 0, 0, w1, bw.b1, w2, bw.b2, bw.scale, C, (HT*)ms));
             else
 #endif
-            hipLaunchKernelGGL(pk_mlp_rc2, dim3((units + 255) / 256), dim3(256), 0, 0, w1, bw.b1, w2, bw.b2, bw.scale, C, CN_RC2_NCK(C), ms);
+            CN_H16_CALL(ctx, hipLaunchKernelGGL(pk_mlp_rc2<HT>, dim3((units + 255) / 256), dim3(256), 0, 0, w1, bw.b1, w2, bw.b2, bw.scale, C, CN_RC2_NCK(C), (HT*)ms));
             bw.mlp_stream = ms;
           }
         }
@@ -497,24 +500,24 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
       lw.blk_p = nullptr;
       lw.ffn_w = nullptr;
       if (ctx->esize == 2 && dff % 256 == 0 && dff <= 2048) {
-        bf16_t* fwp = (bf16_t*)B.alloc((size_t)2 * dff * d * 2);
+        void* fwp = B.alloc((size_t)2 * dff * d * 2);
         const float* w1 = B.find(p + "linear1.weight", (int64_t)dff * d);
         const float* w2 = B.find(p + "linear2.weight", (int64_t)dff * d);
         if (w1 && w2) {
           const int units = (dff / 256) * 2 * 8192;
-          hipLaunchKernelGGL(pk_ffn_stream, dim3(units / 256), dim3(256), 0, 0, w1, w2, dff, fwp);
+          CN_H16_CALL(ctx, hipLaunchKernelGGL(pk_ffn_stream<HT>, dim3(units / 256), dim3(256), 0, 0, w1, w2, dff, (HT*)fwp));
           lw.ffn_w = fwp;
         }
       }
       if (ctx->esize == 2) {
-        bf16_t* bw = (bf16_t*)B.alloc((size_t)6 * d * d * 2);
+        void* bw = B.alloc((size_t)6 * d * d * 2);
         const float* ipw = B.find(p + "self_attn.in_proj_weight", (int64_t)3 * d * d);
         const float* sow = B.find(p + "self_attn.out_proj.weight", (int64_t)d * d);
         const float* cow = B.find(p + "multihead_attn.out_proj.weight", (int64_t)d * d);
         if (ipw && sow && caw && cow) {
           PkBlockSrc ps;
           ps.W[0] = ipw, ps.W[1] = ipw + (size_t)d * d, ps.W[2] = ipw + (size_t)2 * d * d, ps.W[3] = sow, ps.W[4] = caw, ps.W[5] = cow;
-          hipLaunchKernelGGL(pk_block_stream, dim3(6 * 4 * 4 * 4 * 2 * 64 / 256), dim3(256), 0, 0, ps, bw);
+          CN_H16_CALL(ctx, hipLaunchKernelGGL(pk_block_stream<HT>, dim3(6 * 4 * 4 * 4 * 2 * 64 / 256), dim3(256), 0, 0, ps, (HT*)bw));
         }
         lw.blk_w = bw;
       }

@@ -12,6 +12,48 @@ typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+#define CN_F32X16
+
+// ---- the two 16-bit operand types of the MFMA paths ------------------------------------------------------------------
+// bf16_t (CONETTE_PREC_BF16: 8 significant bits, fp32 range) and half_t (CONETTE_PREC_F16: IEEE fp16, 11 significant bits,
+// |x| <= 65504).  v_mfma_f32_*_bf16 and v_mfma_f32_*_f16 take the same cycles (MI355X guide), fragments and packed streams
+// have the same bytes, so every kernel is written once over H and instantiated for both; an fp16 operand carries an eighth
+// of the rounding error of a bf16 one.  Conversions to half_t saturate (cn_from_f32 / cn_sat8) instead of producing inf:
+// post-LayerNorm activations, GELU outputs, attention outputs and weights of this model stay orders of magnitude below 65504.
+typedef _Float16 half_t;
+template <typename H> using cn_h8 = H __attribute__((ext_vector_type(8)));
+template <typename H> using cn_h4 = H __attribute__((ext_vector_type(4)));
+template <typename T> struct CnIsH16 { static constexpr bool value = false; };
+template <> struct CnIsH16<bf16_t> { static constexpr bool value = true; };
+template <> struct CnIsH16<half_t> { static constexpr bool value = true; };
+__device__ __forceinline__ f32x16 cn_mma32(cn_h8<bf16_t> a, cn_h8<bf16_t> b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 cn_mma32(cn_h8<half_t> a, cn_h8<half_t> b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 cn_mma16(cn_h8<bf16_t> a, cn_h8<bf16_t> b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 cn_mma16(cn_h8<half_t> a, cn_h8<half_t> b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// eight converted values that are known to be >= -65504 (GELU / ReLU outputs): +inf -> 65504 with four v_pk_min_f16
+template <typename H> __device__ __forceinline__ cn_h8<H> cn_sat8(cn_h8<H> v) {
+  if constexpr (__is_same(H, half_t)) {
+    cn_h8<H> m;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = (H)65504.0f;
+    return __builtin_elementwise_min(v, m);
+  } else {
+    return v;
+  }
+}
+// eight fp32 values -> one 16-byte fragment (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32)
+template <typename H> __device__ __forceinline__ cn_h8<H> cn_pack8(float a, float b, float c, float d, float e, float f, float g, float h) {
+  return cn_h8<H>{(H)a, (H)b, (H)c, (H)d, (H)e, (H)f, (H)g, (H)h};
+}
 
 // ---- LDS-DMA (global -> LDS, 16 bytes per lane, 1 KB per wave instruction) through inline asm ------------------------
 // Not __builtin_amdgcn_global_load_lds: while a builtin piece is pending, the compiler's wait-count pass treats every later
@@ -115,12 +157,14 @@ static inline int cn_cdiv(int a, int b) { return (a + b - 1) / b; }
 template <typename T> __device__ __forceinline__ T cn_from_f32(float x);
 template <> __device__ __forceinline__ float cn_from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t cn_from_f32<bf16_t>(float x) { return (bf16_t)x; }
+template <> __device__ __forceinline__ half_t cn_from_f32<half_t>(float x) { return (half_t)__builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }
 template <> __device__ __forceinline__ f8_t cn_from_f32<f8_t>(float x) {
   return f8_t{(unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(x, 0.f, 0, false) & 0xff)};
 }
 template <> __device__ __forceinline__ sp16_t cn_from_f32<sp16_t>(float x) { return __builtin_bit_cast(sp16_t, cn_sp16_bits(x)); }
 __device__ __forceinline__ float cn_to_f32(float x) { return x; }
 __device__ __forceinline__ float cn_to_f32(bf16_t x) { return (float)x; }
+__device__ __forceinline__ float cn_to_f32(half_t x) { return (float)x; }
 __device__ __forceinline__ float cn_to_f32(sp16_t x) { return (float)x.hi + (float)x.lo; }
 
 // exact-erf GELU (torch F.gelu default; reference convnext.py:47, aac_tfmer.py:36)
@@ -248,6 +292,9 @@ __device__ __forceinline__ void cn_store4(float* p, float a, float b, float c, f
 __device__ __forceinline__ void cn_store4(bf16_t* p, float a, float b, float c, float d) {
   *(bf16x4*)p = bf16x4{(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
 }
+__device__ __forceinline__ void cn_store4(half_t* p, float a, float b, float c, float d) {
+  *(cn_h4<half_t>*)p = cn_h4<half_t>{cn_from_f32<half_t>(a), cn_from_f32<half_t>(b), cn_from_f32<half_t>(c), cn_from_f32<half_t>(d)};
+}
 __device__ __forceinline__ void cn_store4(sp16_t* p, float a, float b, float c, float d) {
   *(u32x4*)p = u32x4{cn_sp16_bits(a), cn_sp16_bits(b), cn_sp16_bits(c), cn_sp16_bits(d)};
 }
@@ -273,6 +320,10 @@ __device__ __forceinline__ void cn_store8(f8_t* p, const float (&o)[8]) {
   hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[4], o[5], hi, false);
   hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[6], o[7], hi, true);
   *(int2*)p = int2{lo, hi};
+}
+__device__ __forceinline__ void cn_store8(half_t* p, const float (&o)[8]) {
+  *(f16x8*)p = f16x8{cn_from_f32<half_t>(o[0]), cn_from_f32<half_t>(o[1]), cn_from_f32<half_t>(o[2]), cn_from_f32<half_t>(o[3]),
+                     cn_from_f32<half_t>(o[4]), cn_from_f32<half_t>(o[5]), cn_from_f32<half_t>(o[6]), cn_from_f32<half_t>(o[7])};
 }
 __device__ __forceinline__ void cn_store8(bf16_t* p, const float (&o)[8]) {
   *(bf16x8*)p = bf16x8{(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3], (bf16_t)o[4], (bf16_t)o[5], (bf16_t)o[6], (bf16_t)o[7]};

@@ -77,6 +77,7 @@ struct conette_ctx {
   int esize;  // operand element size (2 or 4)
   int fp8;    // CONETTE_PREC_FP8: bf16 everywhere except the pointwise convolutions of stages 0-2 (e4m3 operands)
   int sp16;   // CONETTE_PREC_F16X2: operands are sp16_t (fp16 hi/lo pairs, 4 bytes)
+  int f16;    // CONETTE_PREC_F16: operands are half_t (the bf16 kernels instantiated for fp16), esize 2
   // frontend tables
   const float* window;     // [1024]
   const float2* tw512;     // [512]
@@ -134,3 +135,22 @@ struct CnProfScope {
 
 // ---- stage entry points implemented in the .hip files ---------------------------------------
 int cn_frontend(conette_ctx* ctx, const float* wave, int B, int L, float* out, hipStream_t s);
+
+// `return CALL;` with OT = the operand type of the context's precision (bf16_t also carries the fp8 mode, whose only e4m3
+// operands are those of the fused MLP)
+#define CN_BY_PRECISION(ctx, ...)                                                          \
+  do {                                                                                     \
+    switch ((ctx)->cfg.precision) {                                                        \
+      case CONETTE_PREC_BF16:                                                              \
+      case CONETTE_PREC_FP8: { typedef bf16_t OT; return __VA_ARGS__; }                    \
+      case CONETTE_PREC_F16: { typedef half_t OT; return __VA_ARGS__; }                    \
+      case CONETTE_PREC_F16X2: { typedef sp16_t OT; return __VA_ARGS__; }                  \
+      default: { typedef float OT; return __VA_ARGS__; }                                   \
+    }                                                                                      \
+  } while (0)
+// a statement with HT = the 16-bit operand type of the context (esize == 2)
+#define CN_H16_CALL(ctx, ...)                          \
+  do {                                                 \
+    if ((ctx)->f16) { typedef half_t HT; __VA_ARGS__; } \
+    else { typedef bf16_t HT; __VA_ARGS__; }            \
+  } while (0)

@@ -43,20 +43,20 @@
 
 // Wave-per-row attention: lane l owns dims 4l..4l+3 (head l >> 3); keys in batches of NB with all
 // loads of a batch in flight; fp32 online softmax.  kp(s) / vp(s): this lane's 4 bf16 of key / value s.
-template <int NB> struct DbKV { bf16x4 k[NB], v[NB]; };
+template <int NB, typename HT> struct DbKV { cn_h4<HT> k[NB], v[NB]; };
 
-template <int NB, class KeyPtr, class ValPtr>
-__device__ __forceinline__ void db_kv_load(DbKV<NB>& kv, int s0, int n_keys, KeyPtr kp, ValPtr vp) {
+template <int NB, typename HT, class KeyPtr, class ValPtr>
+__device__ __forceinline__ void db_kv_load(DbKV<NB, HT>& kv, int s0, int n_keys, KeyPtr kp, ValPtr vp) {
 #pragma unroll
   for (int u = 0; u < NB; ++u) {
     const int s = min(s0 + u, n_keys - 1);
-    kv.k[u] = *(const bf16x4*)kp(s);
-    kv.v[u] = *(const bf16x4*)vp(s);
+    kv.k[u] = *(const cn_h4<HT>*)kp(s);
+    kv.v[u] = *(const cn_h4<HT>*)vp(s);
   }
 }
 
-template <int NB>
-__device__ __forceinline__ void db_kv_consume(const DbKV<NB>& kv, const f32x4& q, int s0, int n_keys, float& m,
+template <int NB, typename HT>
+__device__ __forceinline__ void db_kv_consume(const DbKV<NB, HT>& kv, const f32x4& q, int s0, int n_keys, float& m,
                                               float& l, f32x4& o, unsigned long long valid = ~0ull) {
   float sc[NB];
 #pragma unroll
@@ -85,14 +85,14 @@ __device__ __forceinline__ void db_kv_consume(const DbKV<NB>& kv, const f32x4& q
 
 // Rolling K/V pipeline over DEPTH register buffers: db_kv_prefetch issues batches 0 .. DEPTH-1 (early, while
 // other work runs), db_kv_attend consumes batch b and re-issues its buffer with batch b + DEPTH.
-template <int NB, int DEPTH, class KeyPtr, class ValPtr>
-__device__ __forceinline__ void db_kv_prefetch(DbKV<NB> (&buf)[DEPTH], int n_keys, KeyPtr kp, ValPtr vp) {
+template <int NB, int DEPTH, typename HT, class KeyPtr, class ValPtr>
+__device__ __forceinline__ void db_kv_prefetch(DbKV<NB, HT> (&buf)[DEPTH], int n_keys, KeyPtr kp, ValPtr vp) {
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
     if (d * NB < n_keys) db_kv_load(buf[d], d * NB, n_keys, kp, vp);
 }
-template <int NB, int DEPTH, class KeyPtr, class ValPtr>
-__device__ __forceinline__ void db_kv_attend(DbKV<NB> (&buf)[DEPTH], const f32x4& q, int n_keys, KeyPtr kp, ValPtr vp,
+template <int NB, int DEPTH, typename HT, class KeyPtr, class ValPtr>
+__device__ __forceinline__ void db_kv_attend(DbKV<NB, HT> (&buf)[DEPTH], const f32x4& q, int n_keys, KeyPtr kp, ValPtr vp,
                                              float& m, float& l, f32x4& o, unsigned long long valid = ~0ull) {
   for (int s0 = 0; s0 < n_keys; s0 += NB * DEPTH) {
 #pragma unroll
@@ -107,9 +107,10 @@ __device__ __forceinline__ void db_kv_attend(DbKV<NB> (&buf)[DEPTH], const f32x4
 }
 
 // attention output of row `wave` (lane's 4 dims) -> bf16 -> swizzled A tile row `wave`
+template <typename HT>
 __device__ __forceinline__ void db_store_row(char* sA, int wave, int lane, const f32x4& o, float inv) {
   typedef G2Geom<256> G;
-  cn_store4((bf16_t*)(sA + wave * G::RBY + (((lane >> 1) ^ (wave & G::SWM)) * 16) + (lane & 1) * 8), o[0] * inv,
+  cn_store4((HT*)(sA + wave * G::RBY + (((lane >> 1) ^ (wave & G::SWM)) * 16) + (lane & 1) * 8), o[0] * inv,
             o[1] * inv, o[2] * inv, o[3] * inv);
 }
 
@@ -130,7 +131,7 @@ struct DbPrologue {
 
 // the six 256 x 256 weight matrices in the order they are consumed, and the per-column parameters
 struct DbWeights {
-  const bf16_t* stream;  // CnLayerW::blk_w: in_proj q | k | v rows, self out-proj, cross q-proj, cross out-proj in fragment order
+  const void* stream;    // CnLayerW::blk_w (16-bit operands, bf16_t or half_t): in_proj q | k | v rows, self out-proj, cross q-proj, cross out-proj in fragment order
   const float* params;   // CnLayerW::blk_p: bin 768 | bo | bq | bo2 | g1 | b1 | g2 | b2
 };
 
@@ -159,15 +160,16 @@ struct DbWeights {
 // 1 KB of consecutive bytes per wave instruction in the packed stream.  Uniform base + 32-bit lane offset
 // (voff = (wave * 16384 + lane * 8) * 2 bytes) keeps the address in an SGPR pair + one VGPR for all 192 loads.
 struct DbStream {
-  const bf16_t* base;
+  const char* base;  // packed 16-bit fragments
   unsigned voff;
 };
 // Written as inline asm: hipcc otherwise keeps a 64-bit VGPR address per 4 KB window (35 pairs) and renames the
 // destination registers (+28), which pushed the kernel past the register budget that lets a block start on a CU
 // that still runs one of the encoder's GEMM workgroups.  The loads are invisible to hipcc's waitcnt insertion,
 // so db_gemm_regs counts them itself.
-__device__ __forceinline__ void db_frag_load(bf16x8& dst, const DbStream& st, int m, int a, int ks) {
-  const bf16_t* p = st.base + (size_t)(m * 16 + (ks >> 1)) * 4096 + (a * 2 + (ks & 1)) * 512;
+template <typename F8>
+__device__ __forceinline__ void db_frag_load(F8& dst, const DbStream& st, int m, int a, int ks) {
+  const char* p = st.base + ((size_t)(m * 16 + (ks >> 1)) * 4096 + (a * 2 + (ks & 1)) * 512) * 2;
   asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(st.voff), "s"(p));
 }
 
@@ -175,8 +177,8 @@ __device__ __forceinline__ void db_frag_load(bf16x8& dst, const DbStream& st, in
 // each fragment register is re-loaded with matrix M + 1 right behind its MFMA.  Fragments are consumed in issue
 // order and every consumed one is re-issued, so exactly 31 younger loads are in flight at each wait (fewer only
 // while the last matrix drains); the GEMM waves issue no other vector memory instruction.
-template <int M>
-__device__ __forceinline__ void db_gemm_regs(const DbStream& wlane, bf16x8 (&fw)[4][8], const char* sA, int lane,
+template <int M, typename HT>
+__device__ __forceinline__ void db_gemm_regs(const DbStream& wlane, cn_h8<HT> (&fw)[4][8], const char* sA, int lane,
                                              f32x4 (&acc)[4]) {
   typedef G2Geom<256> G;
   const int lr = lane & 15, lq = lane >> 4;
@@ -184,11 +186,11 @@ __device__ __forceinline__ void db_gemm_regs(const DbStream& wlane, bf16x8 (&fw)
   const int asw = lr < DB_ROWS ? (lr & G::SWM) : 0;
 #pragma unroll
   for (int a = 0; a < 4; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-  bf16x8 fa = *(const bf16x8*)(sA + arow * G::RBY + ((lq ^ asw) * 16));
+  cn_h8<HT> fa = *(const cn_h8<HT>*)(sA + arow * G::RBY + ((lq ^ asw) * 16));
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
-    const bf16x8 fc = fa;
-    if (ks < 7) fa = *(const bf16x8*)(sA + arow * G::RBY + (((lq + 4 * (ks + 1)) ^ asw) * 16));
+    const cn_h8<HT> fc = fa;
+    if (ks < 7) fa = *(const cn_h8<HT>*)(sA + arow * G::RBY + (((lq + 4 * (ks + 1)) ^ asw) * 16));
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       if (M < 5) {
@@ -207,7 +209,7 @@ __device__ __forceinline__ void db_gemm_regs(const DbStream& wlane, bf16x8 (&fw)
 #undef DB_WAIT_CASE
         }
       }
-      acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[a][ks], fc, acc[a], 0, 0, 0);
+      acc[a] = cn_mma16(fw[a][ks], fc, acc[a]);
       if (M < 5) db_frag_load(fw[a][ks], wlane, M + 1, a, ks);
     }
   }
@@ -240,12 +242,13 @@ __device__ unsigned long long g_db_prof[16];
 #define DB_NB_CROSS 8      // cross-attention frames per batch
 #define DB_DEPTH_CROSS 2   // requested right after the self-attention; the rest roll while the first are consumed
 
+template <typename HT>
 __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
     DbPrologue pro, DbWeights wt,
-    bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,    // self K/V cache of this layer [step][R][256]
+    HT* __restrict__ kc, HT* __restrict__ vc,    // self K/V cache of this layer [step][R][256]
     const int* __restrict__ anc, int step, int R, int beam, int maxp,
-    const bf16_t* __restrict__ kvx, int kv_ld, int kv_off, const int* __restrict__ lens, int Ta,  // cross K/V
-    float* __restrict__ x /* in: previous layer's x2 (residual of its FFN), out: x2 */, bf16_t* __restrict__ xt,
+    const HT* __restrict__ kvx, int kv_ld, int kv_off, const int* __restrict__ lens, int Ta,  // cross K/V
+    float* __restrict__ x /* in: previous layer's x2 (residual of its FFN), out: x2 */, HT* __restrict__ xt,
     float scale, const unsigned long long* __restrict__ kvalid /* teacher forcing: non-pad caption positions */,
     int dbg, const int* __restrict__ gate /* rows still searching at this step (device counter) or null */) {
   if (gate != nullptr && *gate == 0) return;  // every hypothesis has finished (beam.py:192-194 stops here)
@@ -264,8 +267,8 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
   if (wave < 4) {
     // ======================= GEMM waves ========================================================
     const int lr = lane & 15, lq = lane >> 4;
-    const DbStream wlane{wt.stream, (unsigned)(wave * 4 * 4096 + lane * 8) * 2u};
-    bf16x8 fw[4][8];
+    const DbStream wlane{(const char*)wt.stream, (unsigned)(wave * 4 * 4096 + lane * 8) * 2u};
+    cn_h8<HT> fw[4][8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
     f32x4 acc[4];
     DB_SYNC();  // b1: x rows (sA) and parameters (sP) are in LDS
     {           // q | k | v
-      db_gemm_regs<0>(wlane, fw, sA, lane, acc);
+      db_gemm_regs<0, HT>(wlane, fw, sA, lane, acc);
       if (lr < DB_ROWS)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
           const f32x4 bb = *(const f32x4*)(sP + n);
           *(f32x4*)(sV + (0 * DB_ROWS + lr) * 256 + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
         }
-      db_gemm_regs<1>(wlane, fw, sA, lane, acc);
+      db_gemm_regs<1, HT>(wlane, fw, sA, lane, acc);
       if (lr < DB_ROWS)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
           const f32x4 bb = *(const f32x4*)(sP + 256 + n);
           *(f32x4*)(sV + (1 * DB_ROWS + lr) * 256 + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
         }
-      db_gemm_regs<2>(wlane, fw, sA, lane, acc);
+      db_gemm_regs<2, HT>(wlane, fw, sA, lane, acc);
       if (lr < DB_ROWS)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
     DB_SYNC();  // b2: q | k | v ready
     DB_SYNC();  // b3: self-attention output in sA
     {
-      db_gemm_regs<3>(wlane, fw, sA, lane, acc);
+      db_gemm_regs<3, HT>(wlane, fw, sA, lane, acc);
       if (lr < DB_ROWS)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
     DB_SYNC();  // b4: pre-LN1 rows ready
     DB_SYNC();  // b5: x1 in sX / sA
     {
-      db_gemm_regs<4>(wlane, fw, sA, lane, acc);
+      db_gemm_regs<4, HT>(wlane, fw, sA, lane, acc);
       if (lr < DB_ROWS)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
     DB_SYNC();  // b6: cross queries ready
     DB_SYNC();  // b7: cross-attention output in sA
     {
-      db_gemm_regs<5>(wlane, fw, sA, lane, acc);
+      db_gemm_regs<5, HT>(wlane, fw, sA, lane, acc);
       if (lr < DB_ROWS)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -383,12 +386,12 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
       xr = db_row_ln(v, pro.g3, pro.b3, lane);
     }
     *(f32x4*)(sX + rw * 256 + 4 * lane) = xr;
-    db_store_row(sA, rw, lane, xr, 1.0f);
+    db_store_row<HT>(sA, rw, lane, xr, 1.0f);
   }
   // self-attention K/V of the ancestors: requested now, consumed after the q | k | v GEMMs
   auto skp = [&](int s) { return kc + ((size_t)s * R + rb + __builtin_amdgcn_readlane(my_anc, s)) * 256 + 4 * lane; };
   auto svp = [&](int s) { return vc + ((size_t)s * R + rb + __builtin_amdgcn_readlane(my_anc, s)) * 256 + 4 * lane; };
-  DbKV<DB_NB_SELF> skv[DB_DEPTH_SELF];
+  DbKV<DB_NB_SELF, HT> skv[DB_DEPTH_SELF];
   db_kv_prefetch(skv, step, skp, svp);
   DB_STAMP(0)
   DB_SYNC();  // b1
@@ -396,11 +399,11 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
   DB_STAMP(1)
 
   // ---- P1: self-attention ----------------------------------------------------------------------------
-  DbKV<DB_NB_CROSS> xkv[DB_DEPTH_CROSS];
+  DbKV<DB_NB_CROSS, HT> xkv[DB_DEPTH_CROSS];
   const int clip = tr / beam;
   int n_fr = lens[clip];
   n_fr = n_fr < 1 ? 1 : (n_fr > Ta ? Ta : n_fr);
-  const bf16_t* xbase = kvx + (size_t)clip * Ta * kv_ld + kv_off + 4 * lane;
+  const HT* xbase = kvx + (size_t)clip * Ta * kv_ld + kv_off + 4 * lane;
   auto xkp = [&](int t) { return xbase + (size_t)t * kv_ld; };
   auto xvp = [&](int t) { return xbase + (size_t)t * kv_ld + 256; };
   {
@@ -410,8 +413,8 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       q[i] *= scale;
-      kn[i] = (float)(bf16_t)kn[i];  // cache precision
-      vn[i] = (float)(bf16_t)vn[i];
+      kn[i] = (float)cn_from_f32<HT>(kn[i]);  // cache precision
+      vn[i] = (float)cn_from_f32<HT>(vn[i]);
     }
     if (live) {
       cn_store4(kc + ((size_t)step * R + tr) * 256 + 4 * lane, kn[0], kn[1], kn[2], kn[3]);
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = o[i] * corr + p * vn[i];
     }
-    db_store_row(sA, rw, lane, o, 1.0f / l);
+    db_store_row<HT>(sA, rw, lane, o, 1.0f / l);
   }
   DB_STAMP(2)
   DB_SYNC();  // b3
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
     const f32x4 y = *(const f32x4*)(sY + rw * 256 + 4 * lane);
     const f32x4 x1 = db_row_ln(y, sP + DB_P_G1, sP + DB_P_B1, lane);
     *(f32x4*)(sX + rw * 256 + 4 * lane) = x1;
-    db_store_row(sA, rw, lane, x1, 1.0f);
+    db_store_row<HT>(sA, rw, lane, x1, 1.0f);
   }
   DB_STAMP(4)
   DB_SYNC();  // b5
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
     float m = -INFINITY, l = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     db_kv_attend(xkv, q, n_fr, xkp, xvp, m, l, o);
-    db_store_row(sA, rw, lane, o, 1.0f / l);
+    db_store_row<HT>(sA, rw, lane, o, 1.0f / l);
   }
   DB_STAMP(6)
   DB_SYNC();  // b7
@@ -477,4 +480,4 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
   if (dbg && lane == 0 && rw == 0) atomicAdd(&g_db_prof[9], 1ull);
 }
 
-static inline int cn_dec_block_setup() { return cn_configure_lds((const void*)cn_dec_block_kernel, DB_LDS_BYTES); }
+template <typename HT> static inline int cn_dec_block_setup() { return cn_configure_lds((const void*)cn_dec_block_kernel<HT>, DB_LDS_BYTES); }

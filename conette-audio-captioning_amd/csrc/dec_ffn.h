@@ -1,4 +1,4 @@
-// Fused decoder feed-forward for one new token per row (bf16 operands, d_model 256, d_ff = 256 * NCH):
+// Fused decoder feed-forward for one new token per row (16-bit operands HT = bf16_t | half_t, d_model 256, d_ff = 256 * NCH):
 //
 //   slab[c] = GELU(x W1[c]^T + b1[c]) W2[:, c]^T        c = hidden chunk of 256 columns
 //
@@ -20,8 +20,9 @@
 #define DF_ROWS 32
 #define DF_LDS_BYTES (2 * DF_ROWS * 512 + 1024)
 
-__global__ __launch_bounds__(256, 1) void cn_dec_ffn_kernel(const bf16_t* __restrict__ xt, int R,
-                                                            const bf16_t* __restrict__ stream /* [chunk][2][...] */,
+template <typename HT>
+__global__ __launch_bounds__(256, 1) void cn_dec_ffn_kernel(const HT* __restrict__ xt, int R,
+                                                            const HT* __restrict__ stream /* [chunk][2][...] */,
                                                             const float* __restrict__ b1, float* __restrict__ slabs,
                                                             size_t slab_stride, const int* __restrict__ gate) {
   if (gate != nullptr && *gate == 0) return;  // nothing left to decode at this step
@@ -40,15 +41,15 @@ __global__ __launch_bounds__(256, 1) void cn_dec_ffn_kernel(const bf16_t* __rest
   for (int i = 0; i < 4; ++i) {
     const int piece = wave * 4 + i;
     const int row = 2 * piece + (lane >> 5), cp = lane & 31;
-    const bf16_t* src = xt + (size_t)min(r0 + row, R - 1) * 256 + ((cp ^ (row & G::SWM)) * 8);
+    const HT* src = xt + (size_t)min(r0 + row, R - 1) * 256 + ((cp ^ (row & G::SWM)) * 8);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)(sX + piece * 1024), 16, 0, 0);
   }
   if (wave == 0)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b1 + chunk * 256 + lane * 4),
                                      (__attribute__((address_space(3))) void*)sB, 16, 0, 0);
-  const DbStream wl{stream + (size_t)chunk * 2 * 16 * 4096, (unsigned)(wave * 4 * 4096 + lane * 8) * 2u};
-  bf16x8 fw[4][8];
+  const DbStream wl{(const char*)(stream + (size_t)chunk * 2 * 16 * 4096), (unsigned)(wave * 4 * 4096 + lane * 8) * 2u};
+  cn_h8<HT> fw[4][8];
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
@@ -64,8 +65,8 @@ __global__ __launch_bounds__(256, 1) void cn_dec_ffn_kernel(const bf16_t* __rest
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const int cpos = ((lq + 4 * ks) ^ (lr & G::SWM)) * 16;
-      const bf16x8 f0 = *(const bf16x8*)(sT + lr * G::RBY + cpos);
-      const bf16x8 f1 = *(const bf16x8*)(sT + (16 + lr) * G::RBY + cpos);
+      const cn_h8<HT> f0 = *(const cn_h8<HT>*)(sT + lr * G::RBY + cpos);
+      const cn_h8<HT> f1 = *(const cn_h8<HT>*)(sT + (16 + lr) * G::RBY + cpos);
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         if (refill) {
@@ -82,8 +83,8 @@ __global__ __launch_bounds__(256, 1) void cn_dec_ffn_kernel(const bf16_t* __rest
 #undef DF_WAIT_CASE
           }
         }
-        acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[a][ks], f0, acc[a][0], 0, 0, 0);
-        acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[a][ks], f1, acc[a][1], 0, 0, 0);
+        acc[a][0] = cn_mma16(fw[a][ks], f0, acc[a][0]);
+        acc[a][1] = cn_mma16(fw[a][ks], f1, acc[a][1]);
         if (refill) db_frag_load(fw[a][ks], wl, 1, a, ks);
       }
     }
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256, 1) void cn_dec_ffn_kernel(const bf16_t* __rest
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[j] += bb[j];
       v = cn_gelu_fast4(v);
-      cn_store4((bf16_t*)(sH + row * G::RBY + (((n >> 3) ^ (row & G::SWM)) * 16) + ((n >> 2) & 1) * 8), v[0], v[1], v[2],
+      cn_store4((HT*)(sH + row * G::RBY + (((n >> 3) ^ (row & G::SWM)) * 16) + ((n >> 2) & 1) * 8), v[0], v[1], v[2],
                 v[3]);
     }
   }

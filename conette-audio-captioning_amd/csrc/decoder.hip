@@ -119,6 +119,10 @@ template <> __device__ __forceinline__ f32x4 cn_load4<bf16_t>(const bf16_t* p) {
   return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
 
+template <> __device__ __forceinline__ f32x4 cn_load4<half_t>(const half_t* p) {
+  const cn_h4<half_t> v = *(const cn_h4<half_t>*)p;
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
 template <> __device__ __forceinline__ f32x4 cn_load4<sp16_t>(const sp16_t* p) {
   const u32x4 v = *(const u32x4*)p;
   return f32x4{cn_sp16_value(v[0]), cn_sp16_value(v[1]), cn_sp16_value(v[2]), cn_sp16_value(v[3])};
@@ -855,7 +859,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
       hipLaunchKernelGGL(cn_force_tok_kernel, dim3(cn_cdiv(B, 64)), dim3(64), 0, s, force_caps, B, maxp, step, w.cur_tok);
       CN_LAUNCH_CHECK();
     }
-    const bool block_path = std::is_same<T, bf16_t>::value && !ctx->dec_unfused;
+    const bool block_path = CnIsH16<T>::value && !ctx->dec_unfused;
     // device-side early exit: once every hypothesis of every clip has finished the reference leaves its loop
     // (beam.py:192-194); the launch sequence is static (hipGraph), so the heavy kernels of the remaining steps read the
     // number of rows still searching and return at once
@@ -871,8 +875,8 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
 #else
     constexpr int db_debug = 0;
 #endif
-    if constexpr (std::is_same<T, bf16_t>::value) if (block_path) {
-      // default bf16 path: 3 launches per layer -- fused block (embedding | previous LN3, QKV, self-attention,
+    if constexpr (CnIsH16<T>::value) if (block_path) {
+      // default 16-bit path: 3 launches per layer -- fused block (embedding | previous LN3, QKV, self-attention,
       // cross-attention: dec_block.h), FFN1 GEMM + GELU, FFN2 split-K slabs (summed by the next layer's block
       // prologue; the last layer's by the LN3 kernel in front of the classifier)
       fused_done = true;
@@ -884,8 +888,8 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
       const size_t slab = (size_t)R * d;
       for (int l = 0; l < NL; ++l) {
         const CnLayerW& lw = ctx->layers[l];
-        bf16_t* kc = (bf16_t*)w.kc + (size_t)l * maxp * R * d;
-        bf16_t* vc = (bf16_t*)w.vc + (size_t)l * maxp * R * d;
+        T* kc = (T*)w.kc + (size_t)l * maxp * R * d;
+        T* vc = (T*)w.vc + (size_t)l * maxp * R * d;
         {
           CnProfScope ps(ctx, CONETTE_PROF_DEC_ATTN, s);
           DbPrologue pro;
@@ -896,29 +900,29 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
             pro.slabs = w.slabs, pro.nslab = splits, pro.b2_prev = pw.ff2_b, pro.g3 = pw.n3w, pro.b3 = pw.n3b;
           }
           DbWeights wt;
-          wt.stream = (const bf16_t*)lw.blk_w;
+          wt.stream = lw.blk_w;
           wt.params = lw.blk_p;
-          CN_TRY(cn_dec_block_setup());
-          hipLaunchKernelGGL(cn_dec_block_kernel, dim3(cn_cdiv(R, DB_ROWS)), dim3(DB_THREADS), DB_LDS_BYTES, s, pro, wt, kc, vc,
-                             w.anc, step, R, beam, maxp, (const bf16_t*)kvc, kv_ld, l * 2 * d, frame_lens, Ta, w.x, xt,
+          CN_TRY(cn_dec_block_setup<T>());
+          hipLaunchKernelGGL(cn_dec_block_kernel<T>, dim3(cn_cdiv(R, DB_ROWS)), dim3(DB_THREADS), DB_LDS_BYTES, s, pro, wt, kc, vc,
+                             w.anc, step, R, beam, maxp, (const T*)kvc, kv_ld, l * 2 * d, frame_lens, Ta, w.x, xt,
                              scale, kvalid, db_debug, gate);
           CN_LAUNCH_CHECK();
         }
         if (ffn_fused) {
           CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-          hipLaunchKernelGGL(cn_dec_ffn_kernel, dim3(cn_cdiv(R, DF_ROWS), dff / 256), dim3(256), 0, s, (const bf16_t*)xt, R,
-                             (const bf16_t*)lw.ffn_w, lw.ff1_b, w.slabs, slab, gate);
+          hipLaunchKernelGGL(cn_dec_ffn_kernel<T>, dim3(cn_cdiv(R, DF_ROWS), dff / 256), dim3(256), 0, s, (const T*)xt, R,
+                             (const T*)lw.ffn_w, lw.ff1_b, w.slabs, slab, gate);
           CN_LAUNCH_CHECK();
         } else {
           {
             CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-            EpiBiasAct<bf16_t, ACT_GELU_FAST> e1{lw.ff1_b, ffh, dff, ACT_GELU_FAST};
-            CN_TRY(cn_gemm2(xt, d, (const bf16_t*)lw.ff1_w, d, R, dff, d, e1, s));
+            EpiBiasAct<T, ACT_GELU_FAST> e1{lw.ff1_b, ffh, dff, ACT_GELU_FAST};
+            CN_TRY(cn_gemm2(xt, d, (const T*)lw.ff1_w, d, R, dff, d, e1, s));
           }
           {
             CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
             EpiSlab e2{w.slabs, d, slab};
-            CN_TRY(cn_gemm2(ffh, dff, (const bf16_t*)lw.ff2_w, dff, R, d, dff, e2, s, splits));
+            CN_TRY(cn_gemm2(ffh, dff, (const T*)lw.ff2_w, dff, R, d, dff, e2, s, splits));
           }
         }
       }
@@ -932,7 +936,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
       {
         CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
         EpiBiasAct<float, ACT_NONE> ec{ctx->cls_b, w.logits, w.ldv, ACT_NONE};
-        CN_TRY(cn_gemm2(xt, d, (const bf16_t*)ctx->cls_w, d, R, V, d, ec, s));
+        CN_TRY(cn_gemm2(xt, d, (const T*)ctx->cls_w, d, R, V, d, ec, s));
       }
     }
     if (!fused_done) {
@@ -989,14 +993,14 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
           EpiBiasAct<T, CnGeluAct<T>::value> e1{lw.ff1_b, ffh, dff, CnGeluAct<T>::value};
           CN_TRY(cn_mm(xt, d, (const T*)lw.ff1_w, d, R, dff, d, e1, s));
         }
-        if constexpr (std::is_same<T, bf16_t>::value) {
+        if constexpr (CnIsH16<T>::value) {
           // K = d_ff is long and M = R is small: split K over blockIdx.y into partial slabs, summed
           // (fixed order, with bias + residual) by the LayerNorm kernel that follows
           const int splits = (dff % (FF2_SPLITS * 64) == 0) ? FF2_SPLITS : 1;
           {
             CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
             EpiSlab e2{w.slabs, d, (size_t)R * d};
-            CN_TRY(cn_gemm2(ffh, dff, (const bf16_t*)lw.ff2_w, dff, R, d, dff, e2, s, splits));
+            CN_TRY(cn_gemm2(ffh, dff, (const T*)lw.ff2_w, dff, R, d, dff, e2, s, splits));
           }
           CnProfScope ps(ctx, CONETTE_PROF_DEC_MISC, s);
           hipLaunchKernelGGL((cn_ln256_kernel<T>), dim3(rblocks), dim3(256), 0, s, w.slabs, splits, (size_t)R * d,
@@ -1185,17 +1189,9 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
   }
   hipStream_t s = (hipStream_t)stream;
   auto run = [&]() -> int {
-    if (ctx->cfg.precision == CONETTE_PREC_BF16 || ctx->cfg.precision == CONETTE_PREC_FP8)
-      return decode_impl<bf16_t>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, beam, min_pred,
+    CN_BY_PRECISION(ctx, decode_impl<OT>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, beam, min_pred,
                                  max_pred, best_preds, best_lprobs, mult_preds, mult_lprobs, out_sizes, step0_logits,
-                                 trace_sel, trace_val, (char*)workspace, s);
-    if (ctx->cfg.precision == CONETTE_PREC_F16X2)
-      return decode_impl<sp16_t>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, beam, min_pred,
-                              max_pred, best_preds, best_lprobs, mult_preds, mult_lprobs, out_sizes, step0_logits,
-                              trace_sel, trace_val, (char*)workspace, s);
-    return decode_impl<float>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, beam, min_pred,
-                              max_pred, best_preds, best_lprobs, mult_preds, mult_lprobs, out_sizes, step0_logits,
-                              trace_sel, trace_val, (char*)workspace, s);
+                                 trace_sel, trace_val, (char*)workspace, s));
   };
   DecGraphCache* cache = graph_cache(ctx, true);
   const uint32_t dec_classes = (1u << CONETTE_PROF_DEC_PREPARE) | (1u << CONETTE_PROF_DEC_GEMM) |
@@ -1461,12 +1457,8 @@ extern "C" int conette_forcing(conette_ctx* ctx, const float* frame_embs, const 
   }
   hipStream_t s = (hipStream_t)stream;
   if (!ctx->forcing_stepwise) {  // default: one causal pass over all caption positions
-    if (ctx->cfg.precision == CONETTE_PREC_BF16 || ctx->cfg.precision == CONETTE_PREC_FP8)
-      return forcing_prefill_impl<bf16_t>(ctx, frame_embs, frame_lens, caps_in, batch, t_audio, cap_len, logits,
-                                          (char*)workspace, s);
-    if (ctx->cfg.precision == CONETTE_PREC_F16X2)
-      return forcing_prefill_impl<sp16_t>(ctx, frame_embs, frame_lens, caps_in, batch, t_audio, cap_len, logits, (char*)workspace, s);
-    return forcing_prefill_impl<float>(ctx, frame_embs, frame_lens, caps_in, batch, t_audio, cap_len, logits, (char*)workspace, s);
+    CN_BY_PRECISION(ctx, forcing_prefill_impl<OT>(ctx, frame_embs, frame_lens, caps_in, batch, t_audio, cap_len, logits,
+                                          (char*)workspace, s));
   }
   // CONETTE_OPT_FORCING_STEPWISE: the KV-cached step kernels fed with the caption (cross-check of the pass above)
   // outputs of the search bookkeeping that a forced pass does not produce: parked in the workspace tail
@@ -1477,17 +1469,9 @@ extern "C" int conette_forcing(conette_ctx* ctx, const float* frame_embs, const 
   int32_t* sizes = (int32_t*)tail;
   int32_t* bos = sizes + 2;  // init kernel input; any valid ids: column 0 of the captions
   (void)bos;
-  if (ctx->cfg.precision == CONETTE_PREC_BF16 || ctx->cfg.precision == CONETTE_PREC_FP8)
-    return decode_impl<bf16_t>(ctx, frame_embs, frame_lens, caps_in, nullptr, batch, t_audio, 1, 0, cap_len, mult_preds,
+  CN_BY_PRECISION(ctx, decode_impl<OT>(ctx, frame_embs, frame_lens, caps_in, nullptr, batch, t_audio, 1, 0, cap_len, mult_preds,
                                mult_lprobs, mult_preds, mult_lprobs, sizes, nullptr, nullptr, nullptr, (char*)workspace, s,
-                               caps_in, logits);
-  if (ctx->cfg.precision == CONETTE_PREC_F16X2)
-    return decode_impl<sp16_t>(ctx, frame_embs, frame_lens, caps_in, nullptr, batch, t_audio, 1, 0, cap_len, mult_preds,
-                            mult_lprobs, mult_preds, mult_lprobs, sizes, nullptr, nullptr, nullptr, (char*)workspace, s,
-                            caps_in, logits);
-  return decode_impl<float>(ctx, frame_embs, frame_lens, caps_in, nullptr, batch, t_audio, 1, 0, cap_len, mult_preds,
-                            mult_lprobs, mult_preds, mult_lprobs, sizes, nullptr, nullptr, nullptr, (char*)workspace, s,
-                            caps_in, logits);
+                               caps_in, logits));
 }
 
 extern "C" int conette_greedy(conette_ctx* ctx, const float* frame_embs, const int32_t* frame_lens, const int32_t* bos_ids,
@@ -1518,17 +1502,9 @@ extern "C" int conette_greedy(conette_ctx* ctx, const float* frame_embs, const i
   int32_t* mult_preds = (int32_t*)tail;  // beam 1: the single hypothesis of every clip
   float* mult_lprobs = (float*)(tail + cn_align((size_t)batch * max_pred * 4));
   float* best_lprobs = (float*)(tail + cn_align((size_t)batch * max_pred * 4) + cn_align((size_t)batch * 4));
-  if (ctx->cfg.precision == CONETTE_PREC_BF16 || ctx->cfg.precision == CONETTE_PREC_FP8)
-    return decode_impl<bf16_t>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, 1, min_pred, max_pred, preds,
+  CN_BY_PRECISION(ctx, decode_impl<OT>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, 1, min_pred, max_pred, preds,
                                best_lprobs, mult_preds, mult_lprobs, out_sizes, nullptr, nullptr, nullptr, (char*)workspace,
-                               s, nullptr, nullptr, logits);
-  if (ctx->cfg.precision == CONETTE_PREC_F16X2)
-    return decode_impl<sp16_t>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, 1, min_pred, max_pred, preds,
-                            best_lprobs, mult_preds, mult_lprobs, out_sizes, nullptr, nullptr, nullptr, (char*)workspace, s,
-                            nullptr, nullptr, logits);
-  return decode_impl<float>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, 1, min_pred, max_pred, preds,
-                            best_lprobs, mult_preds, mult_lprobs, out_sizes, nullptr, nullptr, nullptr, (char*)workspace, s,
-                            nullptr, nullptr, logits);
+                               s, nullptr, nullptr, logits));
 }
 
 extern "C" size_t conette_greedy_workspace_bytes(const conette_ctx* ctx, int32_t batch, int32_t t_audio, int32_t max_pred) {

@@ -1,4 +1,4 @@
-// Fused downsample layer (bf16), stage 0 -> 1:   LayerNorm(channels_first, eps 1e-6) + Conv2d(C -> 2C, k 2x2, s 2)
+// Fused downsample layer (16-bit operands HT = bf16_t | half_t), stage 0 -> 1:   LayerNorm(channels_first, eps 1e-6) + Conv2d(C -> 2C, k 2x2, s 2)
 //     x fp32 (B, H, W, C)  ->  out fp32 (B, H/2, W/2, 2C)                        (reference convnext.py:207-217)
 //
 // The two-kernel form (cn_ln_patchify_kernel writes the bf16 patch matrix, cn_gemm2 reads it back) moves the patch matrix
@@ -22,8 +22,9 @@ template <int CP> struct DownGeom {
 };
 
 // src: Conv2d weight (N, C, 2, 2) fp32; g, b: LayerNorm weight / bias (C); bias (N)
+template <typename HT>
 static __global__ void pk_down_fused(const float* __restrict__ src, const float* __restrict__ g, const float* __restrict__ b,
-                                     const float* __restrict__ bias, int N, int C, bf16_t* __restrict__ dst) {
+                                     const float* __restrict__ bias, int N, int C, HT* __restrict__ dst) {
   const int K = 4 * C, KS = K / 16, NT = N / 32;
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u < N) {  // bias' behind the stream
@@ -37,16 +38,16 @@ static __global__ void pk_down_fused(const float* __restrict__ src, const float*
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int k = 16 * s + 8 * (l >> 5) + i, kk = k / C, c = k % C;
-    dst[(size_t)u * 8 + i] = (bf16_t)(src[((size_t)n * C + c) * 4 + kk] * g[c]);
+    dst[(size_t)u * 8 + i] = (HT)(src[((size_t)n * C + c) * 4 + kk] * g[c]);
   }
 }
 
 
 // The GEMM operand of a 32-position tile: a[(ip - IP0) * CH + j] = bf16((x - mean) rstd) of channels 16 j + 8 (lane >> 5) .. + 8 of
 // input position ip (IP0 <= ip < IP0 + NIP; ip = 2 kh + kw) of output position `tile * 32 + (lane & 31)` (clamped to P - 1).
-template <int CP, int IP0 = 0, int NIP = 4>
+template <int CP, int IP0, int NIP, typename HT>
 static __device__ __forceinline__ void cn_down_operand(const float* __restrict__ X, int H, int W, long P, long tile, int lane,
-                                                       bf16x8 (&a)[NIP * DownGeom<CP>::CH]) {
+                                                       cn_h8<HT> (&a)[NIP * DownGeom<CP>::CH]) {
   constexpr int CH = DownGeom<CP>::CH;
   const int H2 = H / 2, W2 = W / 2, hh = lane >> 5;
     // ---- operand: 4 input positions x CH fragments ----------------------------------------------------------------
@@ -90,8 +91,8 @@ static __device__ __forceinline__ void cn_down_operand(const float* __restrict__
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
         const f32x4 lo = d[j][0] * rstd, hi = d[j][1] * rstd;
-        a[ii * CH + j] = bf16x8{(bf16_t)lo[0], (bf16_t)lo[1], (bf16_t)lo[2], (bf16_t)lo[3],
-                                (bf16_t)hi[0], (bf16_t)hi[1], (bf16_t)hi[2], (bf16_t)hi[3]};
+        a[ii * CH + j] = cn_h8<HT>{(HT)lo[0], (HT)lo[1], (HT)lo[2], (HT)lo[3],
+                                (HT)hi[0], (HT)hi[1], (HT)hi[2], (HT)hi[3]};
       }
     }
 }
@@ -120,30 +121,30 @@ static __device__ __forceinline__ void cn_down_store(float* __restrict__ OUT, co
 
 // MFMA q = s NT + t of a tile consumes fragment q of the packed stream; a rolling window of PRE fragments is in flight.
 // (Left to the scheduler, all 144 LDS reads are hoisted to the top and ~500 registers spill.)
-template <int CP> struct DownMma {
+template <int CP, typename HT> struct DownMma {
   typedef DownGeom<CP> G;
   static constexpr int NM = G::KS * G::NT, PRE = 6, R = PRE + 1;
   template <int Q>
-  static __device__ __forceinline__ void step(const char* wl, const bf16x8 (&a)[G::KS], f32x16 (&acc)[G::NT], bf16x8 (&f)[R]) {
-    if constexpr (Q + PRE < NM) f[(Q + PRE) % R] = *(const bf16x8*)(wl + (Q + PRE) * 1024);
+  static __device__ __forceinline__ void step(const char* wl, const cn_h8<HT> (&a)[G::KS], f32x16 (&acc)[G::NT], cn_h8<HT> (&f)[R]) {
+    if constexpr (Q + PRE < NM) f[(Q + PRE) % R] = *(const cn_h8<HT>*)(wl + (Q + PRE) * 1024);
     constexpr int s = Q / G::NT, t = Q % G::NT;
-    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], f[Q % R], acc[t], 0, 0, 0);
+    acc[t] = cn_mma32(a[s], f[Q % R], acc[t]);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (Q + 1 < NM) step<Q + 1>(wl, a, acc, f);
   }
   template <int Q>
-  static __device__ __forceinline__ void run(const char* wl, const bf16x8 (&a)[G::KS], f32x16 (&acc)[G::NT]) {
-    bf16x8 f[R];
+  static __device__ __forceinline__ void run(const char* wl, const cn_h8<HT> (&a)[G::KS], f32x16 (&acc)[G::NT]) {
+    cn_h8<HT> f[R];
 #pragma unroll
-    for (int q = 0; q < PRE; ++q) f[q] = *(const bf16x8*)(wl + q * 1024);
+    for (int q = 0; q < PRE; ++q) f[q] = *(const cn_h8<HT>*)(wl + q * 1024);
     __builtin_amdgcn_sched_barrier(0);
     step<0>(wl, a, acc, f);
   }
 };
 
-template <int CP, int NW>
+template <int CP, int NW, typename HT>
 __global__ __launch_bounds__(NW * 64) void cn_down_fused_kernel(const float* __restrict__ X, int H, int W, long P,
-                                                                const bf16_t* __restrict__ WS, float* __restrict__ OUT) {
+                                                                const HT* __restrict__ WS, float* __restrict__ OUT) {
   typedef DownGeom<CP> G;
   constexpr int KS = G::KS, NT = G::NT, CH = G::CH, N = G::N;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -160,28 +161,28 @@ __global__ __launch_bounds__(NW * 64) void cn_down_fused_kernel(const float* __r
   __syncthreads();
   const char* wl = smem + lane * 16;
   for (long tile = t_lo + wave; tile < t_hi; tile += NW) {
-    bf16x8 a[KS];
-    cn_down_operand<CP>(X, H, W, P, tile, lane, a);
+    cn_h8<HT> a[KS];
+    cn_down_operand<CP, 0, 4, HT>(X, H, W, P, tile, lane, a);
     // ---- C[pos][n] = sum_k a[pos][k] W'[n][k]: positions in the registers' rows, channels on the lanes ------------------
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    DownMma<CP>::template run<0>(wl, a, acc);  // hand-ordered: fragment q + PRE is requested before MFMA q (see mlp_rc2.h)
+    DownMma<CP, HT>::template run<0>(wl, a, acc);  // hand-ordered: fragment q + PRE is requested before MFMA q (see mlp_rc2.h)
     cn_down_store<CP>(OUT, biasp, P, tile, lane, acc);
   }
 }
 
-template <int CP, int NW>
+template <int CP, int NW, typename HT>
 static int cn_launch_down_fused(const float* X, int B, int H, int W, const void* WS, float* OUT, int n_blocks, hipStream_t s) {
   typedef DownGeom<CP> G;
   constexpr int SMEM = (int)G::STREAM_BYTES;
   static_assert(SMEM <= 160 * 1024, "the packed weights must fit in LDS");
   const long P = (long)B * (H / 2) * (W / 2);
-  CN_TRY(cn_configure_lds((const void*)cn_down_fused_kernel<CP, NW>, SMEM));
+  CN_TRY(cn_configure_lds((const void*)cn_down_fused_kernel<CP, NW, HT>, SMEM));
   const int grid = cn_rc2_grid((int)((P + 31) / 32), NW, n_blocks);
-  hipLaunchKernelGGL((cn_down_fused_kernel<CP, NW>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, X, H, W, P, (const bf16_t*)WS, OUT);
+  hipLaunchKernelGGL((cn_down_fused_kernel<CP, NW, HT>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, X, H, W, P, (const HT*)WS, OUT);
   CN_LAUNCH_CHECK();
   return CN_OK;
 }
@@ -192,7 +193,7 @@ static int cn_launch_down_fused(const float* X, int B, int H, int W, const void*
 // operand fragment a[s] must be a compile-time register choice.  NSTEP is a multiple of NST, so the slot of step J of a
 // tile is J % NST.  The vmcnt discipline is mlp_rc2.h's: the operand loads and the stores of a tile sit in the same
 // in-order queue and only make a wait stricter.
-template <int CP, int NW, int KSTEP, int NST> struct DownRing {
+template <int CP, int NW, int KSTEP, int NST, typename HT> struct DownRing {
   typedef DownGeom<CP> G;
   static constexpr int NT = G::NT, KS = G::KS, NSTEP = KS / KSTEP, FR = KSTEP * NT, SB = FR * 1024;
   static constexpr int DPW = FR / NW, PRE = 6, R = PRE + 1;
@@ -211,25 +212,25 @@ template <int CP, int NW, int KSTEP, int NST> struct DownRing {
   static constexpr int HS = NSTEP / 2;  // steps per half tile (input positions 0, 1 | 2, 3)
   static_assert(NSTEP % 2 == 0 && (KS / 2) % KSTEP == 0, "a half tile is a whole number of steps");
   template <int J, int Q>
-  static __device__ __forceinline__ void mma(const char* wl, const bf16x8 (&a)[KS / 2], f32x16 (&acc)[NT], bf16x8 (&f)[R]) {
-    if constexpr (Q + PRE < FR) f[(Q + PRE) % R] = *(const bf16x8*)(wl + (Q + PRE) * 1024);
+  static __device__ __forceinline__ void mma(const char* wl, const cn_h8<HT> (&a)[KS / 2], f32x16 (&acc)[NT], cn_h8<HT> (&f)[R]) {
+    if constexpr (Q + PRE < FR) f[(Q + PRE) % R] = *(const cn_h8<HT>*)(wl + (Q + PRE) * 1024);
     constexpr int s = (J % HS) * KSTEP + Q / NT, t = Q % NT;
-    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], f[Q % R], acc[t], 0, 0, 0);
+    acc[t] = cn_mma32(a[s], f[Q % R], acc[t]);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (Q + 1 < FR) mma<J, Q + 1>(wl, a, acc, f);
   }
   // steps J .. JE - 1 of a tile (one half)
   template <int J, int JE>
   static __device__ __forceinline__ void steps(const char* wsrc, char* smem, int wave, int lane, int g0, bool valid,
-                                               const bf16x8 (&a)[KS / 2], f32x16 (&acc)[NT]) {
+                                               const cn_h8<HT> (&a)[KS / 2], f32x16 (&acc)[NT]) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * DPW) : "memory");
     __builtin_amdgcn_s_barrier();
     stage(wsrc, smem, wave, g0 + J + NST - 1);
     if (valid) {
       const char* wl = smem + (J % NST) * SB + lane * 16;
-      bf16x8 f[R];
+      cn_h8<HT> f[R];
 #pragma unroll
-      for (int q = 0; q < PRE; ++q) f[q] = *(const bf16x8*)(wl + q * 1024);
+      for (int q = 0; q < PRE; ++q) f[q] = *(const cn_h8<HT>*)(wl + q * 1024);
       __builtin_amdgcn_sched_barrier(0);
       mma<J, 0>(wl, a, acc, f);
     }
@@ -237,11 +238,11 @@ template <int CP, int NW, int KSTEP, int NST> struct DownRing {
   }
 };
 
-template <int CP, int NW, int KSTEP, int NST>
+template <int CP, int NW, int KSTEP, int NST, typename HT>
 __global__ __launch_bounds__(NW * 64) void cn_down_fused_ring_kernel(const float* __restrict__ X, int H, int W, long P,
-                                                                     const bf16_t* __restrict__ WS, float* __restrict__ OUT) {
+                                                                     const HT* __restrict__ WS, float* __restrict__ OUT) {
   typedef DownGeom<CP> G;
-  typedef DownRing<CP, NW, KSTEP, NST> K;
+  typedef DownRing<CP, NW, KSTEP, NST, HT> K;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -262,10 +263,10 @@ __global__ __launch_bounds__(NW * 64) void cn_down_fused_ring_kernel(const float
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     {  // K in two halves: the operand of two input positions (96 registers) at a time
-      bf16x8 a[G::KS / 2];
-      cn_down_operand<CP, 0, 2>(X, H, W, P, ltile, lane, a);
+      cn_h8<HT> a[G::KS / 2];
+      cn_down_operand<CP, 0, 2, HT>(X, H, W, P, ltile, lane, a);
       K::template steps<0, K::HS>(wsrc, smem, wave, lane, it * K::NSTEP, valid, a, acc);
-      cn_down_operand<CP, 2, 2>(X, H, W, P, ltile, lane, a);
+      cn_down_operand<CP, 2, 2, HT>(X, H, W, P, ltile, lane, a);
       K::template steps<K::HS, K::NSTEP>(wsrc, smem, wave, lane, it * K::NSTEP, valid, a, acc);
     }
     if (valid) cn_down_store<CP>(OUT, biasp, P, tile, lane, acc);
@@ -273,15 +274,15 @@ __global__ __launch_bounds__(NW * 64) void cn_down_fused_ring_kernel(const float
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring was filled NST - 1 entries past the end
 }
 
-template <int CP, int NW, int KSTEP, int NST>
+template <int CP, int NW, int KSTEP, int NST, typename HT>
 static int cn_launch_down_fused_ring(const float* X, int B, int H, int W, const void* WS, float* OUT, int n_blocks, hipStream_t s) {
-  typedef DownRing<CP, NW, KSTEP, NST> K;
+  typedef DownRing<CP, NW, KSTEP, NST, HT> K;
   static_assert(K::SMEM <= 160 * 1024, "ring must fit in LDS");
   const long P = (long)B * (H / 2) * (W / 2);
-  CN_TRY(cn_configure_lds((const void*)cn_down_fused_ring_kernel<CP, NW, KSTEP, NST>, K::SMEM));
+  CN_TRY(cn_configure_lds((const void*)cn_down_fused_ring_kernel<CP, NW, KSTEP, NST, HT>, K::SMEM));
   const int grid = cn_rc2_grid((int)((P + 31) / 32), NW, n_blocks);
-  hipLaunchKernelGGL((cn_down_fused_ring_kernel<CP, NW, KSTEP, NST>), dim3((unsigned)grid), dim3(NW * 64), K::SMEM, s, X, H, W, P,
-                     (const bf16_t*)WS, OUT);
+  hipLaunchKernelGGL((cn_down_fused_ring_kernel<CP, NW, KSTEP, NST, HT>), dim3((unsigned)grid), dim3(NW * 64), K::SMEM, s, X, H, W, P,
+                     (const HT*)WS, OUT);
   CN_LAUNCH_CHECK();
   return CN_OK;
 }

@@ -758,16 +758,19 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
       const long n_in = (long)B * Hp * Wp;
       const CnDownW& dw = ctx->down[st - 1];
       CnProfScope ps(ctx, CONETTE_PROF_DOWNSAMPLE, s);
-      if (std::is_same<T, bf16_t>::value && Cp <= 192 && dw.fused != nullptr) {
+      bool fused_down = false;
+      if constexpr (CnIsH16<T>::value) if (Cp <= 192 && dw.fused != nullptr) {
         // LayerNorm + patch GEMM in one kernel (down_fused.h).  It cannot run in place: the residual stream moves to the
         // other of ws.x / ws.h (stages 0-2 run the fused MLP in bf16, so the hidden buffer is free until stage 3).
         float* xo = xc == ws.x ? (float*)ws.h : ws.x;
         const int nb = ctx->n_cu - ctx->enc_reserved_cus;
-        if (Cp == 96) CN_TRY((cn_launch_down_fused<96, 8>(xc, B, Hp, Wp, dw.fused, xo, nb, s)));
-        else CN_TRY((cn_launch_down_fused_ring<192, 4, 4, 3>(xc, B, Hp, Wp, dw.fused, xo, nb, s)));
+        if (Cp == 96) CN_TRY((cn_launch_down_fused<96, 8, T>(xc, B, Hp, Wp, dw.fused, xo, nb, s)));
+        else CN_TRY((cn_launch_down_fused_ring<192, 4, 4, 3, T>(xc, B, Hp, Wp, dw.fused, xo, nb, s)));
         xc = xo;
         if (taps) CN_TRY(tap_copy(taps->down[st], xc, (size_t)P * C, s));
-      } else {
+        fused_down = true;
+      }
+      if (!fused_down) {
       const int ppb = Cp == 96 ? 32 : 16;           // positions per block: 4 waves x 4 groups x (2 | 1) positions
       const dim3 pg((unsigned)((n_in + ppb - 1) / ppb));
       if (Cp == 96)
@@ -811,11 +814,11 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
           fused = true;
         }
       }
-      if constexpr (std::is_same<T, bf16_t>::value) if (!fused) {
+      if constexpr (CnIsH16<T>::value) if (!fused) {
         // stages 0-2: register-chained fused MLP (mlp_rc2.h): the 4C hidden never leaves the registers; timed under PW1
         if (bw.mlp_stream != nullptr && C <= 384) {
           CnProfScope ps(ctx, CONETTE_PROF_PW1_GEMM, s);
-          const bf16_t* wsm = (const bf16_t*)bw.mlp_stream;
+          const T* wsm = (const T*)bw.mlp_stream;
           if (C == 96) CN_TRY((cn_launch_mlp_rc2_resident<96, 12, 1>(y, wsm, xc, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
           else if (C == 192) CN_TRY((cn_launch_mlp_rc2_ring<192, 8, CN_RC2_NCK(192), CN_RC2_NCK(192) == 2 ? 3 : 5>(y, wsm, xc, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
 #ifdef CN_NO_RS  // A/B builds only (tools/lab/ab.sh): round 2's chained kernel at stage 2
@@ -895,12 +898,6 @@ extern "C" int conette_encode(conette_ctx* ctx, const float* wave, int32_t batch
     cn_set_error("encode: workspace %zu < %zu", workspace_bytes, need);
     return CN_ERR_WORKSPACE;
   }
-  if (ctx->cfg.precision == CONETTE_PREC_BF16 || ctx->cfg.precision == CONETTE_PREC_FP8)
-    return encode_impl<bf16_t>(ctx, wave, batch, n_samples, frame_embs, clip_probs, taps, (char*)workspace,
-                               (hipStream_t)stream);
-  if (ctx->cfg.precision == CONETTE_PREC_F16X2)
-    return encode_impl<sp16_t>(ctx, wave, batch, n_samples, frame_embs, clip_probs, taps, (char*)workspace,
-                               (hipStream_t)stream);
-  return encode_impl<float>(ctx, wave, batch, n_samples, frame_embs, clip_probs, taps, (char*)workspace,
-                            (hipStream_t)stream);
+  CN_BY_PRECISION(ctx, encode_impl<OT>(ctx, wave, batch, n_samples, frame_embs, clip_probs, taps, (char*)workspace,
+                               (hipStream_t)stream));
 }

@@ -29,6 +29,7 @@ enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3, ACT_GELU_FAST 
 // (sp16) mode, the A&S form of cn_gelu_fast in bf16
 template <typename T> struct CnGeluAct { static constexpr int value = ACT_GELU; };
 template <> struct CnGeluAct<bf16_t> { static constexpr int value = ACT_GELU_FAST; };
+template <> struct CnGeluAct<half_t> { static constexpr int value = ACT_GELU_FAST; };
 template <> struct CnGeluAct<sp16_t> { static constexpr int value = ACT_GELU_AS; };
 
 // out[m][n] = act(acc + bias[n])

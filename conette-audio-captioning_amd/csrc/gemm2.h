@@ -23,6 +23,8 @@
 #pragma once
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gemm.h"
 
 // out[ks][m][n] = acc  (partial sums of one K slice; bias / residual are added by the consumer)
@@ -66,7 +68,7 @@ template <int BK> struct G2Geom {
 
 // all MFMAs of one staged k-tile: acc[a][b] += W-tile(a) . A-tile(b)^T
 // (WM x WN waves per block, each owning a (BM / WM) x (BN / WN) sub-tile: 2 x 2 everywhere but the 256 x 256 tiles, 2 x 4)
-template <int BM, int BN, int BK, int WM = 2, int WN = 2>
+template <int BM, int BN, int BK, int WM = 2, int WN = 2, typename HT = bf16_t>
 __device__ __forceinline__ void cn_g2_compute(const char* sA, const char* sW, int lane, int wm, int wn,
                                               f32x4 (&acc)[BN / (16 * WN)][BM / (16 * WM)]) {
   typedef G2Geom<BK> G;
@@ -77,15 +79,15 @@ __device__ __forceinline__ void cn_g2_compute(const char* sA, const char* sW, in
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     const int coff = (((lane >> 4) + 4 * ks) ^ sw) * 16;
-    bf16x8 fw[TN], fa[TM];
+    cn_h8<HT> fw[TN], fa[TM];
 #pragma unroll
-    for (int a = 0; a < TN; ++a) fw[a] = *(const bf16x8*)(sW + (wn * (BN / WN) + a * 16) * G::RBY + row_off + coff);
+    for (int a = 0; a < TN; ++a) fw[a] = *(const cn_h8<HT>*)(sW + (wn * (BN / WN) + a * 16) * G::RBY + row_off + coff);
 #pragma unroll
-    for (int b = 0; b < TM; ++b) fa[b] = *(const bf16x8*)(sA + (wm * (BM / WM) + b * 16) * G::RBY + row_off + coff);
+    for (int b = 0; b < TM; ++b) fa[b] = *(const cn_h8<HT>*)(sA + (wm * (BM / WM) + b * 16) * G::RBY + row_off + coff);
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
-      for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[a], fa[b], acc[a][b], 0, 0, 0);
+      for (int b = 0; b < TM; ++b) acc[a][b] = cn_mma16(fw[a], fa[b], acc[a][b]);
   }
 }
 
@@ -239,9 +241,10 @@ __device__ __forceinline__ void cn_g2_epilogue(char* smem, f32x4 (&acc)[BN / (16
   }
 }
 
-// SP: the operands are sp16 matrices handed over as bf16-sized columns (lda, ldw, K, k_slice all doubled by the launcher):
+// OPK = the operand kind of the staged bytes: 0 bf16, 1 sp16, 2 fp16 (the kernel takes them as 2-byte columns either way).
+// sp16: the operands are sp16 matrices handed over as bf16-sized columns (lda, ldw, K, k_slice all doubled by the launcher):
 // staging is byte-for-byte the bf16 path, only the fragment reads / MFMAs of a k-tile differ (cn_g2_compute_sp)
-template <int BM, int BN, int BK, int NST, class Epi, int WM = 2, int WN = 2, bool SP = false>
+template <int BM, int BN, int BK, int NST, class Epi, int WM = 2, int WN = 2, int OPK = 0>
 __global__ __launch_bounds__(WM * WN * 64) void cn_gemm2_kernel(const bf16_t* __restrict__ A, int lda,
                                                        const bf16_t* __restrict__ W, int ldw, int M, int N, int K,
                                                        int k_slice, Epi epi, int dbg) {
@@ -312,8 +315,8 @@ __global__ __launch_bounds__(WM * WN * 64) void cn_gemm2_kernel(const bf16_t* __
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
-      if constexpr (SP) cn_g2_compute_sp<BM, BN, BK, WM, WN>(smem, smem + A_BYTES, lane, wm, wn, acc);
-      else cn_g2_compute<BM, BN, BK, WM, WN>(smem, smem + A_BYTES, lane, wm, wn, acc);
+      if constexpr (OPK == 1) cn_g2_compute_sp<BM, BN, BK, WM, WN>(smem, smem + A_BYTES, lane, wm, wn, acc);
+      else cn_g2_compute<BM, BN, BK, WM, WN, typename std::conditional<OPK == 2, half_t, bf16_t>::type>(smem, smem + A_BYTES, lane, wm, wn, acc);
       if (kt + 1 < KT) {
         __syncthreads();
         stage(0, kt + 1);
@@ -354,8 +357,8 @@ __global__ __launch_bounds__(WM * WN * 64) void cn_gemm2_kernel(const bf16_t* __
       if (!(dbg & 4))
 #endif
       {
-        if constexpr (SP) cn_g2_compute_sp<BM, BN, BK, WM, WN>(sA, sA + A_BYTES, lane, wm, wn, acc);
-        else cn_g2_compute<BM, BN, BK, WM, WN>(sA, sA + A_BYTES, lane, wm, wn, acc);
+        if constexpr (OPK == 1) cn_g2_compute_sp<BM, BN, BK, WM, WN>(sA, sA + A_BYTES, lane, wm, wn, acc);
+        else cn_g2_compute<BM, BN, BK, WM, WN, typename std::conditional<OPK == 2, half_t, bf16_t>::type>(sA, sA + A_BYTES, lane, wm, wn, acc);
       }
       G2_STAMP(3)
     }
@@ -399,16 +402,16 @@ static inline int g2_debug_skip() { return 0; }
 static inline int g2_debug_epi() { return 0; }
 #endif
 
-template <int BM, int BN, int BK, int NST, class Epi, int WM = 2, int WN = 2, bool SP = false>
+template <int BM, int BN, int BK, int NST, class Epi, int WM = 2, int WN = 2, int OPK = 0>
 static int cn_launch_gemm2_t(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, int splits,
                              const Epi& epi, hipStream_t stream) {
   constexpr int EPI_BYTES = sizeof(typename Epi::stage_t) == 4 ? 0 : BM * (BN * 2 + 16);
   constexpr int PIPE_BYTES = NST * (BM + BN) * BK * 2;
   constexpr int SMEM = PIPE_BYTES > EPI_BYTES ? PIPE_BYTES : EPI_BYTES;
-  CN_TRY(cn_configure_lds((const void*)cn_gemm2_kernel<BM, BN, BK, NST, Epi, WM, WN, SP>, SMEM));
+  CN_TRY(cn_configure_lds((const void*)cn_gemm2_kernel<BM, BN, BK, NST, Epi, WM, WN, OPK>, SMEM));
   const long blocks = (long)cn_cdiv(M, BM) * cn_cdiv(N, BN);
   const int k_slice = K / splits;
-  hipLaunchKernelGGL((cn_gemm2_kernel<BM, BN, BK, NST, Epi, WM, WN, SP>), dim3((unsigned)blocks, (unsigned)splits), dim3(WM * WN * 64), SMEM,
+  hipLaunchKernelGGL((cn_gemm2_kernel<BM, BN, BK, NST, Epi, WM, WN, OPK>), dim3((unsigned)blocks, (unsigned)splits), dim3(WM * WN * 64), SMEM,
                      stream, A, lda, W, ldw, M, N, K, k_slice, epi, (g2_debug_level() == BM + BN && (g2_debug_epi() == 0 || g2_debug_epi() == (int)sizeof(typename Epi::stage_t)) ? 1 : 0) | g2_debug_skip());
   CN_LAUNCH_CHECK();
   return CN_OK;
@@ -425,8 +428,8 @@ static inline int cn_g2_cus() {  // compute units of the current device (cached)
   return n;
 }
 
-// bf16 dispatch.  splits > 1 only with a slab epilogue; K / splits must be a multiple of 64.
-template <class Epi>
+// bf16 / fp16 dispatch (OPK 0 / 2).  splits > 1 only with a slab epilogue; K / splits must be a multiple of 64.
+template <class Epi, int OPK = 0>
 static int cn_gemm2(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const Epi& epi,
                     hipStream_t stream, int splits = 1) {
   if (K % 32 != 0 || M <= 0 || N <= 0 || splits < 1 || (K / splits) % 64 != 0 && splits > 1) {
@@ -436,8 +439,8 @@ static int cn_gemm2(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, i
   const bool k64 = (K % 64 == 0);
   if (M >= 4096) {
     const bool n96 = (N % 96 == 0) && (N % 128 != 0);
-    if (!k64) return cn_launch_gemm2_t<128, 128, 32, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
-    if (n96) return cn_launch_gemm2_t<128, 96, 64, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+    if (!k64) return cn_launch_gemm2_t<128, 128, 32, 2, Epi, 2, 2, OPK>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+    if (n96) return cn_launch_gemm2_t<128, 96, 64, 2, Epi, 2, 2, OPK>(A, lda, W, ldw, M, N, K, splits, epi, stream);
 #ifndef CN_G2_NO256
     // 256 x 256 tiles, 8 waves (2 x 4), one block per CU: a 128 x 128 tile asks the CU's load path for 512 bytes per MFMA
     // -- all of the ~64 B/clk it delivers when four SIMDs run MFMAs back to back -- this one for 256
@@ -452,16 +455,22 @@ static int cn_gemm2(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, i
       const long ncu = cn_g2_cus(), nt = N / 256;
       const long r256 = cn_cdiv(cn_cdiv(M, 256) * (int)nt, (int)ncu), r224 = cn_cdiv(cn_cdiv(M, 224) * (int)nt, (int)ncu);
       if (r256 == 1 && N % 192 == 0 && cn_cdiv(M, 224) * (N / 192) <= ncu)
-        return cn_launch_gemm2_t<224, 192, 64, 3, Epi, 2, 4>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+        return cn_launch_gemm2_t<224, 192, 64, 3, Epi, 2, 4, OPK>(A, lda, W, ldw, M, N, K, splits, epi, stream);
       if (r256 > 1 && r224 * 224 < r256 * 256)
-        return cn_launch_gemm2_t<224, 256, 64, 2, Epi, 2, 4>(A, lda, W, ldw, M, N, K, splits, epi, stream);
-      return cn_launch_gemm2_t<256, 256, 64, 2, Epi, 2, 4>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+        return cn_launch_gemm2_t<224, 256, 64, 2, Epi, 2, 4, OPK>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+      return cn_launch_gemm2_t<256, 256, 64, 2, Epi, 2, 4, OPK>(A, lda, W, ldw, M, N, K, splits, epi, stream);
     }
 #endif
-    return cn_launch_gemm2_t<128, 128, 64, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+    return cn_launch_gemm2_t<128, 128, 64, 2, Epi, 2, 2, OPK>(A, lda, W, ldw, M, N, K, splits, epi, stream);
   }
-  if (!k64) return cn_launch_gemm2_t<64, 64, 32, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
-  return cn_launch_gemm2_t<64, 64, 64, 2, Epi>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+  if (!k64) return cn_launch_gemm2_t<64, 64, 32, 2, Epi, 2, 2, OPK>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+  return cn_launch_gemm2_t<64, 64, 64, 2, Epi, 2, 2, OPK>(A, lda, W, ldw, M, N, K, splits, epi, stream);
+}
+
+template <class Epi>
+static int cn_gemm2(const half_t* A, int lda, const half_t* W, int ldw, int M, int N, int K, const Epi& epi,
+                    hipStream_t stream, int splits = 1) {
+  return cn_gemm2<Epi, 2>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, epi, stream, splits);
 }
 
 // sp16 dispatch ("exact" precision): K elements of 4 bytes = 2 K bf16-sized columns; K % 32 == 0.  128 x 128 (or 128 x 96)
@@ -478,15 +487,20 @@ static int cn_gemm2_sp(const sp16_t* A, int lda, const sp16_t* W, int ldw, int M
   const bf16_t* w = (const bf16_t*)W;
   if (M >= 4096) {
     const bool n96 = (N % 96 == 0) && (N % 128 != 0);
-    if (n96) return cn_launch_gemm2_t<128, 96, 64, 2, Epi, 2, 2, true>(a, 2 * lda, w, 2 * ldw, M, N, 2 * K, 1, epi, stream);
-    return cn_launch_gemm2_t<128, 128, 64, 2, Epi, 2, 2, true>(a, 2 * lda, w, 2 * ldw, M, N, 2 * K, 1, epi, stream);
+    if (n96) return cn_launch_gemm2_t<128, 96, 64, 2, Epi, 2, 2, 1>(a, 2 * lda, w, 2 * ldw, M, N, 2 * K, 1, epi, stream);
+    return cn_launch_gemm2_t<128, 128, 64, 2, Epi, 2, 2, 1>(a, 2 * lda, w, 2 * ldw, M, N, 2 * K, 1, epi, stream);
   }
-  return cn_launch_gemm2_t<64, 64, 64, 2, Epi, 2, 2, true>(a, 2 * lda, w, 2 * ldw, M, N, 2 * K, splits, epi, stream);
+  return cn_launch_gemm2_t<64, 64, 64, 2, Epi, 2, 2, 1>(a, 2 * lda, w, 2 * ldw, M, N, 2 * K, splits, epi, stream);
 }
 
 // type-generic front end: bf16 -> v2, sp16 -> v2 with split fragments, fp32 -> gemm.h
 template <class Epi>
 static int cn_mm(const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const Epi& epi,
+                 hipStream_t stream) {
+  return cn_gemm2(A, lda, W, ldw, M, N, K, epi, stream);
+}
+template <class Epi>
+static int cn_mm(const half_t* A, int lda, const half_t* W, int ldw, int M, int N, int K, const Epi& epi,
                  hipStream_t stream) {
   return cn_gemm2(A, lda, W, ldw, M, N, K, epi, stream);
 }

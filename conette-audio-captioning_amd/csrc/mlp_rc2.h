@@ -1,4 +1,4 @@
-// Register-chained fused ConvNeXt MLP (bf16), stages 0-2 -- second generation (see mlp_rc.h for the idea):
+// Register-chained fused ConvNeXt MLP (16-bit operands HT = bf16_t | half_t, common.h), stages 0-2 -- second generation (see mlp_rc.h for the idea):
 //
 //     x[m][:] += scale * ( W2 . gelu( W1 . y[m][:] + b1 ) + b2 )          (convnext.py:66-74)
 //
@@ -17,11 +17,6 @@
 // followed by the per-channel vector bb = s b2 (fp32, C).
 #pragma once
 #include "common.h"
-
-#ifndef CN_F32X16
-#define CN_F32X16
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-#endif
 
 template <int C, int NCK> struct Rc2Geom {
   static constexpr int KS1 = C / 16, NT2 = C / 32, NCH = C / 8;
@@ -57,9 +52,10 @@ __device__ __forceinline__ f32x2 cn_gelu_sig2_pk(f32x2 x) {
 }
 
 // ---- packing (fp32 nn.Linear layouts -> fragment stream + aux) ------------------------------------------------------
+template <typename HT>
 static __global__ void pk_mlp_rc2(const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
                            const float* __restrict__ b2, const float* __restrict__ scale, int C, int NCK,
-                           bf16_t* __restrict__ dst) {
+                           HT* __restrict__ dst) {
   const int KS1 = C / 16, NT2 = C / 32, NCH = C / 8, F1 = KS1 + 1, F2 = 2 * NT2, FRAGS = NCK * (F1 + F2), NSTEP = NCH / NCK;
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u < C) ((float*)((char*)dst + (size_t)NSTEP * FRAGS * 1024))[u] = scale[u] * b2[u];  // bb behind the stream
@@ -74,7 +70,7 @@ static __global__ void pk_mlp_rc2(const float* __restrict__ W1, const float* __r
       for (int i = 0; i < 8; ++i) v[i] = W1[(size_t)(32 * j + r) * C + 16 * s + 8 * h + i];
     } else {
       const float b = b1[32 * j + r];
-      const float hi = (float)(bf16_t)b;
+      const float hi = (float)(HT)b;
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = 0.f;
       if (h == 0) {
@@ -91,7 +87,7 @@ static __global__ void pk_mlp_rc2(const float* __restrict__ W1, const float* __r
     for (int i = 0; i < 8; ++i) v[i] = sc * W2[(size_t)c * (4 * C) + 32 * j + 16 * s + 8 * (i >> 2) + 4 * h + (i & 3)];
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) dst[(size_t)u * 8 + i] = (bf16_t)v[i];
+  for (int i = 0; i < 8; ++i) dst[(size_t)u * 8 + i] = (HT)v[i];
 }
 
 // hidden chunks (of 32) per step: two at C = 192 (3-deep ring of 50 KB entries), one elsewhere
@@ -106,20 +102,19 @@ static __global__ void pk_mlp_rc2(const float* __restrict__ W1, const float* __r
 // MFMA of the step loop).  (Lab: issuing piece q INSIDE the step, behind MFMA q by wave q % NW, only moved the ~70 cycles
 // a piece costs its wave from the top of the step into the step, MFMAs or not: 201 us against 189.  profiles/r02_notes.md)
 
-template <int C, int NCK> struct Rc2Wave {
+template <int C, int NCK, typename HT = bf16_t> struct Rc2Wave {
   typedef Rc2Geom<C, NCK> G;
+  typedef cn_h8<HT> hx8;
   static constexpr int KS1 = G::KS1, NT2 = G::NT2, F1 = G::F1, F2 = G::F2;
   static constexpr int NV = 88;  // VALU instructions of the GELU + bf16 packing of 8 accumulator registers (approx.)
 
-  static __device__ __forceinline__ bf16x8 frag(const char* wc, int f) { return *(const bf16x8*)(wc + f * 1024); }
-  static __device__ __forceinline__ f32x16 mma(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ bf16x8 gelu8(const f32x16& X, int o) {
+  static __device__ __forceinline__ hx8 frag(const char* wc, int f) { return *(const hx8*)(wc + f * 1024); }
+  static __device__ __forceinline__ f32x16 mma(hx8 a, hx8 b, f32x16 c) { return cn_mma32(a, b, c); }
+  static __device__ __forceinline__ hx8 gelu8(const f32x16& X, int o) {
     float g[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) g[i] = cn_gelu_sig2(X[o + i]);
-    return bf16x8{(bf16_t)g[0], (bf16_t)g[1], (bf16_t)g[2], (bf16_t)g[3], (bf16_t)g[4], (bf16_t)g[5], (bf16_t)g[6], (bf16_t)g[7]};
+    return cn_sat8<HT>(cn_pack8<HT>(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]));
   }
   static __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
@@ -136,10 +131,10 @@ template <int C, int NCK> struct Rc2Wave {
   static constexpr int PRE = 4;
   static constexpr int NM = NCK * (F1 + F2), R = PRE + 1;
   struct State {
-    bf16x8 F[R];
+    hx8 F[R];
     f32x16 X[NCK];
     float g[NCK][16];
-    bf16x8 H[NCK][2];
+    hx8 H[NCK][2];
   };
   // index of the MFMA behind which GELU element e of chunk i is placed
   static constexpr int gelu_at(int i, int e) {
@@ -161,15 +156,15 @@ template <int C, int NCK> struct Rc2Wave {
 #endif
       if constexpr ((E & 7) == 7) {
         constexpr int o = E - 7;
-        st.H[I][E >> 3] = bf16x8{(bf16_t)st.g[I][o],     (bf16_t)st.g[I][o + 1], (bf16_t)st.g[I][o + 2], (bf16_t)st.g[I][o + 3],
-                                 (bf16_t)st.g[I][o + 4], (bf16_t)st.g[I][o + 5], (bf16_t)st.g[I][o + 6], (bf16_t)st.g[I][o + 7]};
+        st.H[I][E >> 3] = cn_sat8<HT>(cn_pack8<HT>(st.g[I][o], st.g[I][o + 1], st.g[I][o + 2], st.g[I][o + 3],
+                                                   st.g[I][o + 4], st.g[I][o + 5], st.g[I][o + 6], st.g[I][o + 7]));
       }
     }
     if constexpr (E + 1 < 16) gelu_slices<Q, I, E + 1>(st);
     else if constexpr (I + 1 < NCK) gelu_slices<Q, I + 1, 0>(st);
   }
   template <int Q>
-  static __device__ __forceinline__ void mstep(const char* wc, const bf16x8 (&fy)[KS1], const bf16x8 ones, f32x16 (&O)[NT2],
+  static __device__ __forceinline__ void mstep(const char* wc, const hx8 (&fy)[KS1], const hx8 ones, f32x16 (&O)[NT2],
                                                State& st) {
     if constexpr (Q + PRE < NM) st.F[(Q + PRE) % R] = frag(wc, Q + PRE);
     if constexpr (Q < NCK * F1) {
@@ -190,7 +185,7 @@ template <int C, int NCK> struct Rc2Wave {
     st.F[Q % R] = frag(wc, Q);
     if constexpr (Q + 1 < PRE) prefetch<Q + 1>(wc, st);
   }
-  static __device__ __forceinline__ void step(const char* wc, const bf16x8 (&fy)[KS1], const bf16x8 ones, f32x16 (&O)[NT2]) {
+  static __device__ __forceinline__ void step(const char* wc, const hx8 (&fy)[KS1], const hx8 ones, f32x16 (&O)[NT2]) {
     State st;
     prefetch<0>(wc, st);
     __builtin_amdgcn_sched_barrier(0);
@@ -202,11 +197,11 @@ template <int C, int NCK> struct Rc2Wave {
   // past M (the encoder workspace is padded accordingly).
 
   // y rows of a 32-position tile as B fragments: fy[s] = y[m0 + (l & 31)][16 s + 8 (l >> 5) .. + 8]
-  static __device__ __forceinline__ void load_y(const bf16_t* __restrict__ Y, int m0, int lane, bf16x8 (&fy)[KS1]) {
-    const bf16_t* base = Y + (size_t)m0 * C;                 // scalar
+  static __device__ __forceinline__ void load_y(const HT* __restrict__ Y, int m0, int lane, hx8 (&fy)[KS1]) {
+    const HT* base = Y + (size_t)m0 * C;                 // scalar
     const int voff = (lane & 31) * C + 8 * (lane >> 5);      // elements
 #pragma unroll
-    for (int s = 0; s < KS1; ++s) fy[s] = *(const bf16x8*)(base + voff + 16 * s);
+    for (int s = 0; s < KS1; ++s) fy[s] = *(const hx8*)(base + voff + 16 * s);
   }
 
   // O = x: lane = channel 32 t + (l & 31), register r = position (r&3) + 8 (r>>2) + 4 (l>>5)
@@ -250,11 +245,12 @@ static inline int cn_rc2_grid(int n_tiles, int waves_per_block, int max_blocks) 
 }
 
 // ---- resident variant (C = 96): the whole stream (156 KB) lives in LDS; persistent blocks; no barrier, no DMA after the fill
-template <int C, int NW, int NCK>
-__global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_resident_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ WS,
+template <int C, int NW, int NCK, typename HT = bf16_t>
+__global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_resident_kernel(const HT* __restrict__ Y, const HT* __restrict__ WS,
                                                                       float* __restrict__ X, int M) {
   typedef Rc2Geom<C, NCK> G;
-  typedef Rc2Wave<C, NCK> W;
+  typedef Rc2Wave<C, NCK, HT> W;
+  typedef cn_h8<HT> hx8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -265,10 +261,10 @@ __global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_resident_kernel(const bf16
   const float* aux = (const float*)((const char*)WS + G::STREAM_BYTES);
   const int n_tiles = (M + 31) >> 5;
   const int t_lo = (int)((long)blockIdx.x * n_tiles / gridDim.x), t_hi = (int)((long)(blockIdx.x + 1) * n_tiles / gridDim.x);
-  bf16x8 ones;
+  hx8 ones;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)((lane < 32 && i < 2) ? 1.0f : 0.0f);
-  bf16x8 fy[G::KS1];
+  for (int i = 0; i < 8; ++i) ones[i] = (HT)((lane < 32 && i < 2) ? 1.0f : 0.0f);
+  hx8 fy[G::KS1];
   int tile = t_lo + wave;
   if (tile < t_hi) W::load_y(Y, tile * 32, lane, fy);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -284,13 +280,13 @@ __global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_resident_kernel(const bf16
   }
 }
 
-template <int C, int NW, int NCK>
-static int cn_launch_mlp_rc2_resident(const bf16_t* Y, const bf16_t* WS, float* X, int M, int n_blocks, hipStream_t s) {
+template <int C, int NW, int NCK, typename HT>
+static int cn_launch_mlp_rc2_resident(const HT* Y, const HT* WS, float* X, int M, int n_blocks, hipStream_t s) {
   constexpr int SMEM = (int)Rc2Geom<C, NCK>::STREAM_BYTES;
   static_assert(SMEM <= 160 * 1024, "resident variant: the weight stream must fit in LDS");
-  CN_TRY(cn_configure_lds((const void*)cn_mlp_rc2_resident_kernel<C, NW, NCK>, SMEM));
+  CN_TRY(cn_configure_lds((const void*)cn_mlp_rc2_resident_kernel<C, NW, NCK, HT>, SMEM));
   const int grid = cn_rc2_grid((M + 31) / 32, NW, n_blocks);
-  hipLaunchKernelGGL((cn_mlp_rc2_resident_kernel<C, NW, NCK>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, Y, WS, X, M);
+  hipLaunchKernelGGL((cn_mlp_rc2_resident_kernel<C, NW, NCK, HT>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, Y, WS, X, M);
   CN_LAUNCH_CHECK();
   return CN_OK;
 }
@@ -302,8 +298,8 @@ static int cn_launch_mlp_rc2_resident(const bf16_t* Y, const bf16_t* WS, float* 
 // loads, stores) only makes that wait stricter, never unsafe (the counter retires in order).
 // PROF (kernel lab only): per-step s_memtime stamps at points where no LDS read is in flight -> prof[0..4] =
 // wait for the DMA, barrier, DMA issue, step compute, tile boundary (sums over waves, in cycles), prof[5] = wave-steps
-template <int C, int NW, int NCK, int NST, int PROF = 0>
-__global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_ring_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ WS,
+template <int C, int NW, int NCK, int NST, int PROF = 0, typename HT = bf16_t>
+__global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_ring_kernel(const HT* __restrict__ Y, const HT* __restrict__ WS,
                                                                   float* __restrict__ X, int M, unsigned long long* prof = nullptr) {
   unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0, nstep = 0;
   auto stamp = [&](int i) {
@@ -315,7 +311,8 @@ __global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_ring_kernel(const bf16_t* 
   };
   if constexpr (PROF) tprev = clock64();
   typedef Rc2Geom<C, NCK> G;
-  typedef Rc2Wave<C, NCK> W;
+  typedef Rc2Wave<C, NCK, HT> W;
+  typedef cn_h8<HT> hx8;
   constexpr int FR = G::FRAGS, SB = G::STEP_BYTES;
   constexpr int DPW_LO = FR / NW, N_HI = FR % NW;  // waves < N_HI issue DPW_LO + 1 pieces per entry
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -338,13 +335,13 @@ __global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_ring_kernel(const bf16_t* 
       if (i < DPW_LO || wave < N_HI) cn_dma16_s(src + piece * 1024, voff, dst + piece * 1024);
     }
   };
-  bf16x8 ones;
+  hx8 ones;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)((lane < 32 && i < 2) ? 1.0f : 0.0f);
+  for (int i = 0; i < 8; ++i) ones[i] = (HT)((lane < 32 && i < 2) ? 1.0f : 0.0f);
 
 #pragma unroll
   for (int g = 0; g < NST - 1; ++g) stage(g);
-  bf16x8 fy[G::KS1];
+  hx8 fy[G::KS1];
   if (t_lo + wave < t_hi) W::load_y(Y, (t_lo + wave) * 32, lane, fy);
   const char* wl = smem + lane * 16;
   int g = 0;
@@ -389,14 +386,14 @@ __global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_ring_kernel(const bf16_t* 
   }
 }
 
-template <int C, int NW, int NCK, int NST, int PROF = 0>
-static int cn_launch_mlp_rc2_ring(const bf16_t* Y, const bf16_t* WS, float* X, int M, int n_blocks, hipStream_t s,
+template <int C, int NW, int NCK, int NST, int PROF = 0, typename HT>
+static int cn_launch_mlp_rc2_ring(const HT* Y, const HT* WS, float* X, int M, int n_blocks, hipStream_t s,
                                   unsigned long long* prof = nullptr) {
   constexpr int SMEM = NST * Rc2Geom<C, NCK>::STEP_BYTES;
   static_assert(SMEM <= 160 * 1024, "ring must fit in LDS");
-  CN_TRY(cn_configure_lds((const void*)cn_mlp_rc2_ring_kernel<C, NW, NCK, NST, PROF>, SMEM));
+  CN_TRY(cn_configure_lds((const void*)cn_mlp_rc2_ring_kernel<C, NW, NCK, NST, PROF, HT>, SMEM));
   const int grid = cn_rc2_grid((M + 31) / 32, NW, n_blocks);
-  hipLaunchKernelGGL((cn_mlp_rc2_ring_kernel<C, NW, NCK, NST, PROF>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, Y, WS, X, M, prof);
+  hipLaunchKernelGGL((cn_mlp_rc2_ring_kernel<C, NW, NCK, NST, PROF, HT>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, Y, WS, X, M, prof);
   CN_LAUNCH_CHECK();
   return CN_OK;
 }

@@ -1,4 +1,4 @@
-// Role-split fused ConvNeXt MLP (bf16) -- third generation of the stage 0-2 pointwise kernel (mlp_rc2.h is the second):
+// Role-split fused ConvNeXt MLP (16-bit operands HT = bf16_t | half_t) -- third generation of the stage 0-2 pointwise kernel (mlp_rc2.h is the second):
 //
 //     x[m][:] += scale * ( W2 . gelu( W1 . y[m][:] + b1 ) + b2 )          (convnext.py:66-74)
 //
@@ -39,8 +39,9 @@
 
 #include "mlp_rc2.h"
 
+template <typename HT>
 static __global__ void pk_mlp_rs(const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
-                                 const float* __restrict__ b2, const float* __restrict__ scale, int C, bf16_t* __restrict__ dst) {
+                                 const float* __restrict__ b2, const float* __restrict__ scale, int C, HT* __restrict__ dst) {
   const int KS1 = C / 16, NT2 = C / 32, NCH = C / 8, F1 = KS1 + 1, F2 = 2 * NT2, FRAGS = F1 + F2;
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u < C) ((float*)((char*)dst + (size_t)NCH * FRAGS * 1024))[u] = scale[u] * b2[u];  // bb behind the stream
@@ -55,7 +56,7 @@ static __global__ void pk_mlp_rs(const float* __restrict__ W1, const float* __re
       for (int i = 0; i < 8; ++i) v[i] = W1[(size_t)(32 * j + r) * C + 16 * s + 8 * h + i];
     } else {  // bias k-step: fp32 b1 as hi + lo bf16 against a "ones" fragment
       const float b = b1[32 * j + r];
-      const float hi = (float)(bf16_t)b;
+      const float hi = (float)(HT)b;
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = 0.f;
       if (h == 0) {
@@ -72,14 +73,15 @@ static __global__ void pk_mlp_rs(const float* __restrict__ W1, const float* __re
     for (int i = 0; i < 8; ++i) v[i] = sc * W2[(size_t)c * (4 * C) + 32 * j + 16 * s + 8 * (i >> 2) + 4 * h + (i & 3)];
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) dst[(size_t)u * 8 + i] = (bf16_t)v[i];
+  for (int i = 0; i < 8; ++i) dst[(size_t)u * 8 + i] = (HT)v[i];
 }
 
 // ABL (kernel lab only, wrong results): 1 = no ring refill after the prologue, 2 = GELU replaced by a copy, 4 = no residual / y
 // traffic at tile boundaries
-template <int C, int NP, int ABL = 0> struct RsWave {
+template <int C, int NP, int ABL = 0, typename HT = bf16_t> struct RsWave {
   typedef Rc2Geom<C, 1> G;
-  typedef Rc2Wave<C, 1> W;
+  typedef Rc2Wave<C, 1, HT> W;
+  typedef cn_h8<HT> hx8;
   static constexpr int KS1 = G::KS1, NT2 = G::NT2, F1 = G::F1, F2 = G::F2, FR = G::FRAGS;
 #ifndef CN_RS_PRE
 #define CN_RS_PRE 4
@@ -92,7 +94,7 @@ template <int C, int NP, int ABL = 0> struct RsWave {
   // GELU element pair (e, e + 1) rides behind MFMA (e * F1) / 16
   static constexpr int gelu_at(int e) { return (e * F1) / 16; }
   struct AState {
-    bf16x8 F[R];
+    hx8 F[R];
     float g[16];
   };
   template <int Q, int E>
@@ -106,14 +108,14 @@ template <int C, int NP, int ABL = 0> struct RsWave {
   }
   // RELOAD: the tile's last step -- fragment s of the next tile's y replaces fy[s] behind the MFMA that read it
   template <int Q, bool RELOAD>
-  static __device__ __forceinline__ void a_mstep(const char* wc, bf16x8 (&fy)[KS1], const bf16x8 ones, const f32x16& Xp,
-                                                 f32x16& Xn, AState& st, const bf16_t* ynext) {
+  static __device__ __forceinline__ void a_mstep(const char* wc, hx8 (&fy)[KS1], const hx8 ones, const f32x16& Xp,
+                                                 f32x16& Xn, AState& st, const HT* ynext) {
     if constexpr (Q + PRE < F1) st.F[(Q + PRE) % R] = W::frag(wc, Q + PRE);
     if constexpr (Q == 0) Xn = W::mma(st.F[0], fy[0], W::zero16());
     else if constexpr (Q < KS1) Xn = W::mma(st.F[Q % R], fy[Q], Xn);
     else Xn = W::mma(st.F[Q % R], ones, Xn);
     a_gelu<Q, 0>(Xp, st);
-    if constexpr (RELOAD && Q >= 1 && Q <= KS1) fy[Q - 1] = *(const bf16x8*)(ynext + 16 * (Q - 1));  // (one MFMA behind its last reader)
+    if constexpr (RELOAD && Q >= 1 && Q <= KS1) fy[Q - 1] = *(const hx8*)(ynext + 16 * (Q - 1));  // (one MFMA behind its last reader)
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (Q + 1 < F1) a_mstep<Q + 1, RELOAD>(wc, fy, ones, Xp, Xn, st, ynext);
   }
@@ -125,16 +127,14 @@ template <int C, int NP, int ABL = 0> struct RsWave {
   // wc: this step's entry (lane offset applied); gdst: this pair's hand-over buffer (lane offset applied);
   // ynext: the next tile's y rows with this lane's offset applied (RELOAD only)
   template <bool RELOAD>
-  static __device__ __forceinline__ void a_step(const char* wc, bf16x8 (&fy)[KS1], const bf16x8 ones, const f32x16& Xp,
-                                                f32x16& Xn, char* gdst, const bf16_t* ynext) {
+  static __device__ __forceinline__ void a_step(const char* wc, hx8 (&fy)[KS1], const hx8 ones, const f32x16& Xp,
+                                                f32x16& Xn, char* gdst, const HT* ynext) {
     AState st;
     a_prefetch<0>(wc, st);
     __builtin_amdgcn_sched_barrier(0);
     a_mstep<0, RELOAD>(wc, fy, ones, Xp, Xn, st, ynext);
-    *(bf16x8*)gdst = bf16x8{(bf16_t)st.g[0], (bf16_t)st.g[1], (bf16_t)st.g[2],  (bf16_t)st.g[3],
-                            (bf16_t)st.g[4], (bf16_t)st.g[5], (bf16_t)st.g[6],  (bf16_t)st.g[7]};
-    *(bf16x8*)(gdst + 1024) = bf16x8{(bf16_t)st.g[8],  (bf16_t)st.g[9],  (bf16_t)st.g[10], (bf16_t)st.g[11],
-                                     (bf16_t)st.g[12], (bf16_t)st.g[13], (bf16_t)st.g[14], (bf16_t)st.g[15]};
+    *(hx8*)gdst = cn_sat8<HT>(cn_pack8<HT>(st.g[0], st.g[1], st.g[2], st.g[3], st.g[4], st.g[5], st.g[6], st.g[7]));
+    *(hx8*)(gdst + 1024) = cn_sat8<HT>(cn_pack8<HT>(st.g[8], st.g[9], st.g[10], st.g[11], st.g[12], st.g[13], st.g[14], st.g[15]));
   }
 
   // ---- B: O^T += W2c' . G^T; lane = position m0 + (l & 31), register 4 q + e of tile t = channel 32 t + 8 q + 4 (l >> 5) + e
@@ -170,7 +170,7 @@ template <int C, int NP, int ABL = 0> struct RsWave {
     }
   }
   struct BState {
-    bf16x8 F[R];
+    hx8 F[R];
   };
   // MFMA order: Q = 2 t + k (the k-steps of one channel tile back to back); fragment (k, t) sits at k * NT2 + t of the W2 part.
   // LAST: the tile's last chunk -- one tile behind the MFMAs, O[t] (+ bb) is stored and, if there is a next position
@@ -190,7 +190,7 @@ template <int C, int NP, int ABL = 0> struct RsWave {
   // run-time choice between two instantiations of the step, made the register allocator give O different registers on
   // the two paths and shuffle all 192 of them through scratch at the join.
   template <int Q, bool LAST>
-  static __device__ __forceinline__ void b_mstep(const char* w2, const bf16x8 (&H)[2], f32x16 (&O)[NT2], BState& st, const Dma& d,
+  static __device__ __forceinline__ void b_mstep(const char* w2, const hx8 (&H)[2], f32x16 (&O)[NT2], BState& st, const Dma& d,
                                                  float* xrow, const float* xnext, const char* bbl, bool in_range) {
     if constexpr (Q + PRE < F2) st.F[(Q + PRE) % R] = W::frag(w2, fidx(Q + PRE));
     constexpr int k = Q & 1, t = Q >> 1;
@@ -209,7 +209,7 @@ template <int C, int NP, int ABL = 0> struct RsWave {
     if constexpr (Q + 1 < PRE) b_prefetch<Q + 1>(w2, st);
   }
   template <bool LAST>
-  static __device__ __forceinline__ void b_step(const char* w2, const bf16x8 (&H)[2], f32x16 (&O)[NT2], const Dma& d, float* xrow,
+  static __device__ __forceinline__ void b_step(const char* w2, const hx8 (&H)[2], f32x16 (&O)[NT2], const Dma& d, float* xrow,
                                                 const float* xnext, const char* bbl, bool in_range) {
     BState st;
     b_prefetch<0>(w2, st);
@@ -302,12 +302,13 @@ __device__ __forceinline__ void cn_vm_wait(int n) {
 
 // NP pairs per block (2 NP waves: waves [0, NP) are the A roles, [NP, 2 NP) the B roles: with waves dealt round-robin over the
 // four SIMDs a pair shares its SIMD when NP is a multiple of 4); pair p owns tiles t_lo + p + it * NP of the block's range.
-template <int C, int NP, int NST, int ABL = 0>
-__global__ __launch_bounds__(2 * NP * 64) void cn_mlp_rs_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ WS,
+template <int C, int NP, int NST, int ABL = 0, typename HT = bf16_t>
+__global__ __launch_bounds__(2 * NP * 64) void cn_mlp_rs_kernel(const HT* __restrict__ Y, const HT* __restrict__ WS,
                                                                 float* __restrict__ X, int M) {
   typedef Rc2Geom<C, 1> G;
-  typedef Rc2Wave<C, 1> W;
-  typedef RsWave<C, NP, ABL> RW;
+  typedef Rc2Wave<C, 1, HT> W;
+  typedef RsWave<C, NP, ABL, HT> RW;
+  typedef cn_h8<HT> hx8;
   constexpr int NCH = G::NSTEP, FR = G::FRAGS, SB = G::STEP_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* gbuf = smem + NST * SB;          // NP x 2 KB hand-over buffers
@@ -345,16 +346,16 @@ __global__ __launch_bounds__(2 * NP * 64) void cn_mlp_rs_kernel(const bf16_t* __
   }
   if (!role_b) {
     // ================================================= A ==============================================================
-    bf16x8 ones;
+    hx8 ones;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)((lane < 32 && i < 2) ? 1.0f : 0.0f);
-    bf16x8 fy[G::KS1];
+    for (int i = 0; i < 8; ++i) ones[i] = (HT)((lane < 32 && i < 2) ? 1.0f : 0.0f);
+    hx8 fy[G::KS1];
     f32x16 Xa = W::zero16(), Xb = W::zero16();
     const int yoff = (lane & 31) * C + 8 * (lane >> 5);  // elements: fy[s] = y[m0 + (l & 31)][16 s + 8 (l >> 5) .. + 8]
     const int tile0 = t_lo + pair < t_hi ? t_lo + pair : t_lo;  // (a pair without a tile multiplies rows nobody stores)
     W::load_y(Y, tile0 * 32, lane, fy);
     int g = 0;
-    auto step2 = [&](auto reload_tag, const bf16_t* ynext) {  // two steps: the roles of the two X accumulators swap
+    auto step2 = [&](auto reload_tag, const HT* ynext) {  // two steps: the roles of the two X accumulators swap
       constexpr bool RELOAD = decltype(reload_tag)::value;
       __builtin_amdgcn_s_barrier();
       if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(2 * NP * 64) void cn_mlp_rs_kernel(const bf16_t* __
     for (int it = 0; it < max_it; ++it) {
       const int tile = t_lo + pair + it * NP;
       const int tnext = (tile + NP < t_hi && !(ABL & 4)) ? tile + NP : tile0;  // (no next tile: rows it never uses)
-      const bf16_t* ynext = Y + (size_t)tnext * 32 * C + yoff;
+      const HT* ynext = Y + (size_t)tnext * 32 * C + yoff;
       for (int j = 0; j < NCH - 2; j += 2) step2(std::false_type{}, ynext);
       step2(std::true_type{}, ynext);  // the tile's last two steps: the second re-loads y in place
     }
@@ -390,15 +391,15 @@ __global__ __launch_bounds__(2 * NP * 64) void cn_mlp_rs_kernel(const bf16_t* __
     // the last step in which this wave ran a tile boundary, and the vector-memory operations it really issued there: the
     // 4 NT2 loads always, the 4 NT2 stores only if some lane's row is inside the tensor (an all-masked store is branched over)
     int io_step = -1000, io_n = 0;
-    bf16x8 H[2];
+    hx8 H[2];
     auto head = [&]() {  // ring wait, first barrier, G(g - 2) -> registers, second barrier
       // Own pieces of the entry about to be consumed have landed.  They were issued in step g - (NST - 1); younger than them
       // (the counter retires in order) are the pieces of NST - 2 later entries and, if a tile boundary fell strictly
       // between, its stores and loads.
       cn_vm_wait((NST - 2) * n_mine + ((io_step > g - (NST - 1) && io_step < g) ? io_n : 0));
       __builtin_amdgcn_s_barrier();
-      H[0] = *(const bf16x8*)gl;
-      H[1] = *(const bf16x8*)(gl + 1024);
+      H[0] = *(const hx8*)gl;
+      H[1] = *(const hx8*)(gl + 1024);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();  // (32: lab ablation, racy: what the second barrier costs)
     };
@@ -428,13 +429,13 @@ __global__ __launch_bounds__(2 * NP * 64) void cn_mlp_rs_kernel(const bf16_t* __
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring was filled NST - 1 entries past the end
 }
 
-template <int C, int NP, int NST, int ABL = 0>
-static int cn_launch_mlp_rs(const bf16_t* Y, const bf16_t* WS, float* X, int M, int n_blocks, hipStream_t s) {
+template <int C, int NP, int NST, int ABL = 0, typename HT>
+static int cn_launch_mlp_rs(const HT* Y, const HT* WS, float* X, int M, int n_blocks, hipStream_t s) {
   constexpr int SMEM = NST * Rc2Geom<C, 1>::STEP_BYTES + NP * 2048 + C * 4;
   static_assert(SMEM <= 160 * 1024, "ring + hand-over buffers must fit in LDS");
-  CN_TRY(cn_configure_lds((const void*)cn_mlp_rs_kernel<C, NP, NST, ABL>, SMEM));
+  CN_TRY(cn_configure_lds((const void*)cn_mlp_rs_kernel<C, NP, NST, ABL, HT>, SMEM));
   const int grid = cn_rc2_grid((M + 31) / 32, NP, n_blocks);
-  hipLaunchKernelGGL((cn_mlp_rs_kernel<C, NP, NST, ABL>), dim3((unsigned)grid), dim3(2 * NP * 64), SMEM, s, Y, WS, X, M);
+  hipLaunchKernelGGL((cn_mlp_rs_kernel<C, NP, NST, ABL, HT>), dim3((unsigned)grid), dim3(2 * NP * 64), SMEM, s, Y, WS, X, M);
   CN_LAUNCH_CHECK();
   return CN_OK;
 }

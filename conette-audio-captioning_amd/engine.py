@@ -19,6 +19,7 @@ PREC_F32 = 0
 PREC_BF16 = 1
 PREC_F16X2 = 2   # "exact": fp16 hi/lo operand pairs, three MFMAs per product (include/conette_hip.h)
 PREC_FP8 = 3     # bf16 mode with the stage 0-2 pointwise convolutions on fp8 (e4m3) MFMAs
+PREC_F16 = 4     # the bf16 mode's kernels with IEEE fp16 operands: 8x less operand rounding error at the same speed
 N_MELS = 224
 FEAT = 768
 N_TAGS = 527
@@ -173,12 +174,16 @@ class Engine:
             raise RuntimeError("conette_amd.Engine needs a ROCm GPU (no CPU fallback)")
         self.lib = load_library()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        table = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "exact": PREC_F16X2, "f16x2": PREC_F16X2, "fp8": PREC_FP8}
+        table = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "exact": PREC_F16X2, "f16x2": PREC_F16X2, "fp8": PREC_FP8,
+                 "f16": PREC_F16, "fp16": PREC_F16}
         if precision == "mixed":     # bf16 encoder + exact (fp16 hi/lo pairs) decoder
             self.precision, self.precision_dec = PREC_BF16, PREC_F16X2
+        elif precision == "mixed16":  # fp16 encoder + exact decoder
+            self.precision, self.precision_dec = PREC_F16, PREC_F16X2
         else:
             self.precision = self.precision_dec = table[precision]
-        self.precision_name = "mixed" if precision == "mixed" else {PREC_BF16: "bf16", PREC_F32: "fp32", PREC_F16X2: "exact", PREC_FP8: "fp8"}[self.precision]
+        self.precision_name = precision if precision in ("mixed", "mixed16") else {
+            PREC_BF16: "bf16", PREC_F32: "fp32", PREC_F16X2: "exact", PREC_FP8: "fp8", PREC_F16: "f16"}[self.precision]
         vocab = int(state_dict["model.decoder.classifier.weight"].shape[0])
         self.vocab_size = vocab
         self.d_model, self.nhead, self.n_layers, self.d_ff = d_model, nhead, n_layers, d_ff

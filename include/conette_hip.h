@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CONETTE_ABI_VERSION 2 /* 2: conette_encode_taps carries its size; CONETTE_PREC_F16X2; conette_decode_graph_nodes */
+#define CONETTE_ABI_VERSION 2 /* 2: conette_encode_taps carries its size; CONETTE_PREC_F16X2 / _FP8 / _F16; conette_decode_graph_nodes */
 
 /* precision of GEMM operands / intermediate activations (accumulation is always fp32,
  * the residual streams are always fp32) */
@@ -37,6 +37,11 @@ extern "C" {
 #define CONETTE_PREC_FP8 3 /* BASELINE.json configs[4]: bf16 mode with the pointwise convolutions of ConvNeXt stages 0-2 on
                               v_mfma_f32_32x32x16_fp8_fp8 (OCP e4m3 operands, per-tensor / per-output-channel scales,
                               fp32 accumulation and residual stream); ~5 % of a block's update off the bf16 mode per block */
+
+#define CONETTE_PREC_F16 4 /* the bf16 mode's kernels instantiated for IEEE fp16 operands (v_mfma_f32_*_f16: the same cycles,
+                              the same bytes): 11 significant bits instead of 8, i.e. an eighth of the bf16 mode's operand
+                              rounding error at the bf16 mode's speed.  Conversions saturate at +-65504; weights below
+                              6.1e-5 in magnitude are fp16 subnormals (absolute error <= 3e-8, kept by the MFMA) */
 
 typedef struct conette_ctx conette_ctx; /* opaque: packed weights + constant tables */
 

@@ -17,6 +17,7 @@ common.h); the oracle uses the exact erf form, so a handful of hidden values per
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Dict, Optional
 
 import torch
@@ -28,9 +29,27 @@ from . import cpu_ref as O
 Weights = Dict[str, Tensor]
 
 
+_OPERAND_DTYPE = torch.bfloat16
+
+
 def bf16(t: Tensor) -> Tensor:
-    """fp32 -> bf16 (round to nearest even) -> fp32."""
-    return t.to(torch.bfloat16).to(torch.float32)
+    """fp32 -> the 16-bit operand type (round to nearest even; bf16 unless inside ``operands("f16")``) -> fp32."""
+    if _OPERAND_DTYPE is torch.float16:
+        t = t.clamp(-65504.0, 65504.0)      # the kernels' conversions saturate (csrc/common.h cn_from_f32<half_t>)
+    return t.to(_OPERAND_DTYPE).to(torch.float32)
+
+
+@contextlib.contextmanager
+def operands(kind: str):
+    """Every rounding point of this module at another 16-bit operand type: "bf16" (CONETTE_PREC_BF16) or "f16"
+    (CONETTE_PREC_F16: the same kernels instantiated for IEEE fp16, csrc/common.h half_t)."""
+    global _OPERAND_DTYPE
+    keep = _OPERAND_DTYPE
+    _OPERAND_DTYPE = {"bf16": torch.bfloat16, "f16": torch.float16}[kind]
+    try:
+        yield
+    finally:
+        _OPERAND_DTYPE = keep
 
 
 def convnext_block_bf16(w: Weights, prefix: str, x: Tensor, folded: bool) -> Tensor:
