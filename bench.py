@@ -67,6 +67,9 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: CPU self-test of the launcher / sharding / gather path (no GPU work, no timing)")
     ap.add_argument("--master-port", type=int, default=0)
+    ap.add_argument("--also", default="f16,mixed16",
+                    help="N = 1, fixed workload, bf16 only: after the run, the SAME pipelined benchmark at these precisions (one child "
+                         "process each, 3 windows, no CPU / parity legs), reported under `also_pipelined` ('' = skip)")
     return ap.parse_args(argv)
 
 
@@ -277,6 +280,26 @@ def compare_ids(got, got_lp, ref, ref_lp=None, margins=None):
             sel = mg > thr
             r[f"seq_identical_margin_gt_{thr}"] = [int((same & sel).sum()), int(sel.sum())]
     return r
+
+
+def also_pipelined(args, batch):
+    """The same encode | decode | decode pipeline at other precisions, each in a child process of its own (this process stays
+    idle meanwhile; a child is a plain `python bench.py --precision P`, started, never exec'ed into).  `value` of the line stays
+    the bf16 number BASELINE.json's config names; these are the rates of the precisions whose ids are closer to the oracle's
+    (`parity.vs_oracle` of the same line)."""
+    import subprocess
+    out = {}
+    for name in [n for n in args.also.split(",") if n]:
+        cmd = [sys.executable, os.path.abspath(__file__), "--precision", name, "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--repeat", "3", "--batch", str(batch), "--beam", str(args.beam), "--cpu-clips", "0", "--parity-clips", "0", "--also", ""]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            out[name] = {"clips_per_sec": d["value"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
+                         "windows_clips_per_sec": d["windows"]["clips_per_sec"], "pipeline_consistent": d["pipeline_consistent"]}
+        except Exception as e:  # a failed child does not void the line: it is reported as such
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return out
 
 
 def parity_report(args, Engine, eng, sd, dev, w0, lens0, bos0, forbid, t_audio, beam, min_pred, max_pred, ora, result):
@@ -705,6 +728,8 @@ def main() -> None:
     # ---- parity of every precision against the ORACLE + attribution of the bf16 disagreement (rank 0, N = 1, untimed) ----
     if rank == 0 and world == 1 and args.parity_clips > 0 and args.workload == "fixed":
         result["parity"] = parity_report(args, Engine, eng, sd, dev, w0, lens0, bos0, forbid, t0_, beam, min_pred, max_pred, ora, result)
+    if rank == 0 and world == 1 and args.workload == "fixed" and args.precision == "bf16" and args.also and args.parity_clips > 0:
+        result["also_pipelined"] = also_pipelined(args, B0)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

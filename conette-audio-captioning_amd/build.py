@@ -16,6 +16,8 @@ if os.environ.get("CN_G2_PROF"):  # profiling build: phase stamps inside the enc
     FLAGS.append("-DCN_G2_PROF")
 if os.environ.get("CN_NO_RS"):     # A/B build: the chained stage-2 kernel of round 2 instead of the role-split one
     FLAGS.append("-DCN_NO_RS")
+if os.environ.get("CN_NO_SAT8"):   # A/B build: fp16 GELU outputs of the fused MLP without the saturating v_pk_min_f16
+    FLAGS.append("-DCN_NO_SAT8")
 if os.environ.get("CN_DB_ROWS"):   # A/B build: rows per decoder block kernel (dec_block.h: 4)
     FLAGS.append("-DDB_ROWS=" + os.environ["CN_DB_ROWS"])
 if os.environ.get("CN_G2_NOACT"):

@@ -41,14 +41,15 @@ __device__ __forceinline__ f32x4 cn_mma16(cn_h8<half_t> a, cn_h8<half_t> b, f32x
 }
 // eight converted values that are known to be >= -65504 (GELU / ReLU outputs): +inf -> 65504 with four v_pk_min_f16
 template <typename H> __device__ __forceinline__ cn_h8<H> cn_sat8(cn_h8<H> v) {
+#ifndef CN_NO_SAT8  // (A/B builds only: what the saturation costs the fused MLP kernels)
   if constexpr (__is_same(H, half_t)) {
     cn_h8<H> m;
 #pragma unroll
     for (int i = 0; i < 8; ++i) m[i] = (H)65504.0f;
     return __builtin_elementwise_min(v, m);
-  } else {
-    return v;
   }
+#endif
+  return v;
 }
 // eight fp32 values -> one 16-byte fragment (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32)
 template <typename H> __device__ __forceinline__ cn_h8<H> cn_pack8(float a, float b, float c, float d, float e, float f, float g, float h) {

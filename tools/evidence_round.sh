@@ -1,6 +1,6 @@
 #!/bin/bash
 # The bench lines DESIGN.md quotes besides the default one ("keep the evidence you quote"):
-#   bash tools/evidence_round.sh TAG   -> gpurun_out/TAG_{b256,b16,mixedlen,shard256,soak,exact,fp8,default}.json (one JSON line each)
+#   bash tools/evidence_round.sh TAG   -> gpurun_out/TAG_{default,f16,mixed16,mixed_precision,b256,b16,mixedlen,shard256,soak,exact,fp8}.json (one JSON line each)
 TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
@@ -10,11 +10,17 @@ run() { name=$1; shift; timeout 600 python3 bench.py "$@" 2> $OUT/${TAG}_${name}
 import json,sys
 d=json.load(open('$OUT/${TAG}_${name}.json'))
 print('$name', d['value'], d['unit'], 'ms/step', d['ms_per_step'], 'windows', d['windows']['clips_per_sec'], 'consistent', d['pipeline_consistent'])"; }
-run default
-run b256 --batch 256 --steps 30 --cpu-clips 0 --parity-clips 0
-run b16 --batch 16 --steps 200 --cpu-clips 0 --parity-clips 0
-run mixedlen --workload mixed --steps 30 --cpu-clips 0 --parity-clips 0
-run shard256 --global-batch 256 --steps 30 --cpu-clips 0 --parity-clips 0
-run soak --steps 300 --repeat 5 --cpu-clips 0 --parity-clips 0
-run exact --precision exact --steps 30 --cpu-clips 0 --parity-clips 0
-run fp8 --precision fp8 --steps 50 --cpu-clips 0 --parity-clips 0
+if [ $# -gt 1 ]; then ONLY=" ${@:2} "; else ONLY=""; fi   # tools/evidence_round.sh TAG [name ...]: only these lines
+want() { [ -z "$ONLY" ] || [[ "$ONLY" == *" $1 "* ]]; }
+_run() { if want $1; then run "$@"; fi; }
+_run default
+_run f16 --precision f16 --cpu-clips 0 --parity-clips 0
+_run mixed16 --precision mixed16 --cpu-clips 0 --parity-clips 0
+_run mixed_precision --precision mixed --cpu-clips 0 --parity-clips 0
+_run b256 --batch 256 --steps 30 --cpu-clips 0 --parity-clips 0
+_run b16 --batch 16 --steps 200 --cpu-clips 0 --parity-clips 0
+_run mixedlen --workload mixed --steps 30 --cpu-clips 0 --parity-clips 0
+_run shard256 --global-batch 256 --steps 30 --cpu-clips 0 --parity-clips 0
+_run soak --steps 300 --repeat 5 --cpu-clips 0 --parity-clips 0
+_run exact --precision exact --steps 30 --cpu-clips 0 --parity-clips 0
+_run fp8 --precision fp8 --steps 50 --cpu-clips 0 --parity-clips 0
