@@ -50,11 +50,15 @@ __device__ __forceinline__ void cn_wave_sync() { __builtin_amdgcn_wave_barrier()
 #ifndef FE_NW
 #define FE_NW 16  // waves (= frames in flight) per block
 #endif
-// Static LDS of cn_logmel_kernel (the five arrays below) and the dynamic LDS its launch adds on top: together they are the
-// WHOLE 160 KB of a compute unit (minus < 768 bytes of rounding and alignment slack), so that no workgroup that allocates any LDS at all can
-// start beside a log-mel block -- not "most of them" (round 2 reserved 132.5 KB, which still admitted workgroups of up to
-// 27.5 KB: the register-staged 64 x 96 GEMM tile of gemm.h is 25 KB).  The mechanism of the corruption this avoids is not
-// understood (profiles/r02_notes.md); the exclusion is by allocation, not by timing.
+// Static LDS of cn_logmel_kernel (the five arrays below) and the dynamic LDS its launch adds on top: together the WHOLE 160 KB of a
+// compute unit (minus < 768 bytes of rounding and alignment slack), one block of 16 waves per CU.
+// History: in round 2 frames came out wrong -- lanes 48-63 of one VALU result at a time -- whenever the decoder's GEMM workgroups
+// shared a CU with this kernel, and taking the CU's LDS was the cure that kept them out.  Round 3 found the mechanism (profiles/r03_notes.md
+// section 8, tools/lab/pk_mfma_probe.hip): a packed-fp32 instruction whose op_sel feeds the high half of src1 to the low result
+// (hipcc's SLP vectoriser made 34 of them out of the complex arithmetic below) is executed wrongly by MI355X in lanes 48-63 while
+// another wave on the SIMD runs v_mfma_f32_16x16x32_bf16.  The file is now compiled without SLP vectorisation (build.py FILE_FLAGS: no
+// packed instruction at all, same speed), isa_lint.py rejects a library that contains the form, and the exclusive CU stays as it
+// costs nothing.
 #define FE_STATIC_BYTES ((512 + 513) * 8 + 1024 * 4 + FE_NW * 8 * FE_PITCH * 8 + FE_NW * 520 * 4)
 #define FE_LDS_TOTAL (160 * 1024)
 #define FE_FILL_BYTES ((FE_LDS_TOTAL - FE_STATIC_BYTES - 256) / 256 * 256)  // (256 bytes of slack for the arrays' alignment padding)
@@ -74,9 +78,7 @@ __global__ __launch_bounds__(FE_NW * 64) void cn_logmel_kernel(const float* __re
   __shared__ __attribute__((aligned(16))) float s_win[1024];
   __shared__ float2 s_x[FE_NW][8 * FE_PITCH];
   __shared__ float s_p[FE_NW][520];
-  // A block takes a compute unit's LDS for itself (all 160 KB): nothing that allocates LDS can start beside it.
-  // (Frames came out wrong, a 16-lane quarter of one VALU result at a time, whenever the decoder's small GEMM workgroups
-  // shared a CU with this kernel on another stream: profiles/r02_notes.md, tools/pipeline_probe3.py.)
+  // A block takes a compute unit's LDS for itself (all 160 KB): nothing that allocates LDS can start beside it (see above).
   // (the launch adds >= FE_FILL_BYTES of dynamic LDS; it holds the mel matrix when that fits)
   extern __shared__ __attribute__((aligned(16))) float s_mel[];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
