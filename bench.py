@@ -64,6 +64,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-clips", type=int, default=32, help="clips in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--parity-clips", type=int, default=64, help="clips in the bf16-vs-fp32 agreement leg (0 = skip)")
+    ap.add_argument("--parity-batches", type=int, default=4,
+                    help="batches of --parity-clips clips (other seeds) in the agreement-with-the-fp32-mode leg: an identical-caption rate "
+                         "moves by several clips when a kernel's fp32 rounding changes in the last bit, 64 clips are a noisy sample")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: CPU self-test of the launcher / sharding / gather path (no GPU work, no timing)")
     ap.add_argument("--master-port", type=int, default=0)
@@ -349,10 +352,34 @@ def parity_report(args, Engine, eng, sd, dev, w0, lens0, bos0, forbid, t_audio, 
                 vo[name]["frame_embs_rel_rms"] = round(float(err.pow(2).mean().sqrt() / ofe.pow(2).mean().sqrt()), 7)
                 vo[name]["frame_embs_max_abs"] = round(float(err.abs().max()), 6)
         par["vs_oracle"] = vo
-    if "fp32" in engines:  # on all n clips: the library's fp32 mode as the reference (its ids equal the oracle's above)
+    if "fp32" in engines:  # the library's fp32 mode as the reference (its ids equal the oracle's above), on --parity-batches batches
+        from conette_amd import synth as _synth
+
+        def _cat(a, b):  # (ids, lprobs) of two batches: id matrices padded to a common width
+            w_ = max(a[0].shape[1], b[0].shape[1])
+            pa_ = torch.zeros((a[0].shape[0], w_), dtype=a[0].dtype)
+            pb_ = torch.zeros((b[0].shape[0], w_), dtype=b[0].dtype)
+            pa_[:, : a[0].shape[1]] = a[0]
+            pb_[:, : b[0].shape[1]] = b[0]
+            return torch.cat([pa_, pb_]), torch.cat([a[1], b[1]])
+
+        allo = dict(outs)
+        for bi in range(1, max(1, args.parity_batches)):
+            wv_b = torch.from_numpy(_synth.synth_waveforms(n, wv.shape[1], 1234 + 7919 * bi)).to(dev)
+            fe_b = {}
+            for name, e in engines.items():
+                fe_b[name] = e.encode(wv_b)[0].clone()
+                for bm_ in (1, beam):
+                    o = e.decode(fe_b[name], ln, bs, forbid, bm_, min_pred, max_pred)
+                    allo[(name, name, bm_)] = _cat(allo[(name, name, bm_)], (_ids(o), o["best_lprobs"].cpu()))
+            for enc_p, dec_p in mixes:
+                for bm_ in (1, beam):
+                    o = engines[dec_p].decode(fe_b[enc_p], ln, bs, forbid, bm_, min_pred, max_pred)
+                    allo[(enc_p, dec_p, bm_)] = _cat(allo[(enc_p, dec_p, bm_)], (_ids(o), o["best_lprobs"].cpu()))
+        torch.cuda.synchronize(dev)
         vf = {}
-        r32 = {bm_: outs[("fp32", "fp32", bm_)] for bm_ in (1, beam)}
-        for (enc_p, dec_p, bm_), (ids, lp) in outs.items():
+        r32 = {bm_: allo[("fp32", "fp32", bm_)] for bm_ in (1, beam)}
+        for (enc_p, dec_p, bm_), (ids, lp) in allo.items():
             if enc_p == dec_p == "fp32":
                 continue
             key = enc_p if enc_p == dec_p else f"enc_{enc_p}+dec_{dec_p}"
