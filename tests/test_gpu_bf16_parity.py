@@ -248,3 +248,27 @@ def test_forbid_rep_mode_content_words(prec, tmp_path, synth_weights, synth_cfg,
         for t in hyp:
             assert t in allowed or t not in seen, hyp
             seen.add(t)
+
+
+def test_f16_conversions_saturate_instead_of_overflowing(synth_weights):
+    """CONETTE_PREC_F16: a hidden activation beyond the fp16 range (65504) must come out as 65504, not as inf -> NaN.  Block 4's
+    pwconv1 weights and bias scaled until GELU outputs pass 1e5 (the fp32 mode's taps prove they do): the fp16 engine's frame
+    embeddings stay finite and stay close to the bf16 engine's, whose operands have the fp32 range."""
+    from conette_amd.engine import Engine
+    from conette_amd import synth
+    sd = dict(synth_weights)
+    p = "preprocessor.encoder.stages.1.1."
+    sd[p + "pwconv1.weight"] = synth_weights[p + "pwconv1.weight"] * 3.0e4
+    sd[p + "pwconv1.bias"] = synth_weights[p + "pwconv1.bias"] * 3.0e4
+    sd[p + "pwconv2.weight"] = synth_weights[p + "pwconv2.weight"] / 3.0e4   # (keeps the block's update O(1))
+    wave = torch.from_numpy(synth.synth_waveforms(2, 64000, 77)).cuda()
+    fe16, _ = Engine(sd, precision="f16").encode(wave)
+    feb, _ = Engine(sd, precision="bf16").encode(wave)
+    fe32, _ = Engine(sd, precision="fp32").encode(wave)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(fe16).all()) and bool(torch.isfinite(feb).all())
+    # (measured: 2 % for fp16 -- clamped hidden values and the 3e-5-sized W2 operands, which are fp16 subnormals -- against 0.4 % for bf16)
+    rel = float((fe16 - fe32).pow(2).mean().sqrt() / fe32.pow(2).mean().sqrt())
+    relb = float((feb - fe32).pow(2).mean().sqrt() / fe32.pow(2).mean().sqrt())
+    print("rel rms vs fp32: f16", rel, "bf16", relb)
+    assert rel < 0.5 and relb < 0.05
