@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o run -- python3 $ROOT/bench.py --steps 10 --cpu-clips 0 --parity-clips 0 > $OUT/${TAG}_trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o run -- python3 $ROOT/bench.py --steps 10 --cpu-clips 0 --parity-clips 0 $QT_ARGS > $OUT/${TAG}_trace.log 2>&1
 cp $(find $OUT/${TAG}_trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
 rm -rf $OUT/${TAG}_trace
 python3 - <<PY
