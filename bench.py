@@ -55,7 +55,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=0, help="total clips, sharded over the GPUs (strong scaling)")
     ap.add_argument("--beam", type=int, default=3)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "fp8", "mixed", "mixed16", "fp32", "exact"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "bf16+f16dec", "fp8", "mixed", "mixed16", "fp32", "exact"])
     ap.add_argument("--repeat", type=int, default=5,
                     help="timed windows of --steps steps each (barrier + synchronize around every window); `value` and "
                          "`ms_per_step` are the MEDIAN window's, every window's clips/s is listed under `windows`")
@@ -70,7 +70,7 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: CPU self-test of the launcher / sharding / gather path (no GPU work, no timing)")
     ap.add_argument("--master-port", type=int, default=0)
-    ap.add_argument("--also", default="f16,mixed16",
+    ap.add_argument("--also", default="bf16+f16dec,f16,mixed16",
                     help="N = 1, fixed workload, bf16 only: after the run, the SAME pipelined benchmark at these precisions (one child "
                          "process each, 3 windows, no CPU / parity legs), reported under `also_pipelined` ('' = skip)")
     return ap.parse_args(argv)
@@ -314,7 +314,7 @@ def parity_report(args, Engine, eng, sd, dev, w0, lens0, bos0, forbid, t_audio, 
     n = min(args.parity_clips, w0.shape[0])
     wv, ln, bs = w0[:n].contiguous(), lens0[:n].contiguous(), bos0[:n].contiguous()
     engines = {args.precision: eng}
-    for name in ("bf16", "f16", "fp8", "mixed", "mixed16", "exact", "fp32"):
+    for name in ("bf16", "f16", "bf16+f16dec", "fp8", "mixed", "mixed16", "exact", "fp32"):
         if name not in engines:
             try:
                 engines[name] = Engine(sd, precision=name, device=dev)
@@ -700,7 +700,7 @@ def main() -> None:
             "rank_clips_per_sec": rank_rates,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": {"bf16": "bf16", "fp8": "fp8 (e4m3 pointwise convolutions of stages 0-2) + bf16", "fp32": "f32", "exact": "f16x2", "mixed": "bf16 encoder + f16x2 decoder", "f16": "f16",
-                      "mixed16": "f16 encoder + f16x2 decoder"}[args.precision], "data": "synthetic",
+                      "mixed16": "f16 encoder + f16x2 decoder", "bf16+f16dec": "bf16 encoder + f16 decoder"}[args.precision], "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": B, "global_batch": total_clips, "beam_size": beam,
                        "parallelism": f"dp{world}", "world_size_observed": world,
                        **({"share_gpu_selftest": True} if share else {})},

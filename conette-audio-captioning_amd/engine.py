@@ -180,9 +180,11 @@ class Engine:
             self.precision, self.precision_dec = PREC_BF16, PREC_F16X2
         elif precision == "mixed16":  # fp16 encoder + exact decoder
             self.precision, self.precision_dec = PREC_F16, PREC_F16X2
+        elif precision == "bf16+f16dec":  # bf16 encoder (the throughput mode's) + fp16 decoder: the decoder's operands flip the most captions
+            self.precision, self.precision_dec = PREC_BF16, PREC_F16
         else:
             self.precision = self.precision_dec = table[precision]
-        self.precision_name = precision if precision in ("mixed", "mixed16") else {
+        self.precision_name = precision if precision in ("mixed", "mixed16", "bf16+f16dec") else {
             PREC_BF16: "bf16", PREC_F32: "fp32", PREC_F16X2: "exact", PREC_FP8: "fp8", PREC_F16: "f16"}[self.precision]
         vocab = int(state_dict["model.decoder.classifier.weight"].shape[0])
         self.vocab_size = vocab

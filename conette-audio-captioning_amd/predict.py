@@ -2,7 +2,7 @@
 (reference src/conette/predict.py:27-232).
 
     python -m conette_amd.predict --audio a.wav b.wav --task clotho --model_name DIR_OR_HUB_NAME \
-        [--csv_export out.csv] [--precision bf16|f16|fp8|mixed|mixed16|exact|fp32]
+        [--csv_export out.csv] [--precision bf16|bf16+f16dec|f16|fp8|mixed|mixed16|exact|fp32]
 
 ``--model_path`` (a Lightning training log directory with hydra/config.yaml + checkpoints/best.ckpt,
 predict.py:144-178) belongs to the training stack and is out of scope: it is rejected with a
@@ -41,7 +41,7 @@ def get_predict_args(argv: Optional[List[str]] = None) -> Namespace:
     parser.add_argument("--seed", type=_opt_int, help="Random seed value (inference is deterministic).", default=1234)
     parser.add_argument("--csv_export", type=_opt_str, help="Path to CSV output file.", default=None)
     parser.add_argument("--verbose", type=int, help="Verbose level.", default=1)
-    parser.add_argument("--precision", type=str, choices=("bf16", "f16", "fp8", "mixed", "mixed16", "exact", "fp32"), default="bf16")
+    parser.add_argument("--precision", type=str, choices=("bf16", "bf16+f16dec", "f16", "fp8", "mixed", "mixed16", "exact", "fp32"), default="bf16")
     return parser.parse_args(argv)
 
 

@@ -15,6 +15,7 @@ want() { [ -z "$ONLY" ] || [[ "$ONLY" == *" $1 "* ]]; }
 _run() { if want $1; then run "$@"; fi; }
 _run default
 _run f16 --precision f16 --cpu-clips 0 --parity-clips 0
+_run bf16_f16dec --precision bf16+f16dec --cpu-clips 0 --parity-clips 0
 _run mixed16 --precision mixed16 --cpu-clips 0 --parity-clips 0
 _run mixed_precision --precision mixed --cpu-clips 0 --parity-clips 0
 _run b256 --batch 256 --steps 30 --cpu-clips 0 --parity-clips 0
