@@ -61,6 +61,25 @@ def test_mixed_is_bf16_encode_plus_exact_decode(engines, synth_weights):
         assert torch.equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("name,enc,dec", [("mixed16", "f16", "exact"), ("bf16+f16dec", "bf16", "f16")])
+def test_two_context_precisions_are_their_halves(name, enc, dec, synth_weights):
+    """every two-context precision is bit for bit "engine A's encode fed to engine B's decode" (frame_embs fp32 is the interface)"""
+    from conette_amd.engine import Engine
+    g = G.load("b4_10s_beam3_clotho")
+    w = _wave(g).cuda()
+    both, e_enc, e_dec = Engine(synth_weights, precision=name), Engine(synth_weights, precision=enc), Engine(synth_weights, precision=dec)
+    fe_m, clip_m = both.encode(w)
+    fe_a, clip_a = e_enc.encode(w)
+    assert torch.equal(fe_m, fe_a) and torch.equal(clip_m, clip_a)
+    lens = torch.full((w.shape[0],), fe_a.shape[1], dtype=torch.int32)
+    bos = synth_weights["model.task_id_to_token_id"][torch.zeros(w.shape[0], dtype=torch.long)]
+    fm = synth_weights["model.forbid_rep_mask"]
+    a = both.decode(fe_a, lens, bos, fm, 3, 3, 20)
+    b = e_dec.decode(fe_a, lens, bos, fm, 3, 3, 20)
+    for k in ("best_preds", "best_lprobs", "mult_preds", "mult_lprobs"):
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_sp16_split_holds_22_bits():
     """host restatement of common.h cn_sp16_bits: hi = rn16(x), lo = rn16(x - hi)"""
     x = (torch.randn(100000) * torch.logspace(-4, 3, 100000)).float()
