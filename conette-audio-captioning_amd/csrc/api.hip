@@ -141,6 +141,33 @@ __global__ void pk_ffn_stream(const float* __restrict__ W1, const float* __restr
 #pragma unroll
   for (int i = 0; i < 8; ++i) dst[(size_t)u * 8 + i] = cn_from_f32<HT>(s[i]);
 }
+// the same two streams for the exact precision (sp16): every matrix / tile twice, its lo halves then its hi halves
+// (hi = rn16(x), lo = rn16(x - hi): common.h), each pass in the fp16 fragment order above.
+// block stream: pass p = 2 m + part at unit p * 8192 + (w, qd, a, kk, lane); FFN stream: pass (c * 2 + t) * 2 + part
+__global__ void pk_block_stream_sp(PkBlockSrc src, half_t* __restrict__ dst) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= 12 * 8192) return;
+  const int lane = u & 63, kk = (u >> 6) & 1, a = (u >> 7) & 3, qd = (u >> 9) & 3, w = (u >> 11) & 3, part = (u >> 13) & 1, m = u >> 14;
+  const float* s = src.W[m] + (size_t)(64 * w + 16 * a + (lane & 15)) * 256 + 32 * (2 * qd + kk) + 8 * (lane >> 4);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const unsigned b = cn_sp16_bits(s[i]);
+    dst[(size_t)u * 8 + i] = __builtin_bit_cast(half_t, (unsigned short)(part ? (b & 0xffffu) : (b >> 16)));
+  }
+}
+__global__ void pk_ffn_stream_sp(const float* __restrict__ W1, const float* __restrict__ W2, int dff, half_t* __restrict__ dst) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= (dff / 256) * 4 * 8192) return;
+  const int lane = u & 63, kk = (u >> 6) & 1, a = (u >> 7) & 3, qd = (u >> 9) & 3, w = (u >> 11) & 3, part = (u >> 13) & 1,
+            t = (u >> 14) & 1, c = u >> 15;
+  const int r = 64 * w + 16 * a + (lane & 15), k = 32 * (2 * qd + kk) + 8 * (lane >> 4);
+  const float* s = t == 0 ? W1 + (size_t)(c * 256 + r) * 256 + k : W2 + (size_t)r * dff + c * 256 + k;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const unsigned b = cn_sp16_bits(s[i]);
+    dst[(size_t)u * 8 + i] = __builtin_bit_cast(half_t, (unsigned short)(part ? (b & 0xffffu) : (b >> 16)));
+  }
+}
 __global__ void pk_bn(const float* w, const float* b, const float* mean, const float* var, float* scale, float* shift,
                       int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -249,7 +276,11 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
   size_t total = (1 << 20) + (size_t)CN_N_BINS * CN_N_MELS * 4;  // (+ the band-compact mel matrix, at most a dense copy)
   for (int i = 0; i < n_tensors; ++i) total += cn_align((size_t)numel[i] * 4) + 256;
   if (cfg->precision == CONETTE_PREC_FP8) total += 16u << 20;
-  if (cfg->precision == CONETTE_PREC_F16X2) total += 8u << 20;   // the fp16 hi / lo streams of the 6 fused blocks (~3.4 MB)  // the e4m3 streams of the 15 fused blocks (~8.6 MB)
+  if (cfg->precision == CONETTE_PREC_F16X2) {
+    total += 8u << 20;   // the fp16 hi / lo streams of the 6 fused ConvNeXt blocks (~3.4 MB)
+    // + per decoder layer the hi / lo fragment streams of dec_block.h (12 passes of 128 KB) and dec_ffn.h (4 per hidden chunk)
+    total += (size_t)cfg->n_layers * ((size_t)12 * 131072 + (size_t)(cfg->d_ff / 256 + 1) * 4 * 131072 + 4096);
+  }
   ctx->arena_bytes = total;
   hipError_t e = hipMalloc((void**)&ctx->arena, total);
   if (e != hipSuccess) {
@@ -507,6 +538,27 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
           const int units = (dff / 256) * 2 * 8192;
           CN_H16_CALL(ctx, hipLaunchKernelGGL(pk_ffn_stream<HT>, dim3(units / 256), dim3(256), 0, 0, w1, w2, dff, (HT*)fwp));
           lw.ffn_w = fwp;
+        }
+      }
+      if (ctx->sp16) {  // exact precision: the same two fused kernels on hi / lo half-tiles (dec_block.h, dec_ffn.h)
+        const float* ipw = B.find(p + "self_attn.in_proj_weight", (int64_t)3 * d * d);
+        const float* sow = B.find(p + "self_attn.out_proj.weight", (int64_t)d * d);
+        const float* cow = B.find(p + "multihead_attn.out_proj.weight", (int64_t)d * d);
+        void* bw = B.alloc((size_t)12 * d * d * 2);
+        if (ipw && sow && caw && cow) {
+          PkBlockSrc ps;
+          ps.W[0] = ipw, ps.W[1] = ipw + (size_t)d * d, ps.W[2] = ipw + (size_t)2 * d * d, ps.W[3] = sow, ps.W[4] = caw, ps.W[5] = cow;
+          hipLaunchKernelGGL(pk_block_stream_sp, dim3(12 * 8192 / 256), dim3(256), 0, 0, ps, (half_t*)bw);
+          lw.blk_w = bw;
+        }
+        if (dff % 256 == 0 && dff <= 2048) {
+          void* fwp = B.alloc((size_t)4 * dff * d * 2);
+          const float* w1 = B.find(p + "linear1.weight", (int64_t)dff * d);
+          const float* w2 = B.find(p + "linear2.weight", (int64_t)dff * d);
+          if (w1 && w2) {
+            hipLaunchKernelGGL(pk_ffn_stream_sp, dim3((dff / 256) * 4 * 8192 / 256), dim3(256), 0, 0, w1, w2, dff, (half_t*)fwp);
+            lw.ffn_w = fwp;
+          }
         }
       }
       if (ctx->esize == 2) {

@@ -56,11 +56,11 @@ struct CnLayerW {
   const void* ff2_w;  // [256][d_ff]
   const float* ff2_b;
   const float *n1w, *n1b, *n2w, *n2b, *n3w, *n3b;
-  // bf16 only: the six attention-side 256 x 256 matrices (in_proj q, k, v rows; self out-proj; cross q-proj;
+  // 16-bit operands (and, as twelve hi / lo passes, the exact precision): the six attention-side 256 x 256 matrices (in_proj q, k, v rows; self out-proj; cross q-proj;
   // cross out-proj) re-ordered into the MFMA-fragment stream of dec_block.h:
   // [matrix 6][wave 4][quarter 4][piece (a, kk) 8][lane 64][8 bf16]
   const void* blk_w;
-  // bf16, d_ff % 256 == 0, d_ff <= 2048: linear1 / linear2 as per-hidden-chunk fragment streams of dec_ffn.h:
+  // 16-bit operands (exact precision: every tile as a lo pass and a hi pass), d_ff % 256 == 0, d_ff <= 2048: linear1 / linear2 as per-hidden-chunk fragment streams of dec_ffn.h:
   // [chunk d_ff/256][tile 2 (W1 rows of the chunk | W2 columns of the chunk)][wave 4][quarter 4][piece 8][lane 64][8 bf16]
   const void* ffn_w;
   const float* blk_p;  // 2560 floats: in_proj bias 768 | bo | bq | bo2 | g1 | b1 | g2 | b2 (one contiguous LDS fill)

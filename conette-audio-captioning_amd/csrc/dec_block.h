@@ -33,8 +33,32 @@
 //
 // The roles hand over through LDS with raw s_barrier (lgkmcnt(0) only: __syncthreads() would also
 // drain the prefetch queues).  Per-CU ingest (~80 GB/s) bounds the kernel: 768 KB of weights per block.
+//
+// Exact precision (HT = sp16_t, round 4): the same kernel with every operand an fp16 hi / lo pair.  The weight stream holds
+// each matrix twice -- its lo halves, then its hi halves, both in the fp16 fragment order -- and flows through the SAME 128
+// fragment registers as twelve half-matrices: the lo pass starts the accumulators with W_lo . a_hi, the hi pass adds
+// W_hi . a_lo and W_hi . a_hi (the three products of common.h's sp16 scheme, smallest terms first); the activation tile
+// exists twice (hi and lo halves of the row waves' fp32 values), the K/V caches and the cross K/V are sp16 (16 bytes per
+// lane and key), LayerNorm uses 1 / sqrtf like the per-sub-layer kernels it replaces.  3 launches per layer instead of 11.
 #pragma once
 #include "gemm2.h"
+
+// operand traits of the block / FFN kernels: the element type of an MFMA fragment, a lane's four dims of one cached key,
+// how many passes the weight stream makes per matrix (sp16: lo, hi) and how many activation tiles there are (sp16: hi, lo)
+template <typename HT> struct DbOp {
+  typedef HT frag_t;
+  typedef cn_h4<HT> kv4_t;
+  static constexpr int NPH = 1;
+  static constexpr bool kExactLn = false;
+  static __device__ __forceinline__ float kvf(const kv4_t& v, int i) { return (float)v[i]; }
+};
+template <> struct DbOp<sp16_t> {
+  typedef half_t frag_t;
+  typedef u32x4 kv4_t;
+  static constexpr int NPH = 2;
+  static constexpr bool kExactLn = true;
+  static __device__ __forceinline__ float kvf(const kv4_t& v, int i) { return cn_sp16_value(v[i]); }
+};
 
 #ifndef DB_ROWS
 #define DB_ROWS 4   // rows (= row waves) per block: many small blocks spread the K/V and weight streams over more CUs
@@ -43,15 +67,15 @@
 
 // Wave-per-row attention: lane l owns dims 4l..4l+3 (head l >> 3); keys in batches of NB with all
 // loads of a batch in flight; fp32 online softmax.  kp(s) / vp(s): this lane's 4 bf16 of key / value s.
-template <int NB, typename HT> struct DbKV { cn_h4<HT> k[NB], v[NB]; };
+template <int NB, typename HT> struct DbKV { typename DbOp<HT>::kv4_t k[NB], v[NB]; };
 
 template <int NB, typename HT, class KeyPtr, class ValPtr>
 __device__ __forceinline__ void db_kv_load(DbKV<NB, HT>& kv, int s0, int n_keys, KeyPtr kp, ValPtr vp) {
 #pragma unroll
   for (int u = 0; u < NB; ++u) {
     const int s = min(s0 + u, n_keys - 1);
-    kv.k[u] = *(const cn_h4<HT>*)kp(s);
-    kv.v[u] = *(const cn_h4<HT>*)vp(s);
+    kv.k[u] = *(const typename DbOp<HT>::kv4_t*)kp(s);
+    kv.v[u] = *(const typename DbOp<HT>::kv4_t*)vp(s);
   }
 }
 
@@ -61,7 +85,8 @@ __device__ __forceinline__ void db_kv_consume(const DbKV<NB, HT>& kv, const f32x
   float sc[NB];
 #pragma unroll
   for (int u = 0; u < NB; ++u) {
-    float d = q[0] * (float)kv.k[u][0] + q[1] * (float)kv.k[u][1] + q[2] * (float)kv.k[u][2] + q[3] * (float)kv.k[u][3];
+    float d = q[0] * DbOp<HT>::kvf(kv.k[u], 0) + q[1] * DbOp<HT>::kvf(kv.k[u], 1) + q[2] * DbOp<HT>::kvf(kv.k[u], 2) +
+              q[3] * DbOp<HT>::kvf(kv.k[u], 3);
     d = cn_sum8_dpp(d);
     sc[u] = (s0 + u < n_keys && ((valid >> ((s0 + u) & 63)) & 1)) ? d : -INFINITY;
   }
@@ -78,7 +103,7 @@ __device__ __forceinline__ void db_kv_consume(const DbKV<NB, HT>& kv, const f32x
     const float p = __expf(sc[u] - mn);
     l += p;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = fmaf(p, (float)kv.v[u][i], o[i]);
+    for (int i = 0; i < 4; ++i) o[i] = fmaf(p, DbOp<HT>::kvf(kv.v[u], i), o[i]);
   }
   m = mn;
 }
@@ -107,11 +132,19 @@ __device__ __forceinline__ void db_kv_attend(DbKV<NB, HT> (&buf)[DEPTH], const f
 }
 
 // attention output of row `wave` (lane's 4 dims) -> bf16 -> swizzled A tile row `wave`
+// (sp16: the hi halves go to the tile at sA, the lo halves to its twin DB_TILE_BYTES further)
+#define DB_TILE_BYTES ((DB_ROWS + 1) * 512)
 template <typename HT>
 __device__ __forceinline__ void db_store_row(char* sA, int wave, int lane, const f32x4& o, float inv) {
   typedef G2Geom<256> G;
-  cn_store4((HT*)(sA + wave * G::RBY + (((lane >> 1) ^ (wave & G::SWM)) * 16) + (lane & 1) * 8), o[0] * inv,
-            o[1] * inv, o[2] * inv, o[3] * inv);
+  char* p = sA + wave * G::RBY + (((lane >> 1) ^ (wave & G::SWM)) * 16) + (lane & 1) * 8;
+  if constexpr (DbOp<HT>::NPH == 2) {
+    const unsigned b0 = cn_sp16_bits(o[0] * inv), b1 = cn_sp16_bits(o[1] * inv), b2 = cn_sp16_bits(o[2] * inv), b3 = cn_sp16_bits(o[3] * inv);
+    *(uint2*)p = uint2{__builtin_amdgcn_perm(b1, b0, 0x05040100u), __builtin_amdgcn_perm(b3, b2, 0x05040100u)};
+    *(uint2*)(p + DB_TILE_BYTES) = uint2{__builtin_amdgcn_perm(b1, b0, 0x07060302u), __builtin_amdgcn_perm(b3, b2, 0x07060302u)};
+  } else {
+    cn_store4((HT*)p, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+  }
 }
 
 struct DbPrologue {
@@ -136,11 +169,12 @@ struct DbWeights {
 };
 
 // LDS map (dynamic, bytes)
-#define DB_OFF_A 0                               // activation tile: DB_ROWS rows + one zero row, 512 B each
-#define DB_OFF_X (DB_OFF_A + (DB_ROWS + 1) * 512)  // fp32 residual rows
-#define DB_OFF_V (DB_OFF_X + DB_ROWS * 1024)     // q | k | v rows (fp32); later: pre-LN rows (Y) and cross q (Q)
-#define DB_OFF_P (DB_OFF_V + 3 * DB_ROWS * 1024)  // parameters: bin 768 | bo | bq | bo2 | g1 | b1 | g2 | b2
-#define DB_LDS_BYTES (DB_OFF_P + 2560 * 4)
+#define DB_OFF_A 0                               // activation tile(s): DB_ROWS rows + one zero row, 512 B each (NT = 2 in sp16: hi, lo)
+#define DB_OFF_X(NT) (DB_OFF_A + (NT) * DB_TILE_BYTES)  // fp32 residual rows
+#define DB_OFF_V(NT) (DB_OFF_X(NT) + DB_ROWS * 1024)     // q | k | v rows (fp32); later: pre-LN rows (Y) and cross q (Q)
+#define DB_OFF_P(NT) (DB_OFF_V(NT) + 3 * DB_ROWS * 1024)  // parameters: bin 768 | bo | bq | bo2 | g1 | b1 | g2 | b2
+#define DB_LDS_BYTES_T(NT) (DB_OFF_P(NT) + 2560 * 4)
+#define DB_LDS_BYTES DB_LDS_BYTES_T(1)
 #define DB_P_BO 768
 #define DB_P_BQ 1024
 #define DB_P_BO2 1280
@@ -174,30 +208,40 @@ __device__ __forceinline__ void db_frag_load(F8& dst, const DbStream& st, int m,
 }
 
 // acc[a] (columns n = 64w + 16a + 4(lane >> 4) + j, row m = lane & 15) = A-tile . W[M]^T for this wave's columns;
-// each fragment register is re-loaded with matrix M + 1 right behind its MFMA.  Fragments are consumed in issue
-// order and every consumed one is re-issued, so exactly 31 younger loads are in flight at each wait (fewer only
-// while the last matrix drains); the GEMM waves issue no other vector memory instruction.
-template <int M, typename HT>
-__device__ __forceinline__ void db_gemm_regs(const DbStream& wlane, cn_h8<HT> (&fw)[4][8], const char* sA, int lane,
-                                             f32x4 (&acc)[4]) {
+// each fragment register is re-loaded with the next pass of the stream right behind its MFMA.  Fragments are consumed in
+// issue order and every consumed one is re-issued, so exactly 31 younger loads are in flight at each wait (fewer only
+// while the last pass drains); the GEMM waves issue no other vector memory instruction.
+// P = pass of the stream: 16-bit operands have one pass per matrix (P = matrix); sp16 has two -- P = 2 m: the lo halves of
+// W_m against the hi activation tile (starts the sum), P = 2 m + 1: the hi halves against the lo and the hi tile.
+template <int P, typename HT>
+__device__ __forceinline__ void db_gemm_regs(const DbStream& wlane, cn_h8<typename DbOp<HT>::frag_t> (&fw)[4][8], const char* sA,
+                                             int lane, f32x4 (&acc)[4]) {
   typedef G2Geom<256> G;
+  typedef typename DbOp<HT>::frag_t FT;
+  constexpr int NPH = DbOp<HT>::NPH, LASTP = 6 * NPH - 1;
+  constexpr bool kHiPass = NPH == 2 && (P & 1) == 1;
   const int lr = lane & 15, lq = lane >> 4;
   const int arow = lr < DB_ROWS ? lr : DB_ROWS;  // padding rows of the M tile all read the zero row
   const int asw = lr < DB_ROWS ? (lr & G::SWM) : 0;
+  if (!kHiPass) {
 #pragma unroll
-  for (int a = 0; a < 4; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-  cn_h8<HT> fa = *(const cn_h8<HT>*)(sA + arow * G::RBY + ((lq ^ asw) * 16));
+    for (int a = 0; a < 4; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  cn_h8<FT> fa = *(const cn_h8<FT>*)(sA + arow * G::RBY + ((lq ^ asw) * 16));
+  cn_h8<FT> fl = fa;
+  if (kHiPass) fl = *(const cn_h8<FT>*)(sA + DB_TILE_BYTES + arow * G::RBY + ((lq ^ asw) * 16));
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
-    const cn_h8<HT> fc = fa;
-    if (ks < 7) fa = *(const cn_h8<HT>*)(sA + arow * G::RBY + (((lq + 4 * (ks + 1)) ^ asw) * 16));
+    const cn_h8<FT> fc = fa, fcl = fl;
+    if (ks < 7) {
+      fa = *(const cn_h8<FT>*)(sA + arow * G::RBY + (((lq + 4 * (ks + 1)) ^ asw) * 16));
+      if (kHiPass) fl = *(const cn_h8<FT>*)(sA + DB_TILE_BYTES + arow * G::RBY + (((lq + 4 * (ks + 1)) ^ asw) * 16));
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
-      if (M < 5) {
+      if (P < LASTP) {
         asm volatile("s_waitcnt vmcnt(31)" : "+v"(fw[a][ks]));
       } else {
-        constexpr int kDummy = 0;
-        (void)kDummy;
         switch (31 - (ks * 4 + a)) {  // compile-time after unrolling
 #define DB_WAIT_CASE(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(fw[a][ks])); break;
           DB_WAIT_CASE(31) DB_WAIT_CASE(30) DB_WAIT_CASE(29) DB_WAIT_CASE(28) DB_WAIT_CASE(27) DB_WAIT_CASE(26)
@@ -209,19 +253,33 @@ __device__ __forceinline__ void db_gemm_regs(const DbStream& wlane, cn_h8<HT> (&
 #undef DB_WAIT_CASE
         }
       }
+      if (kHiPass) acc[a] = cn_mma16(fw[a][ks], fcl, acc[a]);
       acc[a] = cn_mma16(fw[a][ks], fc, acc[a]);
-      if (M < 5) db_frag_load(fw[a][ks], wlane, M + 1, a, ks);
+      if (P < LASTP) db_frag_load(fw[a][ks], wlane, P + 1, a, ks);
     }
+  }
+}
+// matrix M of the layer (0 q, 1 k, 2 v, 3 self out-proj, 4 cross q-proj, 5 cross out-proj) in the operand type's passes
+template <int M, typename HT>
+__device__ __forceinline__ void db_gemm_mat(const DbStream& wlane, cn_h8<typename DbOp<HT>::frag_t> (&fw)[4][8], const char* sA,
+                                            int lane, f32x4 (&acc)[4]) {
+  if constexpr (DbOp<HT>::NPH == 2) {
+    db_gemm_regs<2 * M, HT>(wlane, fw, sA, lane, acc);
+    db_gemm_regs<2 * M + 1, HT>(wlane, fw, sA, lane, acc);
+  } else {
+    db_gemm_regs<M, HT>(wlane, fw, sA, lane, acc);
   }
 }
 
 // row LayerNorm (eps 1e-5) of a lane's 4 columns of one 256-wide row
+template <bool EXACT = false>
 __device__ __forceinline__ f32x4 db_row_ln(const f32x4& v, const float* g, const float* b, int lane) {
   const float mean = cn_wave_sum_dpp(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
   float s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) s2 = fmaf(v[i] - mean, v[i] - mean, s2);
-  const float rstd = __builtin_amdgcn_rsqf(cn_wave_sum_dpp(s2) * (1.0f / 256.0f) + 1e-5f);
+  const float var = cn_wave_sum_dpp(s2) * (1.0f / 256.0f) + 1e-5f;
+  const float rstd = EXACT ? 1.0f / sqrtf(var) : __builtin_amdgcn_rsqf(var);
   const f32x4 gg = *(const f32x4*)(g + 4 * lane), bb = *(const f32x4*)(b + 4 * lane);
   f32x4 r;
 #pragma unroll
@@ -254,12 +312,15 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
   if (gate != nullptr && *gate == 0) return;  // every hypothesis has finished (beam.py:192-194 stops here)
   typedef G2Geom<256> G;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename DbOp<HT>::frag_t FT;
+  constexpr int NT = DbOp<HT>::NPH;  // activation tiles (sp16: hi and lo halves)
+  constexpr bool kXL = DbOp<HT>::kExactLn;
   char* sA = smem + DB_OFF_A;
-  float* sX = (float*)(smem + DB_OFF_X);
-  float* sV = (float*)(smem + DB_OFF_V);
+  float* sX = (float*)(smem + DB_OFF_X(NT));
+  float* sV = (float*)(smem + DB_OFF_V(NT));
   float* sY = sV;                      // pre-LayerNorm rows (after q | k | v are dead)
   float* sQ = sV + DB_ROWS * 256;      // scaled cross-attention queries
-  float* sP = (float*)(smem + DB_OFF_P);
+  float* sP = (float*)(smem + DB_OFF_P(NT));
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r0 = blockIdx.x * DB_ROWS;
@@ -268,7 +329,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
     // ======================= GEMM waves ========================================================
     const int lr = lane & 15, lq = lane >> 4;
     const DbStream wlane{(const char*)wt.stream, (unsigned)(wave * 4 * 4096 + lane * 8) * 2u};
-    cn_h8<HT> fw[4][8];
+    cn_h8<FT> fw[4][8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
@@ -276,7 +337,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
     f32x4 acc[4];
     DB_SYNC();  // b1: x rows (sA) and parameters (sP) are in LDS
     {           // q | k | v
-      db_gemm_regs<0, HT>(wlane, fw, sA, lane, acc);
+      db_gemm_mat<0, HT>(wlane, fw, sA, lane, acc);
       if (lr < DB_ROWS)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -284,7 +345,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
           const f32x4 bb = *(const f32x4*)(sP + n);
           *(f32x4*)(sV + (0 * DB_ROWS + lr) * 256 + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
         }
-      db_gemm_regs<1, HT>(wlane, fw, sA, lane, acc);
+      db_gemm_mat<1, HT>(wlane, fw, sA, lane, acc);
       if (lr < DB_ROWS)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -292,7 +353,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
           const f32x4 bb = *(const f32x4*)(sP + 256 + n);
           *(f32x4*)(sV + (1 * DB_ROWS + lr) * 256 + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
         }
-      db_gemm_regs<2, HT>(wlane, fw, sA, lane, acc);
+      db_gemm_mat<2, HT>(wlane, fw, sA, lane, acc);
       if (lr < DB_ROWS)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -304,7 +365,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
     DB_SYNC();  // b2: q | k | v ready
     DB_SYNC();  // b3: self-attention output in sA
     {
-      db_gemm_regs<3, HT>(wlane, fw, sA, lane, acc);
+      db_gemm_mat<3, HT>(wlane, fw, sA, lane, acc);
       if (lr < DB_ROWS)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -316,7 +377,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
     DB_SYNC();  // b4: pre-LN1 rows ready
     DB_SYNC();  // b5: x1 in sX / sA
     {
-      db_gemm_regs<4, HT>(wlane, fw, sA, lane, acc);
+      db_gemm_mat<4, HT>(wlane, fw, sA, lane, acc);
       if (lr < DB_ROWS)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -328,7 +389,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
     DB_SYNC();  // b6: cross queries ready
     DB_SYNC();  // b7: cross-attention output in sA
     {
-      db_gemm_regs<5, HT>(wlane, fw, sA, lane, acc);
+      db_gemm_mat<5, HT>(wlane, fw, sA, lane, acc);
       if (lr < DB_ROWS)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
@@ -347,7 +408,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
   const bool live = r0 + rw < R;
   const int rt = tid - 256;
   unsigned long long t_prev = dbg ? wall_clock64() : 0ull;
-  if (rt < 32) ((uint4*)(sA + DB_ROWS * 512))[rt] = uint4{0, 0, 0, 0};  // the zero row
+  if (rt < 32 * NT) ((uint4*)(sA + (rt >> 5) * DB_TILE_BYTES + DB_ROWS * 512))[rt & 31] = uint4{0, 0, 0, 0};  // the zero row(s)
   // parameters -> LDS, 10 pieces of 1 KB by LDS-DMA (landed before this wave's younger P0 loads, i.e. before b1)
 #pragma unroll
   for (int c = 0; c < (10 + DB_ROWS - 1) / DB_ROWS; ++c) {
@@ -383,7 +444,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
         for (int i = 0; i < 4; ++i) v[i] += u[sl][i];
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] += bb[i] + rs[i];
-      xr = db_row_ln(v, pro.g3, pro.b3, lane);
+      xr = db_row_ln<kXL>(v, pro.g3, pro.b3, lane);
     }
     *(f32x4*)(sX + rw * 256 + 4 * lane) = xr;
     db_store_row<HT>(sA, rw, lane, xr, 1.0f);
@@ -413,8 +474,8 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       q[i] *= scale;
-      kn[i] = (float)cn_from_f32<HT>(kn[i]);  // cache precision
-      vn[i] = (float)cn_from_f32<HT>(vn[i]);
+      kn[i] = cn_to_f32(cn_from_f32<HT>(kn[i]));  // cache precision
+      vn[i] = cn_to_f32(cn_from_f32<HT>(vn[i]));
     }
     if (live) {
       cn_store4(kc + ((size_t)step * R + tr) * 256 + 4 * lane, kn[0], kn[1], kn[2], kn[3]);
@@ -445,7 +506,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
   // ---- LN1 --------------------------------------------------------------------------------------------
   {
     const f32x4 y = *(const f32x4*)(sY + rw * 256 + 4 * lane);
-    const f32x4 x1 = db_row_ln(y, sP + DB_P_G1, sP + DB_P_B1, lane);
+    const f32x4 x1 = db_row_ln<kXL>(y, sP + DB_P_G1, sP + DB_P_B1, lane);
     *(f32x4*)(sX + rw * 256 + 4 * lane) = x1;
     db_store_row<HT>(sA, rw, lane, x1, 1.0f);
   }
@@ -470,7 +531,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
   // ---- LN2 -> x, xt ---------------------------------------------------------------------------------------
   {
     const f32x4 y = *(const f32x4*)(sY + rw * 256 + 4 * lane);
-    const f32x4 x2 = db_row_ln(y, sP + DB_P_G2, sP + DB_P_B2, lane);
+    const f32x4 x2 = db_row_ln<kXL>(y, sP + DB_P_G2, sP + DB_P_B2, lane);
     if (live) {
       *(f32x4*)(x + (size_t)tr * 256 + 4 * lane) = x2;
       cn_store4(xt + (size_t)tr * 256 + 4 * lane, x2[0], x2[1], x2[2], x2[3]);
@@ -480,4 +541,6 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
   if (dbg && lane == 0 && rw == 0) atomicAdd(&g_db_prof[9], 1ull);
 }
 
-template <typename HT> static inline int cn_dec_block_setup() { return cn_configure_lds((const void*)cn_dec_block_kernel<HT>, DB_LDS_BYTES); }
+template <typename HT> static inline int cn_dec_block_setup() {
+  return cn_configure_lds((const void*)cn_dec_block_kernel<HT>, DB_LDS_BYTES_T(DbOp<HT>::NPH));
+}

@@ -859,7 +859,11 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
       hipLaunchKernelGGL(cn_force_tok_kernel, dim3(cn_cdiv(B, 64)), dim3(64), 0, s, force_caps, B, maxp, step, w.cur_tok);
       CN_LAUNCH_CHECK();
     }
-    const bool block_path = CnIsH16<T>::value && !ctx->dec_unfused;
+    // fused path (dec_block.h + dec_ffn.h): 16-bit operands, and since round 4 the exact precision (hi / lo passes of the same
+    // two kernels; needs both packed streams, i.e. d_ff % 256 == 0 and d_ff <= 2048)
+    constexpr bool kBlockT = CnIsH16<T>::value || std::is_same<T, sp16_t>::value;
+    const bool block_path = kBlockT && !ctx->dec_unfused && ctx->layers[0].blk_w != nullptr &&
+                            (CnIsH16<T>::value || (ctx->layers[0].ffn_w != nullptr && dff / 256 <= FF2_SPLITS));
     // device-side early exit: once every hypothesis of every clip has finished the reference leaves its loop
     // (beam.py:192-194); the launch sequence is static (hipGraph), so the heavy kernels of the remaining steps read the
     // number of rows still searching and return at once
@@ -875,8 +879,8 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
 #else
     constexpr int db_debug = 0;
 #endif
-    if constexpr (CnIsH16<T>::value) if (block_path) {
-      // default 16-bit path: 3 launches per layer -- fused block (embedding | previous LN3, QKV, self-attention,
+    if constexpr (kBlockT) if (block_path) {
+      // default path: 3 launches per layer -- fused block (embedding | previous LN3, QKV, self-attention,
       // cross-attention: dec_block.h), FFN1 GEMM + GELU, FFN2 split-K slabs (summed by the next layer's block
       // prologue; the last layer's by the LN3 kernel in front of the classifier)
       fused_done = true;
@@ -903,17 +907,18 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
           wt.stream = lw.blk_w;
           wt.params = lw.blk_p;
           CN_TRY(cn_dec_block_setup<T>());
-          hipLaunchKernelGGL(cn_dec_block_kernel<T>, dim3(cn_cdiv(R, DB_ROWS)), dim3(DB_THREADS), DB_LDS_BYTES, s, pro, wt, kc, vc,
+          hipLaunchKernelGGL(cn_dec_block_kernel<T>, dim3(cn_cdiv(R, DB_ROWS)), dim3(DB_THREADS), DB_LDS_BYTES_T(DbOp<T>::NPH), s, pro, wt, kc, vc,
                              w.anc, step, R, beam, maxp, (const T*)kvc, kv_ld, l * 2 * d, frame_lens, Ta, w.x, xt,
                              scale, kvalid, db_debug, gate);
           CN_LAUNCH_CHECK();
         }
         if (ffn_fused) {
           CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
-          hipLaunchKernelGGL(cn_dec_ffn_kernel<T>, dim3(cn_cdiv(R, DF_ROWS), dff / 256), dim3(256), 0, s, (const T*)xt, R,
-                             (const T*)lw.ffn_w, lw.ff1_b, w.slabs, slab, gate);
+          CN_TRY(cn_dec_ffn_setup<T>());
+          hipLaunchKernelGGL(cn_dec_ffn_kernel<T>, dim3(cn_cdiv(R, DF_ROWS), dff / 256), dim3(256), DF_LDS_BYTES_T(DbOp<T>::NPH), s, (const T*)xt, R,
+                             lw.ffn_w, lw.ff1_b, w.slabs, slab, gate);
           CN_LAUNCH_CHECK();
-        } else {
+        } else if constexpr (CnIsH16<T>::value) {
           {
             CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
             EpiBiasAct<T, ACT_GELU_FAST> e1{lw.ff1_b, ffh, dff, ACT_GELU_FAST};
@@ -936,7 +941,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
       {
         CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
         EpiBiasAct<float, ACT_NONE> ec{ctx->cls_b, w.logits, w.ldv, ACT_NONE};
-        CN_TRY(cn_gemm2(xt, d, (const T*)ctx->cls_w, d, R, V, d, ec, s));
+        CN_TRY(cn_mm(xt, d, (const T*)ctx->cls_w, d, R, V, d, ec, s));
       }
     }
     if (!fused_done) {

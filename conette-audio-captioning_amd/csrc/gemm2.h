@@ -487,8 +487,10 @@ static int cn_gemm2_sp(const sp16_t* A, int lda, const sp16_t* W, int ldw, int M
   const bf16_t* w = (const bf16_t*)W;
   if (M >= 4096) {
     const bool n96 = (N % 96 == 0) && (N % 128 != 0);
-    if (n96) return cn_launch_gemm2_t<128, 96, 64, 2, Epi, 2, 2, 1>(a, 2 * lda, w, 2 * ldw, M, N, 2 * K, 1, epi, stream);
-    return cn_launch_gemm2_t<128, 128, 64, 2, Epi, 2, 2, 1>(a, 2 * lda, w, 2 * ldw, M, N, 2 * K, 1, epi, stream);
+    // (splits is honoured by every tile shape: the exact decoder's FFN2 asks for split-K slabs at any row count, and a launch
+    // that ignored it would leave slabs 1 .. splits - 1 unwritten for the LayerNorm that sums them -- ADVICE r03)
+    if (n96) return cn_launch_gemm2_t<128, 96, 64, 2, Epi, 2, 2, 1>(a, 2 * lda, w, 2 * ldw, M, N, 2 * K, splits, epi, stream);
+    return cn_launch_gemm2_t<128, 128, 64, 2, Epi, 2, 2, 1>(a, 2 * lda, w, 2 * ldw, M, N, 2 * K, splits, epi, stream);
   }
   return cn_launch_gemm2_t<64, 64, 64, 2, Epi, 2, 2, 1>(a, 2 * lda, w, 2 * ldw, M, N, 2 * K, splits, epi, stream);
 }

@@ -89,3 +89,68 @@ def test_sp16_split_holds_22_bits():
     err = (hi.float() + lo.float() - x).abs()
     bound = torch.maximum(x.abs() * 2.0 ** -22, torch.full_like(x, 2.0 ** -25))
     assert bool((err <= bound).all()), float((err / bound).max())
+
+
+def _decode_inputs(synth_weights, n, seed=99, t=31):
+    g = torch.Generator().manual_seed(seed)
+    fe = torch.randn((n, t, 768), generator=g) * 0.5
+    lens = torch.randint(t // 2, t + 1, (n,), generator=g, dtype=torch.int32)
+    bos = synth_weights["model.task_id_to_token_id"][torch.randint(0, 3, (n,), generator=g)]
+    return fe.cuda(), lens, bos, synth_weights["model.forbid_rep_mask"]
+
+
+@pytest.mark.parametrize("beam,max_pred,n", [(3, 20, 64), (8, 12, 9), (1, 20, 5), (5, 30, 7)])
+def test_exact_fused_decoder_equals_the_per_sublayer_path(beam, max_pred, n, engines, synth_weights):
+    """Round 4: the exact decode runs the fused block / FFN kernels on hi / lo passes (dec_block.h, dec_ffn.h: 3 launches per
+    layer).  The per-sub-layer path it replaces (11 launches per layer, cn_gemm2<SP>) stays as the cross-check: same ids, same
+    hypotheses, scores within the fp32 tolerance -- both are 22-bit-operand evaluations of the same sums in another order."""
+    eng = engines["exact"]
+    fe, lens, bos, fm = _decode_inputs(synth_weights, n)
+    a = eng.decode(fe, lens, bos, fm, beam, 3, max_pred, want_trace=True)
+    eng.set_decode_fusion(False)
+    try:
+        b = eng.decode(fe, lens, bos, fm, beam, 3, max_pred, want_trace=True)
+    finally:
+        eng.set_decode_fusion(True)
+    torch.cuda.synchronize()
+    # (a caption may differ only where the search meets a tie narrower than the two paths' rounding noise: none on these seeds)
+    for k in ("best_preds", "mult_preds", "trace_sel"):
+        assert torch.equal(a[k], b[k]), k
+    torch.testing.assert_close(a["best_lprobs"], b["best_lprobs"], rtol=0, atol=2e-5)
+    torch.testing.assert_close(a["mult_lprobs"], b["mult_lprobs"], rtol=0, atol=2e-5)
+    torch.testing.assert_close(a["trace_val"], b["trace_val"], rtol=0, atol=2e-4)
+
+
+def test_exact_decode_graph_is_the_fused_launch_sequence(engines, synth_weights):
+    """<= 400 graph nodes per 20-step search (1 386 with one launch per sub-layer; the bf16 structure has 306)"""
+    eng = engines["exact"]
+    fe, lens, bos, fm = _decode_inputs(synth_weights, 16)
+    side = torch.cuda.Stream()  # (the legacy default stream cannot be captured)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):  # eager, capture, replay
+            eng.decode(fe, lens, bos, fm, 3, 3, 20, clone=False, slot=7)
+    torch.cuda.synchronize()
+    assert 0 < eng.decode_graph_nodes() <= 400, eng.decode_graph_nodes()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_exact_decode_at_4096_rows(fused, engines, synth_weights):
+    """R = batch x beam >= 4096 takes the 128-row GEMM tiles in the per-sub-layer path; its split-K FFN2 must write every slab
+    the LayerNorm sums (`splits` was dropped there).  Checked against the same clips decoded 64 at a time."""
+    eng = engines["exact"]
+    n, beam = 512, 8
+    fe, lens, bos, fm = _decode_inputs(synth_weights, n, seed=5)
+    fe = fe[:64].repeat(n // 64, 1, 1).contiguous()
+    lens, bos = lens[:64].repeat(n // 64), bos[:64].repeat(n // 64)
+    eng.set_decode_fusion(fused)
+    try:
+        big = eng.decode(fe, lens, bos, fm, beam, 3, 8)
+        small = eng.decode(fe[:64], lens[:64], bos[:64], fm, beam, 3, 8)
+    finally:
+        eng.set_decode_fusion(True)
+    torch.cuda.synchronize()
+    for k in ("best_preds", "mult_preds"):
+        v = big[k].view(n // 64, 64, *big[k].shape[1:])
+        assert torch.equal(v, small[k][None].expand_as(v)), k
+    torch.testing.assert_close(big["best_lprobs"].view(n // 64, 64), small["best_lprobs"][None].expand(n // 64, 64), rtol=0, atol=2e-5)
