@@ -70,7 +70,7 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: CPU self-test of the launcher / sharding / gather path (no GPU work, no timing)")
     ap.add_argument("--master-port", type=int, default=0)
-    ap.add_argument("--also", default="bf16+f16dec,f16,mixed16",
+    ap.add_argument("--also", default="bf16+f16dec,f16,mixed16,exact",
                     help="N = 1, fixed workload, bf16 only: after the run, the SAME pipelined benchmark at these precisions (one child "
                          "process each, 3 windows, no CPU / parity legs), reported under `also_pipelined` ('' = skip)")
     return ap.parse_args(argv)
@@ -99,19 +99,30 @@ def pmc_table(suffix: str):
     return files[-1] if files else None
 
 
+def _build_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_conette_build", os.path.join(ROOT, "conette-audio-captioning_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def pmc_is_current(path: str):
-    """True / False: the PMC table was measured on the library that is running now (tools/profile_round.sh writes the
-    library's sha256 next to the tables); None: no record (tables of earlier rounds)."""
-    import hashlib
+    """True / False: the PMC table was measured on a build of the sources the running library was built from
+    (tools/profile_round.sh writes build.py's source hash -- csrc/ + header + flags -- next to the tables, build.py writes the
+    same hash next to the library; a binary hash would turn false for anyone who recompiles: VERDICT r03).  None: no record
+    (tables of rounds 1-3 carry a binary hash only)."""
     meta = path.rsplit("_pmc_", 1)[0] + "_pmc_meta.json"
-    lib = os.path.join(ROOT, "conette-audio-captioning_amd", "libconette_hip.so")
-    if not os.path.exists(meta) or not os.path.exists(lib):
+    if not os.path.exists(meta):
         return None
     try:
-        want = json.load(open(meta)).get("library_sha256")
+        want = json.load(open(meta)).get("source_sha256")
+        have = _build_module().built_source_hash()
     except (OSError, ValueError):
         return None
-    return hashlib.sha256(open(lib, "rb").read()).hexdigest() == want
+    if want is None or have is None:
+        return None
+    return want == have
 
 
 def pmc_traffic(cls: str, batch: int, launches_per_step: float):
@@ -186,7 +197,7 @@ def gloo_selftest(args, rank: int, world: int) -> None:
     import torch
     import torch.distributed as dist
     import conette_amd  # noqa: F401
-    from conette_amd.dist import gather_captions, shard_bounds, trim_captions
+    from conette_amd.dist import gather_caption_windows, gather_captions, shard_bounds, trim_captions
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     total = args.global_batch if args.global_batch > 0 else world * args.batch
@@ -198,6 +209,11 @@ def gloo_selftest(args, rank: int, world: int) -> None:
     scores = -torch.arange(total, dtype=torch.float32)
     p, l = gather_captions(full[lo:hi].clone(), scores[lo:hi].clone(), total)
     ok = torch.equal(p, full) and torch.equal(l, scores) and trim_captions(p).shape[1] == 8
+    # the per-window form the timed loop uses: K steps' tables in one collective
+    fk = torch.stack([full + k for k in range(3)])
+    sk = torch.stack([scores - k for k in range(3)])
+    pk, lk = gather_caption_windows(fk[:, lo:hi].clone(), sk[:, lo:hi].clone(), total)
+    ok = ok and torch.equal(pk, fk) and torch.equal(lk, sk)
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
@@ -456,7 +472,7 @@ def main() -> None:
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from conette_amd.dist import gather_captions, shard_bounds, trim_captions
+    from conette_amd.dist import gather_caption_windows, shard_bounds, trim_captions
     from conette_amd.engine import Engine
 
     beam, min_pred, max_pred = args.beam, 3, int(os.environ.get("CN_MAX_PRED", "20"))  # (CN_MAX_PRED: interference experiments only)
@@ -478,10 +494,13 @@ def main() -> None:
     forbid = sd["model.forbid_rep_mask"].to(dev)
 
     if args.workload == "mixed":
-        from conette_amd.bucketing import plan_buckets
+        from conette_amd.bucketing import plan_buckets, plan_buckets_by_cost
         rng = np.random.default_rng(1234 + clip0)
         lengths = rng.integers(1 * SR, 30 * SR + 1, size=B)
-        buckets = plan_buckets(lengths.tolist(), max_padded_seconds=float(os.environ.get("CN_BUCKET_SECONDS", "960")), sr=SR)
+        if os.environ.get("CN_BUCKET_SECONDS"):   # (round 3's planner: a padded-seconds budget per bucket)
+            buckets = plan_buckets(lengths.tolist(), max_padded_seconds=float(os.environ["CN_BUCKET_SECONDS"]), sr=SR)
+        else:                                     # minimum modelled cost: padded audio + a fixed cost per bucket
+            buckets = plan_buckets_by_cost(lengths.tolist(), fixed_cost_seconds=float(os.environ.get("CN_BUCKET_FIXED", "150")), sr=SR)
         batches = []
         for idx in buckets:
             ls = [int(lengths[i]) for i in idx]
@@ -508,8 +527,14 @@ def main() -> None:
     # stretches to the length of an encode when it shares the chip with one; with two chains (batches i-1 and i-2 decode
     # while batch i encodes) a chain may take two steps, and the step is bounded by the encoder again.
     # (the exact precision's decode is the one-launch-per-sub-layer path, 12 ms alone at B = 64: three chains in flight)
-    n_dec = max(1, min(int(os.environ.get("CN_DEC_STREAMS", "3" if args.precision in ("exact", "mixed", "mixed16") else "2")), 3))  # (four and more chains: 2x slower, measured)
-    s_decs = [torch.cuda.Stream(dev, priority=prio) for _ in range(n_dec)]
+    # (mixed-length workload: every bucket of a step is a decode chain of its own -- three streams, dealt bucket by bucket)
+    n_dec = max(1, min(int(os.environ.get("CN_DEC_STREAMS", "3" if (args.precision in ("exact", "mixed", "mixed16") or args.workload == "mixed") else "2")), 3))  # (four and more chains: 2x slower, measured)
+    dec_cus = int(os.environ.get("CN_DEC_CUS", "0"))   # > 0: the decode chains are confined to this many compute units (CU-masked streams)
+    if dec_cus > 0:
+        from conette_amd.engine import make_masked_stream
+        s_decs = [make_masked_stream(dev, dec_cus) for _ in range(n_dec)]
+    else:
+        s_decs = [torch.cuda.Stream(dev, priority=prio) for _ in range(n_dec)]
     n_slot = n_dec + 1
     from conette_amd.engine import MAX_DECODE_GRAPHS
     if len(batches) * n_slot > MAX_DECODE_GRAPHS:
@@ -534,7 +559,7 @@ def main() -> None:
             sl = slots[n_slot * k + (i % n_slot)]
             bos = bos_dev[k]
             s_enc = s_encs[i % len(s_encs)]
-            s_dec = s_decs[i % n_dec]
+            s_dec = s_decs[(i * len(batches) + k) % n_dec]   # consecutive buckets decode on different streams
             with torch.cuda.stream(s_enc):
                 if i >= n_slot:
                     s_enc.wait_event(sl["dec_done"])          # slot's frame buffer is free again
@@ -545,19 +570,32 @@ def main() -> None:
                 out = eng.decode(sl["fe"], lens_, bos, forbid, beam, min_pred, max_pred, clone=False, slot=n_slot * k + (i % n_slot))
                 res.append((out["best_preds"], out["best_lprobs"]))
                 sl["dec_done"].record(s_dec)
-        with torch.cuda.stream(s_decs[i % n_dec]):
+        s_last = s_decs[(i * len(batches) + len(batches) - 1) % n_dec]
+        with torch.cuda.stream(s_last):
+            if len(batches) > 1:
+                for s_ in s_decs:
+                    s_last.wait_stream(s_)
             preds = res[0][0] if len(res) == 1 else torch.cat([r[0] for r in res])
             lps = res[0][1] if len(res) == 1 else torch.cat([r[1] for r in res])
             state["last_local"] = (preds, lps)  # this rank's captions of the step (before the all-gather)
-            if state.get("keep") is not None and i < state["keep"][0].shape[0]:  # batch 0's result of every timed step, compared after the run
-                kp, kl = state["keep"]
-                kp[i].copy_(preds[: kp.shape[1], : kp.shape[2]], non_blocking=True)
-                kl[i].copy_(lps[: kl.shape[1]], non_blocking=True)
-            if world > 1:
-                preds, lps = gather_captions(preds, lps, total_clips)
+            if state.get("keep") is not None and i < state["keep"][0].shape[0]:  # every local caption of every timed step: compared
+                kp, kl = state["keep"]                                          # with the solo pass after the run, gathered per window
+                kp[i, : preds.shape[0]].copy_(preds[:, : kp.shape[2]], non_blocking=True)
+                kl[i, : lps.shape[0]].copy_(lps, non_blocking=True)
         state["i"] = i + 1
         state["last"] = out
+        state["last_stream"] = s_last
         return preds, lps
+
+    def gather_window(first, count):
+        """N > 1: the ONE collective of a timed window -- ids + scores of all its steps, all ranks, in clip order (north_star:
+        'an RCCL all-gather only to return final token ids').  Enqueued behind the window's last decode on that decode's
+        stream, so no rank waits for another inside the window: a per-step gather would be a per-step rendezvous."""
+        kp, kl = state["keep"]
+        with torch.cuda.stream(state["last_stream"]):
+            for s_ in s_decs:
+                state["last_stream"].wait_stream(s_)
+            return gather_caption_windows(kp[first: first + count], kl[first: first + count], total_clips)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -600,25 +638,54 @@ def main() -> None:
     state["i"] = 0
     n_rep = max(1, args.repeat)
     n_timed = n_rep * args.steps
-    n_keep = n_timed if os.environ.get("CN_BENCH_CHECK_ALL", "1") != "0" else 0  # (0: only the last step is compared)
-    state["keep"] = (torch.zeros((n_keep,) + tuple(solo_preds.shape), dtype=solo_preds.dtype, device=dev),
-                     torch.zeros((n_keep,) + tuple(solo_lps.shape), dtype=solo_lps.dtype, device=dev))
+    n_keep = n_timed if (world > 1 or os.environ.get("CN_BENCH_CHECK_ALL", "1") != "0") else 0  # (0: only the last step is compared)
+    state["keep"] = (torch.zeros((n_keep, B, solo_preds.shape[1]), dtype=solo_preds.dtype, device=dev),
+                     torch.zeros((n_keep, B), dtype=solo_lps.dtype, device=dev))
     win_dt, own_dt = [], []
-    for _ in range(n_rep):
+    gathered = None
+    for w_i in range(n_rep):
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-        torch.cuda.synchronize(dev)
-        own_dt.append(time.perf_counter() - t0)   # this rank's own work (before it waits for the others)
+        if world > 1:      # (this rank's own work ends where its last decode ends; the gather behind it waits for the others)
+            for s_ in s_decs + s_encs:
+                s_.synchronize()
+            own_dt.append(time.perf_counter() - t0)
+            gathered = gather_window(w_i * args.steps, args.steps)   # inside the timed window: the path's one collective
+            torch.cuda.synchronize(dev)
+        else:
+            torch.cuda.synchronize(dev)
+            own_dt.append(time.perf_counter() - t0)   # this rank's own work
         fence()
         win_dt.append(time.perf_counter() - t0)
     # the pipelined steps (encode of batch i next to the decodes of batches i-1, i-2) must reproduce the solo pass bit for bit
     lp_, ll_ = state["last_local"][0][:B0], state["last_local"][1][:B0]
-    kp, kl = state["keep"]
+    kp_all, kl_all = state["keep"]
     state["keep"] = None
+    kp, kl = kp_all[:, :B0], kl_all[:, :B0]      # batch 0 (the only one of the fixed workload) of every timed step against the solo pass
     wp = min(kp.shape[2], lp_.shape[1])  # timed steps whose captions / scores of batch 0 differ from the solo pass
     bad_steps = int(((kp[:, :, :wp] != solo_preds[None, :, :wp]).flatten(1).any(dim=1) | (kl != solo_lps[None]).flatten(1).any(dim=1)).sum().item())
+    # what the job returns: the (all-gathered) ids of the last timed step, every clip, in clip order.  Its hash lets a sharded run be
+    # compared with the single-GPU run of the same clips (tests/test_gpu_bench_n2.py); on N > 1 every rank must hold the same table.
+    import hashlib
+    final_ids = gathered[0][-1] if gathered is not None else state["last_local"][0]
+    final_ids = trim_captions(final_ids.cpu()) if final_ids.numel() else final_ids.cpu()
+    captions_sha = hashlib.sha256(final_ids.to(torch.int32).contiguous().numpy().tobytes()).hexdigest()
+    gather_consistent = None
+    if world > 1:   # my rows of the gathered table (last window) are what I decoded, scores included; and every rank holds the same table
+        first = (n_rep - 1) * args.steps
+        ok_g = bool(torch.equal(gathered[0][:, clip0: clip0 + B], kp_all[first: first + args.steps]) and
+                    torch.equal(gathered[1][:, clip0: clip0 + B], kl_all[first: first + args.steps]))
+        dig = torch.tensor(list(bytes.fromhex(captions_sha)), dtype=torch.int32, device=cdev)
+        lo_d, hi_d = dig.clone(), dig.clone()
+        dist.all_reduce(lo_d, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_d, op=dist.ReduceOp.MAX)
+        flag_g = torch.tensor([1 if (ok_g and torch.equal(lo_d, hi_d)) else 0], dtype=torch.int32, device=cdev)
+        dist.all_reduce(flag_g, op=dist.ReduceOp.MIN)
+        gather_consistent = bool(flag_g.item())
+        if not gather_consistent:
+            raise SystemExit("bench: the all-gathered caption table differs between ranks or from a rank's own results")
     pipeline_consistent = bool(bad_steps == 0 and torch.equal(lp_[:, : solo_preds.shape[1]], solo_preds[: lp_.shape[0], : lp_.shape[1]]) and
                                torch.equal(ll_, solo_lps[: ll_.shape[0]]))
     if not pipeline_consistent:
@@ -694,6 +761,8 @@ def main() -> None:
         result = {
             "metric": "clips_per_sec", "value": round(clips_per_s, 2), "unit": "clips/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "warmup_run": warm_used, "ms_per_step": round(dt / args.steps * 1e3, 3), "pipeline_consistent": pipeline_consistent, "pipeline_steps_checked": n_keep if n_keep else 1,
+            "captions_sha256": captions_sha, "gather": ({"collectives_per_window": 2, "consistent_across_ranks": gather_consistent,
+                                                        "what": "ids (K, B, max_pred) int32 + scores (K, B) fp32 of all K steps of a window, once per window"} if world > 1 else None),
             "timed_region_s": round(dt, 4), "repeat": n_rep,
             "windows": {"clips_per_sec": [round(total_clips * args.steps / w, 2) for w in win_dt], "median_index": med,
                         "spread": round((max(win_dt) - min(win_dt)) / dt, 4), "timed_total_s": round(sum(win_dt), 4)},

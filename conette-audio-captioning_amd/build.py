@@ -1,6 +1,7 @@
 """Build the gfx950 shared library in-tree: hipcc -> conette-audio-captioning_amd/libconette_hip.so."""
 from __future__ import annotations
 
+import json
 import os
 import shutil
 import subprocess
@@ -43,22 +44,45 @@ def hipcc() -> str:
 FILE_FLAGS = {} if os.environ.get("CN_ALLOW_PK_HAZARD") else {"frontend.hip": ["-fno-slp-vectorize"], "decoder.hip": ["-fno-slp-vectorize"]}
 
 
+SIDECAR = os.path.join(HERE, "libconette_hip.build.json")   # what LIB was built from: source hash + flags (travels with the .so)
+
+
+def source_hash() -> str:
+    """sha256 over every file of csrc/ + the public header + the compiler flags (per file) -- the identity of a build.  A
+    rebuild of the same sources gives another BINARY hash (checked in round 3), so staleness and 'which build do these PMC
+    tables describe' (bench.py pmc_is_current, tools/profile_round.sh) are both keyed on this instead."""
+    import hashlib
+    h = hashlib.sha256()
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if not f.startswith(".")) + [os.path.join(HERE, "..", "include", "conette_hip.h")]
+    for d in deps:
+        h.update(os.path.basename(d).encode() + b"\0")
+        h.update(open(d, "rb").read())
+    h.update(repr((FLAGS, sorted(FILE_FLAGS.items()), os.environ.get("CN_FE_SRC", ""), os.environ.get("CN_FE_FLAGS", ""))).encode())
+    return h.hexdigest()
+
+
+def built_source_hash():
+    """the source hash recorded beside the library when it was linked (None: no library or no record)"""
+    try:
+        return json.load(open(SIDECAR)).get("source_sha256") if os.path.exists(LIB) else None
+    except (OSError, ValueError):
+        return None
+
+
 def _stale() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "conette_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return built_source_hash() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
     cc = hipcc()
+    src_hash = source_hash()   # taken BEFORE compiling: an edit made while hipcc runs must leave the result stale
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
 
     def one(src):
+        import hashlib
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         extra = list(FILE_FLAGS.get(src, []))
         if src == "frontend.hip":
@@ -67,28 +91,68 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if src == "frontend.hip" and os.environ.get("CN_FE_SRC"):   # lab: the instrumented copy (tools/lab/frontend_lab.hip)
             path = os.path.abspath(os.environ["CN_FE_SRC"])
         cmd = [cc, *FLAGS, *extra, "-c", path, "-o", obj]
-        r = subprocess.run(cmd, capture_output=True, text=True)
+        # per-object cache: the object is reused when the command line and every repo file it was compiled from (-MD list) are
+        # unchanged -- an edit to decoder.hip or dec_block.h recompiles one file, not four
+        stamp = obj + ".stamp"
+
+        def digest(files):
+            h = hashlib.sha256(repr(cmd).encode())
+            for f in sorted(files):
+                h.update(f.encode() + b"\0" + open(f, "rb").read())
+            return h.hexdigest()
+        if not force and os.path.exists(obj) and os.path.exists(stamp):
+            try:
+                rec = json.load(open(stamp))
+                if all(os.path.exists(f) for f in rec["deps"]) and digest(rec["deps"]) == rec["digest"]:
+                    return obj
+            except (OSError, ValueError, KeyError):
+                pass
+        import time
+        t_start = time.time()
+        r = subprocess.run(cmd + ["-MD", "-MF", obj + ".d"], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-4000:]}")
         if verbose and r.stderr:
             print(r.stderr, file=sys.stderr)
+        try:   # repo files among the dependencies (system / ROCm headers belong to the image)
+            toks = open(obj + ".d").read().replace("\\\n", " ").split()
+            root = os.path.abspath(os.path.join(HERE, ".."))
+            deps = sorted({os.path.abspath(t) for t in toks[1:] if os.path.abspath(t).startswith(root)})
+            if all(os.path.getmtime(f) < t_start for f in deps):   # (a file edited while hipcc ran: no stamp, recompiled next time)
+                json.dump({"deps": deps, "digest": digest(deps)}, open(stamp, "w"))
+            elif os.path.exists(stamp):
+                os.remove(stamp)
+        except OSError:
+            pass
         return obj
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(one, SOURCES))
-    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
-    if not os.environ.get("CN_ALLOW_PK_HAZARD"):   # (lab builds that reproduce the fault set it)
-        try:
-            from . import isa_lint
-        except ImportError:   # run as a script
-            import isa_lint
-        bad = isa_lint.lint_library(LIB)
-        if bad:
-            os.remove(LIB)
-            raise RuntimeError("isa_lint: the library contains packed-fp32 instructions of the form MI355X executes wrongly beside bf16 MFMAs "
-                               f"(v_pk_*_f32 op_sel:[0,1..]): {bad[:4]} ... {len(bad)} in all")
+    # link to a temporary path, lint THAT, and only then move it into place: a library that has not passed the lint (a hazard
+    # hit, or the lint itself failing: llvm-objdump missing) never sits at the path engine.py loads
+    tmp = LIB + ".tmp"
+    try:
+        r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+        if not os.environ.get("CN_ALLOW_PK_HAZARD"):   # (lab builds that reproduce the fault set it)
+            try:
+                from . import isa_lint
+            except ImportError:   # run as a script
+                import isa_lint
+            bad = isa_lint.lint_library(tmp)
+            if bad:
+                raise RuntimeError("isa_lint: the library contains packed-fp32 instructions of the form MI355X executes wrongly beside bf16 MFMAs "
+                                   f"(v_pk_*_f32 op_sel:[0,1..]): {bad[:4]} ... {len(bad)} in all")
+        if os.path.exists(SIDECAR):
+            os.remove(SIDECAR)       # (never a new library beside an old record)
+        os.replace(tmp, LIB)
+        with open(SIDECAR, "w") as f:
+            json.dump({"source_sha256": src_hash, "flags": FLAGS, "file_flags": FILE_FLAGS,
+                       "linted": not os.environ.get("CN_ALLOW_PK_HAZARD")}, f)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 

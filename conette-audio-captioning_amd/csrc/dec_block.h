@@ -43,12 +43,19 @@
 #pragma once
 #include "gemm2.h"
 
+#ifndef DB_ROWS
+#define DB_ROWS 4   // rows (= row waves) per block, 16-bit operands: many small blocks spread the K/V and weight streams over more CUs
+#endif
+#ifndef DB_ROWS_SP
+#define DB_ROWS_SP 4  // exact precision: the same (eight rows = two per row wave halve the weight re-streaming: solo search 5.3 -> 6.6 ms, mixed16 beside an encoder +0.3 %; profiles/r04_notes.md)
+#endif
 // operand traits of the block / FFN kernels: the element type of an MFMA fragment, a lane's four dims of one cached key,
 // how many passes the weight stream makes per matrix (sp16: lo, hi) and how many activation tiles there are (sp16: hi, lo)
 template <typename HT> struct DbOp {
   typedef HT frag_t;
   typedef cn_h4<HT> kv4_t;
   static constexpr int NPH = 1;
+  static constexpr int ROWS = DB_ROWS;
   static constexpr bool kExactLn = false;
   static __device__ __forceinline__ float kvf(const kv4_t& v, int i) { return (float)v[i]; }
 };
@@ -56,14 +63,11 @@ template <> struct DbOp<sp16_t> {
   typedef half_t frag_t;
   typedef u32x4 kv4_t;
   static constexpr int NPH = 2;
+  static constexpr int ROWS = DB_ROWS_SP;
   static constexpr bool kExactLn = true;
   static __device__ __forceinline__ float kvf(const kv4_t& v, int i) { return cn_sp16_value(v[i]); }
 };
 
-#ifndef DB_ROWS
-#define DB_ROWS 4   // rows (= row waves) per block: many small blocks spread the K/V and weight streams over more CUs
-#endif
-#define DB_THREADS (256 + 64 * DB_ROWS)  // 4 GEMM waves + DB_ROWS row waves
 
 // Wave-per-row attention: lane l owns dims 4l..4l+3 (head l >> 3); keys in batches of NB with all
 // loads of a batch in flight; fp32 online softmax.  kp(s) / vp(s): this lane's 4 bf16 of key / value s.
@@ -132,8 +136,19 @@ __device__ __forceinline__ void db_kv_attend(DbKV<NB, HT> (&buf)[DEPTH], const f
 }
 
 // attention output of row `wave` (lane's 4 dims) -> bf16 -> swizzled A tile row `wave`
-// (sp16: the hi halves go to the tile at sA, the lo halves to its twin DB_TILE_BYTES further)
-#define DB_TILE_BYTES ((DB_ROWS + 1) * 512)
+// (sp16: the hi halves go to the tile at sA, the lo halves to its twin DbL<HT>::TILE further)
+template <typename HT> struct DbL {   // LDS map (dynamic, bytes) of the block kernel for operand type HT
+  static constexpr int ROWS = DbOp<HT>::ROWS, NT = DbOp<HT>::NPH;
+  static constexpr int RPW = ROWS / 4;                  // rows per row wave (four row waves)
+  static_assert(ROWS % 4 == 0 && ROWS <= 12, "rows per block: a multiple of the four row waves, within one 16-row MFMA tile (+ the zero row)");
+  static constexpr int THREADS = 512;                  // 4 GEMM waves + 4 row waves
+  static constexpr int TILE = (ROWS + 1) * 512;        // one activation tile: ROWS rows + one zero row, 512 B each
+  static constexpr int OFF_A = 0;                      // activation tile(s) (NT = 2 in sp16: hi, lo)
+  static constexpr int OFF_X = OFF_A + NT * TILE;      // fp32 residual rows
+  static constexpr int OFF_V = OFF_X + ROWS * 1024;    // q | k | v rows (fp32); later: pre-LN rows (Y) and cross q (Q)
+  static constexpr int OFF_P = OFF_V + 3 * ROWS * 1024;  // parameters: bin 768 | bo | bq | bo2 | g1 | b1 | g2 | b2
+  static constexpr int BYTES = OFF_P + 2560 * 4;
+};
 template <typename HT>
 __device__ __forceinline__ void db_store_row(char* sA, int wave, int lane, const f32x4& o, float inv) {
   typedef G2Geom<256> G;
@@ -141,7 +156,7 @@ __device__ __forceinline__ void db_store_row(char* sA, int wave, int lane, const
   if constexpr (DbOp<HT>::NPH == 2) {
     const unsigned b0 = cn_sp16_bits(o[0] * inv), b1 = cn_sp16_bits(o[1] * inv), b2 = cn_sp16_bits(o[2] * inv), b3 = cn_sp16_bits(o[3] * inv);
     *(uint2*)p = uint2{__builtin_amdgcn_perm(b1, b0, 0x05040100u), __builtin_amdgcn_perm(b3, b2, 0x05040100u)};
-    *(uint2*)(p + DB_TILE_BYTES) = uint2{__builtin_amdgcn_perm(b1, b0, 0x07060302u), __builtin_amdgcn_perm(b3, b2, 0x07060302u)};
+    *(uint2*)(p + DbL<HT>::TILE) = uint2{__builtin_amdgcn_perm(b1, b0, 0x07060302u), __builtin_amdgcn_perm(b3, b2, 0x07060302u)};
   } else {
     cn_store4((HT*)p, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
   }
@@ -168,13 +183,7 @@ struct DbWeights {
   const float* params;   // CnLayerW::blk_p: bin 768 | bo | bq | bo2 | g1 | b1 | g2 | b2
 };
 
-// LDS map (dynamic, bytes)
-#define DB_OFF_A 0                               // activation tile(s): DB_ROWS rows + one zero row, 512 B each (NT = 2 in sp16: hi, lo)
-#define DB_OFF_X(NT) (DB_OFF_A + (NT) * DB_TILE_BYTES)  // fp32 residual rows
-#define DB_OFF_V(NT) (DB_OFF_X(NT) + DB_ROWS * 1024)     // q | k | v rows (fp32); later: pre-LN rows (Y) and cross q (Q)
-#define DB_OFF_P(NT) (DB_OFF_V(NT) + 3 * DB_ROWS * 1024)  // parameters: bin 768 | bo | bq | bo2 | g1 | b1 | g2 | b2
-#define DB_LDS_BYTES_T(NT) (DB_OFF_P(NT) + 2560 * 4)
-#define DB_LDS_BYTES DB_LDS_BYTES_T(1)
+// offsets inside the parameter block (floats)
 #define DB_P_BO 768
 #define DB_P_BQ 1024
 #define DB_P_BO2 1280
@@ -221,21 +230,21 @@ __device__ __forceinline__ void db_gemm_regs(const DbStream& wlane, cn_h8<typena
   constexpr int NPH = DbOp<HT>::NPH, LASTP = 6 * NPH - 1;
   constexpr bool kHiPass = NPH == 2 && (P & 1) == 1;
   const int lr = lane & 15, lq = lane >> 4;
-  const int arow = lr < DB_ROWS ? lr : DB_ROWS;  // padding rows of the M tile all read the zero row
-  const int asw = lr < DB_ROWS ? (lr & G::SWM) : 0;
+  const int arow = lr < DbOp<HT>::ROWS ? lr : DbOp<HT>::ROWS;  // padding rows of the M tile all read the zero row
+  const int asw = lr < DbOp<HT>::ROWS ? (lr & G::SWM) : 0;
   if (!kHiPass) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   cn_h8<FT> fa = *(const cn_h8<FT>*)(sA + arow * G::RBY + ((lq ^ asw) * 16));
   cn_h8<FT> fl = fa;
-  if (kHiPass) fl = *(const cn_h8<FT>*)(sA + DB_TILE_BYTES + arow * G::RBY + ((lq ^ asw) * 16));
+  if (kHiPass) fl = *(const cn_h8<FT>*)(sA + DbL<HT>::TILE + arow * G::RBY + ((lq ^ asw) * 16));
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
     const cn_h8<FT> fc = fa, fcl = fl;
     if (ks < 7) {
       fa = *(const cn_h8<FT>*)(sA + arow * G::RBY + (((lq + 4 * (ks + 1)) ^ asw) * 16));
-      if (kHiPass) fl = *(const cn_h8<FT>*)(sA + DB_TILE_BYTES + arow * G::RBY + (((lq + 4 * (ks + 1)) ^ asw) * 16));
+      if (kHiPass) fl = *(const cn_h8<FT>*)(sA + DbL<HT>::TILE + arow * G::RBY + (((lq + 4 * (ks + 1)) ^ asw) * 16));
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -301,7 +310,7 @@ __device__ unsigned long long g_db_prof[16];
 #define DB_DEPTH_CROSS 2   // requested right after the self-attention; the rest roll while the first are consumed
 
 template <typename HT>
-__global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
+__global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
     DbPrologue pro, DbWeights wt,
     HT* __restrict__ kc, HT* __restrict__ vc,    // self K/V cache of this layer [step][R][256]
     const int* __restrict__ anc, int step, int R, int beam, int maxp,
@@ -315,15 +324,15 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
   typedef typename DbOp<HT>::frag_t FT;
   constexpr int NT = DbOp<HT>::NPH;  // activation tiles (sp16: hi and lo halves)
   constexpr bool kXL = DbOp<HT>::kExactLn;
-  char* sA = smem + DB_OFF_A;
-  float* sX = (float*)(smem + DB_OFF_X(NT));
-  float* sV = (float*)(smem + DB_OFF_V(NT));
+  char* sA = smem + DbL<HT>::OFF_A;
+  float* sX = (float*)(smem + DbL<HT>::OFF_X);
+  float* sV = (float*)(smem + DbL<HT>::OFF_V);
   float* sY = sV;                      // pre-LayerNorm rows (after q | k | v are dead)
-  float* sQ = sV + DB_ROWS * 256;      // scaled cross-attention queries
-  float* sP = (float*)(smem + DB_OFF_P(NT));
+  float* sQ = sV + DbOp<HT>::ROWS * 256;      // scaled cross-attention queries
+  float* sP = (float*)(smem + DbL<HT>::OFF_P);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r0 = blockIdx.x * DB_ROWS;
+  const int r0 = blockIdx.x * DbOp<HT>::ROWS;
 
   if (wave < 4) {
     // ======================= GEMM waves ========================================================
@@ -338,35 +347,35 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
     DB_SYNC();  // b1: x rows (sA) and parameters (sP) are in LDS
     {           // q | k | v
       db_gemm_mat<0, HT>(wlane, fw, sA, lane, acc);
-      if (lr < DB_ROWS)
+      if (lr < DbOp<HT>::ROWS)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int n = 64 * wave + 16 * a + 4 * lq;
           const f32x4 bb = *(const f32x4*)(sP + n);
-          *(f32x4*)(sV + (0 * DB_ROWS + lr) * 256 + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
+          *(f32x4*)(sV + (0 * DbOp<HT>::ROWS + lr) * 256 + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
         }
       db_gemm_mat<1, HT>(wlane, fw, sA, lane, acc);
-      if (lr < DB_ROWS)
+      if (lr < DbOp<HT>::ROWS)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int n = 64 * wave + 16 * a + 4 * lq;
           const f32x4 bb = *(const f32x4*)(sP + 256 + n);
-          *(f32x4*)(sV + (1 * DB_ROWS + lr) * 256 + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
+          *(f32x4*)(sV + (1 * DbOp<HT>::ROWS + lr) * 256 + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
         }
       db_gemm_mat<2, HT>(wlane, fw, sA, lane, acc);
-      if (lr < DB_ROWS)
+      if (lr < DbOp<HT>::ROWS)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int n = 64 * wave + 16 * a + 4 * lq;
           const f32x4 bb = *(const f32x4*)(sP + 512 + n);
-          *(f32x4*)(sV + (2 * DB_ROWS + lr) * 256 + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
+          *(f32x4*)(sV + (2 * DbOp<HT>::ROWS + lr) * 256 + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
         }
     }
     DB_SYNC();  // b2: q | k | v ready
     DB_SYNC();  // b3: self-attention output in sA
     {
       db_gemm_mat<3, HT>(wlane, fw, sA, lane, acc);
-      if (lr < DB_ROWS)
+      if (lr < DbOp<HT>::ROWS)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int n = 64 * wave + 16 * a + 4 * lq;
@@ -378,7 +387,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
     DB_SYNC();  // b5: x1 in sX / sA
     {
       db_gemm_mat<4, HT>(wlane, fw, sA, lane, acc);
-      if (lr < DB_ROWS)
+      if (lr < DbOp<HT>::ROWS)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int n = 64 * wave + 16 * a + 4 * lq;
@@ -390,7 +399,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
     DB_SYNC();  // b7: cross-attention output in sA
     {
       db_gemm_mat<5, HT>(wlane, fw, sA, lane, acc);
-      if (lr < DB_ROWS)
+      if (lr < DbOp<HT>::ROWS)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int n = 64 * wave + 16 * a + 4 * lq;
@@ -403,28 +412,38 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
   }
 
   // ========================= row waves ===========================================================
-  const int rw = wave - 4;                 // row of the block
-  const int tr = min(r0 + rw, R - 1);      // the row this wave works for (clamped: padding waves recompute the last row)
-  const bool live = r0 + rw < R;
+  // Four row waves; wave rw works for the rows rw + 4 h of the block, h < RPW (16-bit operands: RPW = 1, one row per wave;
+  // exact precision: RPW = 2, eight rows per block -- twelve waves would cap the kernel at 168 registers, the hi / lo GEMM
+  // waves need 212).  Row h = 0 is the one whose K/V batches are requested ahead of the phases that consume them.
+  constexpr int ROWS = DbOp<HT>::ROWS, RPW = DbL<HT>::RPW;
+  const int rw = wave - 4;
   const int rt = tid - 256;
   unsigned long long t_prev = dbg ? wall_clock64() : 0ull;
-  if (rt < 32 * NT) ((uint4*)(sA + (rt >> 5) * DB_TILE_BYTES + DB_ROWS * 512))[rt & 31] = uint4{0, 0, 0, 0};  // the zero row(s)
+  if (rt < 32 * NT) ((uint4*)(sA + (rt >> 5) * DbL<HT>::TILE + ROWS * 512))[rt & 31] = uint4{0, 0, 0, 0};  // the zero row(s)
   // parameters -> LDS, 10 pieces of 1 KB by LDS-DMA (landed before this wave's younger P0 loads, i.e. before b1)
 #pragma unroll
-  for (int c = 0; c < (10 + DB_ROWS - 1) / DB_ROWS; ++c) {
-    const int piece = rw + DB_ROWS * c;
+  for (int c = 0; c < 3; ++c) {
+    const int piece = rw + 4 * c;
     if (piece < 10)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wt.params + piece * 256 + lane * 4),
                                        (__attribute__((address_space(3))) void*)((char*)sP + piece * 1024), 16, 0, 0);
   }
-  // ---- P0: this wave's row of the residual stream -----------------------------------------------------
-  const int rb = (tr / beam) * beam;
-  const int* arow = anc + (size_t)tr * maxp;
-  const int my_anc = lane < step ? arow[lane] : 0;  // step <= 63 (CN_MAX_PRED 64)
-  {
+  int rr[RPW], tr[RPW], rb[RPW], my_anc[RPW];
+  bool live[RPW];
+#pragma unroll
+  for (int h = 0; h < RPW; ++h) {
+    rr[h] = rw + 4 * h;                    // row of the block
+    tr[h] = min(r0 + rr[h], R - 1);        // the row worked for (clamped: padding rows recompute the last row)
+    live[h] = r0 + rr[h] < R;
+    rb[h] = (tr[h] / beam) * beam;
+    my_anc[h] = lane < step ? anc[(size_t)tr[h] * maxp + lane] : 0;  // step <= 63 (CN_MAX_PRED 64)
+  }
+  // ---- P0: the rows of the residual stream --------------------------------------------------------------
+#pragma unroll
+  for (int h = 0; h < RPW; ++h) {
     f32x4 xr;
     if (pro.slabs == nullptr) {
-      const f32x4 e = *(const f32x4*)(pro.emb + (size_t)pro.tok[tr] * 256 + 4 * lane);
+      const f32x4 e = *(const f32x4*)(pro.emb + (size_t)pro.tok[tr[h]] * 256 + 4 * lane);
       const f32x4 pe = *(const f32x4*)(pro.pe_row + 4 * lane);
 #pragma unroll
       for (int i = 0; i < 4; ++i) xr[i] = e[i] * pro.emb_scale + pe[i];
@@ -433,9 +452,9 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
       const int ns = pro.nslab;
 #pragma unroll
       for (int sl = 0; sl < 8; ++sl)
-        u[sl] = sl < ns ? *(const f32x4*)(pro.slabs + sl * pro.slab_stride + (size_t)tr * 256 + 4 * lane)
+        u[sl] = sl < ns ? *(const f32x4*)(pro.slabs + sl * pro.slab_stride + (size_t)tr[h] * 256 + 4 * lane)
                         : f32x4{0.f, 0.f, 0.f, 0.f};
-      const f32x4 rs = *(const f32x4*)(x + (size_t)tr * 256 + 4 * lane);
+      const f32x4 rs = *(const f32x4*)(x + (size_t)tr[h] * 256 + 4 * lane);
       const f32x4 bb = *(const f32x4*)(pro.b2_prev + 4 * lane);
       f32x4 v = u[0];
 #pragma unroll
@@ -446,14 +465,14 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
       for (int i = 0; i < 4; ++i) v[i] += bb[i] + rs[i];
       xr = db_row_ln<kXL>(v, pro.g3, pro.b3, lane);
     }
-    *(f32x4*)(sX + rw * 256 + 4 * lane) = xr;
-    db_store_row<HT>(sA, rw, lane, xr, 1.0f);
+    *(f32x4*)(sX + rr[h] * 256 + 4 * lane) = xr;
+    db_store_row<HT>(sA, rr[h], lane, xr, 1.0f);
   }
-  // self-attention K/V of the ancestors: requested now, consumed after the q | k | v GEMMs
-  auto skp = [&](int s) { return kc + ((size_t)s * R + rb + __builtin_amdgcn_readlane(my_anc, s)) * 256 + 4 * lane; };
-  auto svp = [&](int s) { return vc + ((size_t)s * R + rb + __builtin_amdgcn_readlane(my_anc, s)) * 256 + 4 * lane; };
+  // self-attention K/V of the ancestors (row h = 0): requested now, consumed after the q | k | v GEMMs
+  auto skp = [&](int h) { return [&, h](int s) { return kc + ((size_t)s * R + rb[h] + __builtin_amdgcn_readlane(my_anc[h], s)) * 256 + 4 * lane; }; };
+  auto svp = [&](int h) { return [&, h](int s) { return vc + ((size_t)s * R + rb[h] + __builtin_amdgcn_readlane(my_anc[h], s)) * 256 + 4 * lane; }; };
   DbKV<DB_NB_SELF, HT> skv[DB_DEPTH_SELF];
-  db_kv_prefetch(skv, step, skp, svp);
+  db_kv_prefetch(skv, step, skp(0), svp(0));
   DB_STAMP(0)
   DB_SYNC();  // b1
   DB_SYNC();  // b2: q | k | v ready
@@ -461,32 +480,39 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
 
   // ---- P1: self-attention ----------------------------------------------------------------------------
   DbKV<DB_NB_CROSS, HT> xkv[DB_DEPTH_CROSS];
-  const int clip = tr / beam;
-  int n_fr = lens[clip];
-  n_fr = n_fr < 1 ? 1 : (n_fr > Ta ? Ta : n_fr);
-  const HT* xbase = kvx + (size_t)clip * Ta * kv_ld + kv_off + 4 * lane;
-  auto xkp = [&](int t) { return xbase + (size_t)t * kv_ld; };
-  auto xvp = [&](int t) { return xbase + (size_t)t * kv_ld + 256; };
-  {
-    f32x4 q = *(const f32x4*)(sV + (0 * DB_ROWS + rw) * 256 + 4 * lane);
-    f32x4 kn = *(const f32x4*)(sV + (1 * DB_ROWS + rw) * 256 + 4 * lane);
-    f32x4 vn = *(const f32x4*)(sV + (2 * DB_ROWS + rw) * 256 + 4 * lane);
+  int n_fr[RPW];
+  const HT* xbase[RPW];
+#pragma unroll
+  for (int h = 0; h < RPW; ++h) {
+    const int clip = tr[h] / beam;
+    const int n = lens[clip];
+    n_fr[h] = n < 1 ? 1 : (n > Ta ? Ta : n);
+    xbase[h] = kvx + (size_t)clip * Ta * kv_ld + kv_off + 4 * lane;
+  }
+  auto xkp = [&](int h) { return [&, h](int t) { return xbase[h] + (size_t)t * kv_ld; }; };
+  auto xvp = [&](int h) { return [&, h](int t) { return xbase[h] + (size_t)t * kv_ld + 256; }; };
+#pragma unroll
+  for (int h = 0; h < RPW; ++h) {
+    f32x4 q = *(const f32x4*)(sV + (0 * ROWS + rr[h]) * 256 + 4 * lane);
+    f32x4 kn = *(const f32x4*)(sV + (1 * ROWS + rr[h]) * 256 + 4 * lane);
+    f32x4 vn = *(const f32x4*)(sV + (2 * ROWS + rr[h]) * 256 + 4 * lane);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       q[i] *= scale;
       kn[i] = cn_to_f32(cn_from_f32<HT>(kn[i]));  // cache precision
       vn[i] = cn_to_f32(cn_from_f32<HT>(vn[i]));
     }
-    if (live) {
-      cn_store4(kc + ((size_t)step * R + tr) * 256 + 4 * lane, kn[0], kn[1], kn[2], kn[3]);
-      cn_store4(vc + ((size_t)step * R + tr) * 256 + 4 * lane, vn[0], vn[1], vn[2], vn[3]);
+    if (live[h]) {
+      cn_store4(kc + ((size_t)step * R + tr[h]) * 256 + 4 * lane, kn[0], kn[1], kn[2], kn[3]);
+      cn_store4(vc + ((size_t)step * R + tr[h]) * 256 + 4 * lane, vn[0], vn[1], vn[2], vn[3]);
     }
     float m = -INFINITY, l = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    const unsigned long long valid = kvalid ? kvalid[tr] : ~0ull;
-    db_kv_attend(skv, q, step, skp, svp, m, l, o, valid);
-    // the audio K/V of the clip: first batches requested here, consumed after out-proj, LN1 and the query GEMM
-    db_kv_prefetch(xkv, n_fr, xkp, xvp);
+    const unsigned long long valid = kvalid ? kvalid[tr[h]] : ~0ull;
+    if (h > 0) db_kv_prefetch(skv, step, skp(h), svp(h));
+    db_kv_attend(skv, q, step, skp(h), svp(h), m, l, o, valid);
+    // the audio K/V of the clip (row h = 0): first batches requested here, consumed after out-proj, LN1 and the query GEMM
+    if (h == RPW - 1) db_kv_prefetch(xkv, n_fr[0], xkp(0), xvp(0));
     if ((valid >> step) & 1) {  // own key / value
       float d = q[0] * kn[0] + q[1] * kn[1] + q[2] * kn[2] + q[3] * kn[3];
       d = cn_sum8_dpp(d);
@@ -496,7 +522,7 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = o[i] * corr + p * vn[i];
     }
-    db_store_row<HT>(sA, rw, lane, o, 1.0f / l);
+    db_store_row<HT>(sA, rr[h], lane, o, 1.0f / l);
   }
   DB_STAMP(2)
   DB_SYNC();  // b3
@@ -504,11 +530,12 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
   DB_STAMP(3)
 
   // ---- LN1 --------------------------------------------------------------------------------------------
-  {
-    const f32x4 y = *(const f32x4*)(sY + rw * 256 + 4 * lane);
+#pragma unroll
+  for (int h = 0; h < RPW; ++h) {
+    const f32x4 y = *(const f32x4*)(sY + rr[h] * 256 + 4 * lane);
     const f32x4 x1 = db_row_ln<kXL>(y, sP + DB_P_G1, sP + DB_P_B1, lane);
-    *(f32x4*)(sX + rw * 256 + 4 * lane) = x1;
-    db_store_row<HT>(sA, rw, lane, x1, 1.0f);
+    *(f32x4*)(sX + rr[h] * 256 + 4 * lane) = x1;
+    db_store_row<HT>(sA, rr[h], lane, x1, 1.0f);
   }
   DB_STAMP(4)
   DB_SYNC();  // b5
@@ -516,12 +543,14 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
   DB_STAMP(5)
 
   // ---- cross-attention over the clip's audio memory -----------------------------------------------------
-  {
-    const f32x4 q = *(const f32x4*)(sQ + rw * 256 + 4 * lane);
+#pragma unroll
+  for (int h = 0; h < RPW; ++h) {
+    const f32x4 q = *(const f32x4*)(sQ + rr[h] * 256 + 4 * lane);
     float m = -INFINITY, l = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    db_kv_attend(xkv, q, n_fr, xkp, xvp, m, l, o);
-    db_store_row<HT>(sA, rw, lane, o, 1.0f / l);
+    if (h > 0) db_kv_prefetch(xkv, n_fr[h], xkp(h), xvp(h));
+    db_kv_attend(xkv, q, n_fr[h], xkp(h), xvp(h), m, l, o);
+    db_store_row<HT>(sA, rr[h], lane, o, 1.0f / l);
   }
   DB_STAMP(6)
   DB_SYNC();  // b7
@@ -529,12 +558,13 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
   DB_STAMP(7)
 
   // ---- LN2 -> x, xt ---------------------------------------------------------------------------------------
-  {
-    const f32x4 y = *(const f32x4*)(sY + rw * 256 + 4 * lane);
+#pragma unroll
+  for (int h = 0; h < RPW; ++h) {
+    const f32x4 y = *(const f32x4*)(sY + rr[h] * 256 + 4 * lane);
     const f32x4 x2 = db_row_ln<kXL>(y, sP + DB_P_G2, sP + DB_P_B2, lane);
-    if (live) {
-      *(f32x4*)(x + (size_t)tr * 256 + 4 * lane) = x2;
-      cn_store4(xt + (size_t)tr * 256 + 4 * lane, x2[0], x2[1], x2[2], x2[3]);
+    if (live[h]) {
+      *(f32x4*)(x + (size_t)tr[h] * 256 + 4 * lane) = x2;
+      cn_store4(xt + (size_t)tr[h] * 256 + 4 * lane, x2[0], x2[1], x2[2], x2[3]);
     }
   }
   DB_STAMP(8)
@@ -542,5 +572,5 @@ __global__ __launch_bounds__(DB_THREADS, 1) void cn_dec_block_kernel(
 }
 
 template <typename HT> static inline int cn_dec_block_setup() {
-  return cn_configure_lds((const void*)cn_dec_block_kernel<HT>, DB_LDS_BYTES_T(DbOp<HT>::NPH));
+  return cn_configure_lds((const void*)cn_dec_block_kernel<HT>, DbL<HT>::BYTES);
 }

@@ -907,7 +907,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
           wt.stream = lw.blk_w;
           wt.params = lw.blk_p;
           CN_TRY(cn_dec_block_setup<T>());
-          hipLaunchKernelGGL(cn_dec_block_kernel<T>, dim3(cn_cdiv(R, DB_ROWS)), dim3(DB_THREADS), DB_LDS_BYTES_T(DbOp<T>::NPH), s, pro, wt, kc, vc,
+          hipLaunchKernelGGL(cn_dec_block_kernel<T>, dim3(cn_cdiv(R, DbOp<T>::ROWS)), dim3(DbL<T>::THREADS), DbL<T>::BYTES, s, pro, wt, kc, vc,
                              w.anc, step, R, beam, maxp, (const T*)kvc, kv_ld, l * 2 * d, frame_lens, Ta, w.x, xt,
                              scale, kvalid, db_debug, gate);
           CN_LAUNCH_CHECK();
@@ -1098,8 +1098,24 @@ struct DecGraph {
   DecKey key;
   hipGraphExec_t exec;
   hipGraph_t graph;
+  hipEvent_t last;  // recorded behind every launch of `exec`: what an eviction waits for (never the whole device)
   int seen;
 };
+// The cache (lookup, LRU order, capture, eviction) is shared by every host thread that decodes on this context -- the
+// pipelines run two or three decode streams, usually from one thread, but nothing in the ABI says so: one lock around it.
+static std::mutex g_dec_graph_mu;
+static void dec_graph_release(DecGraph& g) {
+  if (!g.exec) return;
+  // the graph may still be executing on another stream: wait for ITS last launch.  (Not hipDeviceSynchronize: that is illegal
+  // while any stream of the process is being captured -- e.g. another thread's first capture -- and would invalidate it.)
+  if (g.last) {
+    if (hipEventSynchronize(g.last) != hipSuccess) (void)hipGetLastError();
+    (void)hipEventDestroy(g.last);
+  }
+  (void)hipGraphExecDestroy(g.exec);
+  (void)hipGraphDestroy(g.graph);
+  g.exec = nullptr, g.graph = nullptr, g.last = nullptr;
+}
 #define CN_MAX_DEC_GRAPHS 64  // (bucket, pipeline slot) keys: conette_amd.engine sizes its buffer cache from the same number
 struct DecGraphCache {
   DecGraph g[CN_MAX_DEC_GRAPHS];
@@ -1119,30 +1135,25 @@ static DecGraphCache* graph_cache(conette_ctx* ctx, bool create) {
 void cn_decode_graphs_free(conette_ctx* ctx) {
   DecGraphCache* c = graph_cache(ctx, false);
   if (!c) return;
-  for (int i = 0; i < c->n; ++i)
-    if (c->g[i].exec) {
-      (void)hipGraphExecDestroy(c->g[i].exec);
-      (void)hipGraphDestroy(c->g[i].graph);
-    }
+  std::lock_guard<std::mutex> lock(g_dec_graph_mu);
+  for (int i = 0; i < c->n; ++i) dec_graph_release(c->g[i]);
   delete c;
   ctx->dec_graphs = nullptr;
 }
 extern "C" int conette_set_option(conette_ctx* ctx, int32_t option, int32_t value) {
   if (!ctx) return CN_ERR_ARG;
   if (option == CONETTE_OPT_DECODE_GRAPH) {
+    std::lock_guard<std::mutex> lock(g_dec_graph_mu);
     DecGraphCache* c = graph_cache(ctx, true);
     if (c) c->enabled = value ? 1 : 0;
     return CN_OK;
   }
   if (option == CONETTE_OPT_DECODE_FUSION) {
     ctx->dec_unfused = value ? 0 : 1;
+    std::lock_guard<std::mutex> lock(g_dec_graph_mu);
     DecGraphCache* c = graph_cache(ctx, false);
     if (c) {  // cached graphs hold the other launch sequence
-      for (int i = 0; i < c->n; ++i)
-        if (c->g[i].exec) {
-          (void)hipGraphExecDestroy(c->g[i].exec);
-          (void)hipGraphDestroy(c->g[i].graph);
-        }
+      for (int i = 0; i < c->n; ++i) dec_graph_release(c->g[i]);
       c->n = 0;
     }
     return CN_OK;
@@ -1198,6 +1209,7 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
                                  max_pred, best_preds, best_lprobs, mult_preds, mult_lprobs, out_sizes, step0_logits,
                                  trace_sel, trace_val, (char*)workspace, s));
   };
+  std::lock_guard<std::mutex> lock(g_dec_graph_mu);
   DecGraphCache* cache = graph_cache(ctx, true);
   const uint32_t dec_classes = (1u << CONETTE_PROF_DEC_PREPARE) | (1u << CONETTE_PROF_DEC_GEMM) |
                                (1u << CONETTE_PROF_DEC_ATTN) | (1u << CONETTE_PROF_DEC_MISC) |
@@ -1221,19 +1233,17 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
     }
   if (e && e->exec) {
     CN_HIP(hipGraphLaunch(e->exec, s));
+    CN_HIP(hipEventRecord(e->last, s));
     return CN_OK;
   }
   if (!e) {  // first sighting: run eagerly (also performs the one-time kernel attribute setup)
     if (cache->n == CN_MAX_DEC_GRAPHS) {
       // Evict the least recently used entry.  Its graph may still be executing on another stream (two or three decode
-      // streams replay graphs side by side), and destroying an executable graph under a running launch is undefined: the
-      // device is drained first.  This is the one place an entry point synchronises, and it is off the steady state (more
-      // than CN_MAX_DEC_GRAPHS distinct (shape, buffer) keys alive at once); conette_set_option(DECODE_GRAPH, 0) avoids it.
-      if (cache->g[0].exec) {
-        (void)hipDeviceSynchronize();
-        (void)hipGraphExecDestroy(cache->g[0].exec);
-        (void)hipGraphDestroy(cache->g[0].graph);
-      }
+      // streams replay graphs side by side), and destroying an executable graph under a running launch is undefined: its
+      // own last launch is waited for (an event per graph).  This is the one place an entry point blocks, and it is off the
+      // steady state (more than CN_MAX_DEC_GRAPHS distinct (shape, buffer) keys alive at once);
+      // conette_set_option(DECODE_GRAPH, 0) avoids it.
+      dec_graph_release(cache->g[0]);
       memmove(&cache->g[0], &cache->g[1], sizeof(DecGraph) * (CN_MAX_DEC_GRAPHS - 1));
       cache->n--;
     }
@@ -1267,14 +1277,24 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
     cache->enabled = 0;
     return run();
   }
+  hipEvent_t last = nullptr;
+  if (hipEventCreateWithFlags(&last, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    cache->enabled = 0;
+    return run();
+  }
   e->exec = exec;
   e->graph = graph;
+  e->last = last;
   {
     size_t n_nodes = 0;
     if (hipGraphGetNodes(graph, nullptr, &n_nodes) == hipSuccess) cache->last_nodes = (int)n_nodes;
     else (void)hipGetLastError();
   }
   CN_HIP(hipGraphLaunch(exec, s));
+  CN_HIP(hipEventRecord(last, s));
   return CN_OK;
 }
 

@@ -46,6 +46,34 @@ def gather_captions(preds: torch.Tensor, lprobs: torch.Tensor, n_total: int, pad
     return all_p[:n_total].to(dev), all_l[:n_total].to(dev)
 
 
+def gather_caption_windows(preds: torch.Tensor, lprobs: torch.Tensor, n_total: int, pad_id: int = 0,
+                           group: Optional[dist.ProcessGroup] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """ONE all-gather for a whole window of steps: per-shard (K, b_local, max_pred) ids and (K, b_local) scores of K
+    consecutive passes -> (K, n_total, max_pred), (K, n_total) in clip order on every rank.
+
+    The pipelined loop of bench.py calls this once per timed window instead of gather_captions once per step: a collective
+    is a rendezvous of all ranks, and one per step would serialise every rank's step-to-step jitter into every step."""
+    if not dist.is_available() or not dist.is_initialized():
+        return preds[:, :n_total], lprobs[:, :n_total]
+    world = dist.get_world_size(group)
+    per = (n_total + world - 1) // world
+    k, b, width = preds.shape
+    p = torch.full((k, per, width), pad_id, dtype=preds.dtype, device=preds.device)
+    l = torch.zeros((k, per), dtype=lprobs.dtype, device=lprobs.device)
+    p[:, :b] = preds
+    l[:, :b] = lprobs
+    dev = preds.device
+    if dist.get_backend(group) == "gloo" and dev.type != "cpu":  # (gloo moves host memory: the N > 1 self-test on one GPU)
+        p, l = p.cpu(), l.cpu()
+    all_p = torch.empty((world * k, per, width), dtype=preds.dtype, device=p.device)   # (rank-major concatenation)
+    all_l = torch.empty((world * k, per), dtype=lprobs.dtype, device=l.device)
+    dist.all_gather_into_tensor(all_p, p.contiguous(), group=group)
+    dist.all_gather_into_tensor(all_l, l.contiguous(), group=group)
+    all_p = all_p.view(world, k, per, width).permute(1, 0, 2, 3).reshape(k, world * per, width)
+    all_l = all_l.view(world, k, per).permute(1, 0, 2).reshape(k, world * per)
+    return all_p[:, :n_total].to(dev), all_l[:, :n_total].to(dev)
+
+
 def trim_captions(preds: torch.Tensor, eos_id: int = 2) -> torch.Tensor:
     """Cut trailing pad columns after gathering: longest (first EOS index) + 1 (beam.py:222-225)."""
     has = preds == eos_id

@@ -164,6 +164,22 @@ def make_partitioned_streams(device: torch.device, decode_share: int = 8, n_cus:
     return out[0], out[1]
 
 
+def make_masked_stream(device: torch.device, n_share: int, n_cus: int = 256, offset: int = 0):
+    """A stream whose kernels run on ``n_share`` of the ``n_cus`` compute units only (every (n_cus / n_share)-th CU-mask bit from
+    ``offset``): a decode chain confined this way never holds a compute unit one of the encoder's persistent kernels is
+    waiting for, while the encoder's own stream stays unrestricted."""
+    lib = load_library()
+    words = (n_cus + 31) // 32
+    mask = [0] * words
+    for j in range(n_share):
+        i = (offset + (j * n_cus) // n_share) % n_cus
+        mask[i // 32] |= 1 << (i % 32)
+    with torch.cuda.device(device):
+        h = C.c_void_p()
+        _check(lib.conette_stream_create_masked((C.c_uint32 * words)(*mask), words, C.byref(h)), "conette_stream_create_masked")
+        return torch.cuda.ExternalStream(h.value, device=device)
+
+
 class Engine:
     """Opaque context (packed weights) + caller-owned workspaces for one device."""
 
@@ -423,17 +439,32 @@ class Engine:
         """Kernel / copy nodes of the most recently captured decode hipGraph (0 before the first capture)."""
         return int(self.lib.conette_decode_graph_nodes(self._ctx_dec))
 
+    _DEC_CLASSES = ("dec_prepare", "dec_gemm", "dec_attn", "dec_misc", "search")
+
     def profile_enable(self, classes=()) -> None:
-        mask = 0
+        """Event pairs around the launches of these kernel classes.  In the two-context precisions (mixed, mixed16,
+        bf16+f16dec) the encoder classes go to the encoder context and the decoder classes to the decoder context (which also
+        makes its decode run eagerly instead of replaying a hipGraph, as in the one-context case)."""
+        mask_enc = mask_dec = 0
         for c in classes:
-            mask |= 1 << PROF_CLASSES.index(c)
-        _check(self.lib.conette_profile_enable(self._ctx, mask), "profile_enable")
+            bit = 1 << PROF_CLASSES.index(c)
+            if c in self._DEC_CLASSES:
+                mask_dec |= bit
+            else:
+                mask_enc |= bit
+        if self._ctx_dec is self._ctx:
+            _check(self.lib.conette_profile_enable(self._ctx, mask_enc | mask_dec), "profile_enable")
+        else:
+            _check(self.lib.conette_profile_enable(self._ctx, mask_enc), "profile_enable")
+            _check(self.lib.conette_profile_enable(self._ctx_dec, mask_dec), "profile_enable")
 
     def profile_read(self) -> Dict[str, Any]:
         n = len(PROF_CLASSES)
         ms = (C.c_float * n)()
         cnt = (C.c_int32 * n)()
-        _check(self.lib.conette_profile_read(self._ctx, ms, cnt), "profile_read")
+        _check(self.lib.conette_profile_read(self._ctx, ms, cnt), "profile_read")   # (accumulates into ms / cnt)
+        if self._ctx_dec is not self._ctx:
+            _check(self.lib.conette_profile_read(self._ctx_dec, ms, cnt), "profile_read")
         return {PROF_CLASSES[i]: (float(ms[i]), int(cnt[i])) for i in range(n) if cnt[i] > 0}
 
     # ---- a1 --------------------------------------------------------------------------------

@@ -69,3 +69,35 @@ def test_bucket_plan():
     assert padding_waste(lengths, buckets) < 0.15                     # one pad-to-max batch of these clips wastes ~50 %
     assert padding_waste(lengths, [list(range(200))]) > 0.4
     assert plan_buckets([5], 1.0) == [[0]] and plan_buckets([], 1.0) == []
+
+
+def test_bucket_plan_by_cost_is_optimal():
+    """plan_buckets_by_cost: a partition of the sorted clips, shortest first, whose modelled cost (padded audio seconds + a fixed cost
+    per bucket) equals the brute-force minimum over all contiguous partitions on small inputs, and beats the budget planner's."""
+    sys.path.insert(0, ROOT)
+    import itertools
+    import random
+
+    import conette_amd  # noqa: F401
+    from conette_amd.bucketing import plan_buckets, plan_buckets_by_cost
+
+    def cost(lengths, buckets, fixed):
+        return sum(len(b) * max(lengths[i] for i in b) / 32000.0 + fixed for b in buckets)
+
+    rng = random.Random(3)
+    for n in (1, 2, 5, 9):
+        lengths = [rng.randint(32000, 960000) for _ in range(n)]
+        for fixed in (0.0, 20.0, 150.0, 1e6):
+            got = plan_buckets_by_cost(lengths, fixed)
+            assert sorted(i for b in got for i in b) == list(range(n))
+            order = sorted(range(n), key=lambda i: (lengths[i], i))
+            best = min(cost(lengths, [order[a:b] for a, b in zip((0,) + cuts, cuts + (n,))], fixed)
+                       for k in range(n) for cuts in itertools.combinations(range(1, n), k))
+            assert abs(cost(lengths, got, fixed) - best) < 1e-6, (n, fixed)
+        assert len(plan_buckets_by_cost(lengths, 1e6)) == 1 and len(plan_buckets_by_cost(lengths, 0.0)) == len(set(lengths))
+    lengths = [rng.randint(32000, 960000) for _ in range(200)]
+    a, b = plan_buckets_by_cost(lengths, 150.0), plan_buckets(lengths, 960.0)
+    assert cost(lengths, a, 150.0) <= cost(lengths, b, 150.0)
+    firsts = [max(lengths[i] for i in bk) for bk in a]
+    assert firsts == sorted(firsts)
+    assert plan_buckets_by_cost([], 150.0) == []

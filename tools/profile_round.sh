@@ -17,7 +17,8 @@ timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_wr
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES --output-format csv -d $OUT/${TAG}_pmc_mfma_raw -o run -- $P > $OUT/${TAG}_pmc_mfma.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CU_CYCLES --output-format csv -d $OUT/${TAG}_pmc_lds_raw -o run -- $P > $OUT/${TAG}_pmc_lds.log 2>&1
 # which build the PMC tables describe: bench.py only quotes them for the library they were measured on
-python3 -c "import hashlib,json,sys; print(json.dumps({'library_sha256': hashlib.sha256(open('$ROOT/conette-audio-captioning_amd/libconette_hip.so','rb').read()).hexdigest()}))" > $OUT/${TAG}_pmc_meta.json
+# (the SOURCE hash build.py records beside the library -- csrc/ + header + flags -- not the binary's: a rebuild changes the latter)
+python3 -c "import hashlib,json,sys; d=json.load(open('$ROOT/conette-audio-captioning_amd/libconette_hip.build.json')); print(json.dumps({'source_sha256': d['source_sha256'], 'library_sha256': hashlib.sha256(open('$ROOT/conette-audio-captioning_amd/libconette_hip.so','rb').read()).hexdigest()}))" > $OUT/${TAG}_pmc_meta.json
 python3 $ROOT/tools/pmc_summary.py $OUT/${TAG}_pmc_hbm_traffic.csv $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write
 python3 $ROOT/tools/pmc_mfma_summary.py $OUT/${TAG}_pmc_mfma.csv $OUT/${TAG}_pmc_mfma_raw $OUT/${TAG}_pmc_lds_raw
 rm -rf $OUT/${TAG}_trace $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_mfma_raw $OUT/${TAG}_pmc_lds_raw
