@@ -117,12 +117,16 @@ __device__ unsigned long long g_dw_prof[8];
     t_prev = t_;                                                      \
   }
 
-// LDS tile geometry of cn_dwconv_ln_kernel: rows of PITCH words, PITCH % 4 == 0 (16-byte reads) and, where it costs at most
-// 1/4 more LDS, PITCH / 4 = PARTS (mod 16) so that the statistics pass is conflict free; otherwise the next odd chunk count.
+// LDS tile geometry of cn_dwconv_ln_kernel: rows of PITCH4 16-byte chunks, PITCH4 odd.  Round 4 (rocprof r03_h: 34 % / 23 % of
+// the LDS cycles of the C = 96 / 192 launches were bank conflicts, 2.7-3x on the statistics pass by the simulator of
+// profiles/r04_notes.md): the statistics pass now runs with lane = POSITION -- the PARTS threads of a position own CPT
+// consecutive chunks each, a wave's 16-byte reads go to 64 (or 2 x 32) different rows, and an odd pitch puts consecutive rows
+// on different bank quads: conflict free.  The store pass keeps its 8 consecutive channels per lane (one 16-byte store): a
+// layout that also frees it of its 2-way conflict (two half-row runs per lane, pitch = 12 mod 16) needs two 8-byte stores per
+// item and measured SLOWER (205 against 194 us at C = 96: the pass is store-issue bound, not LDS bound).
 template <int C, int S, int TH> struct DwTile {
-  static constexpr int CT = C > 384 ? 384 : C, NPOS = TH * 4 * S, PARTS = CT * S / NPOS, NCHUNK = C / 4;
-  static constexpr int want = NCHUNK + ((PARTS % 16) - (NCHUNK % 16) + 16) % 16;   // smallest >= NCHUNK, = PARTS (mod 16)
-  static constexpr int PITCH4 = (want * 4 <= NCHUNK * 5) ? want : (NCHUNK | 1);
+  static constexpr int NCHUNK = C / 4;
+  static constexpr int PITCH4 = NCHUNK | 1;
   static constexpr int PITCH = PITCH4 * 4;
 };
 
@@ -244,24 +248,24 @@ __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(c
   // LDS active for 59 % of the kernel at C = 192 with contiguous per-thread segments and 4-byte reads).
   constexpr int NPOS = NP * S, NT = CT * S, PARTS = NT / NPOS, NCHUNK = C / 4, CPT = NCHUNK / PARTS;
   static_assert(NT % NPOS == 0 && NCHUNK % PARTS == 0, "LayerNorm thread mapping");
-  float* s_ps = s_v + NPOS * PITCH;       // [NPOS][PARTS]
+  float* s_ps = s_v + NPOS * PITCH;       // [PARTS][NPOS]
   float* s_mean = s_ps + NPOS * PARTS;    // [NPOS]
   float* s_rstd = s_mean + NPOS;          // [NPOS]
   {
-    const int pos = tid / PARTS, part = tid % PARTS;
-    const float* row = s_v + pos * PITCH + part * 4;
+    const int pos = tid % NPOS, part = tid / NPOS;   // lane = position (see DwTile)
+    const float* row = s_v + pos * PITCH + part * (CPT * 4);
     f32x4 seg[CPT];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-      seg[i] = *(const f32x4*)(row + i * PARTS * 4);
+      seg[i] = *(const f32x4*)(row + i * 4);
       sum += (seg[i][0] + seg[i][1]) + (seg[i][2] + seg[i][3]);
     }
-    s_ps[pos * PARTS + part] = sum;
+    s_ps[part * NPOS + pos] = sum;
     __syncthreads();
     float mean = 0.f;
 #pragma unroll
-    for (int j = 0; j < PARTS; ++j) mean += s_ps[pos * PARTS + j];
+    for (int j = 0; j < PARTS; ++j) mean += s_ps[j * NPOS + pos];
     mean *= (1.0f / C);
     float sq = 0.f;
 #pragma unroll
@@ -272,12 +276,12 @@ __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(c
         sq = fmaf(d, d, sq);
       }
     __syncthreads();
-    s_ps[pos * PARTS + part] = sq;
+    s_ps[part * NPOS + pos] = sq;
     __syncthreads();
     if (part == 0) {
       float var = 0.f;
 #pragma unroll
-      for (int j = 0; j < PARTS; ++j) var += s_ps[pos * PARTS + j];
+      for (int j = 0; j < PARTS; ++j) var += s_ps[j * NPOS + pos];
       s_mean[pos] = mean;
       s_rstd[pos] = 1.0f / sqrtf(var * (1.0f / C) + 1e-6f);
     }

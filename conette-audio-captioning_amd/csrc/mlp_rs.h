@@ -370,8 +370,11 @@ __global__ __launch_bounds__(2 * NP * 64) void cn_mlp_rs_kernel(const HT* __rest
     };
     for (int it = 0; it < max_it; ++it) {
       const int tile = t_lo + pair + it * NP;
-      const int tnext = (tile + NP < t_hi && !(ABL & 4)) ? tile + NP : tile0;  // (no next tile: rows it never uses)
-      const HT* ynext = Y + (size_t)tnext * 32 * C + yoff;
+      // No next tile: the re-load stays an unconditional instruction stream (see b_mstep) but every lane reads ROW 0 of the
+      // pair's first tile -- one 768-byte row instead of a whole 24 KB tile.  (Round 3 re-read the first tile here: with two
+      // tiles per pair and launch that was + 50 % of the y and residual reads, the "1.39x FETCH_SIZE" of VERDICT r03.)
+      const bool has_next = tile + NP < t_hi && !(ABL & 4);
+      const HT* ynext = has_next ? Y + (size_t)(tile + NP) * 32 * C + yoff : Y + (size_t)tile0 * 32 * C + 8 * (lane >> 5);
       for (int j = 0; j < NCH - 2; j += 2) step2(std::false_type{}, ynext);
       step2(std::true_type{}, ynext);  // the tile's last two steps: the second re-loads y in place
     }
@@ -411,9 +414,10 @@ __global__ __launch_bounds__(2 * NP * 64) void cn_mlp_rs_kernel(const HT* __rest
       const int tile = t_lo + pair + it * NP;
       const bool valid = tile < t_hi;
       const int tcur = valid ? tile : tile0;
-      const int tnext = (valid && tile + NP < t_hi && !(ABL & 4)) ? tile + NP : tile0;
+      const bool has_next = valid && tile + NP < t_hi && !(ABL & 4);
       float* xrow = X + (size_t)tcur * 32 * C + xoff;
-      const float* xnext = X + (size_t)tnext * 32 * C + xoff;
+      // (no next tile: every lane re-loads row 0 of the pair's first tile -- 1.5 KB, not a 48 KB tile it never uses)
+      const float* xnext = has_next ? X + (size_t)(tile + NP) * 32 * C + xoff : X + (size_t)tile0 * 32 * C + 4 * (lane >> 5);
       const bool in_range = valid && tile * 32 + (lane & 31) < M && (!(ABL & 4) || it == max_it - 1);
       for (int cb = 0; cb < NCH - 1; ++cb, ++g) {
         head();

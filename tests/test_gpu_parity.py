@@ -21,9 +21,6 @@ from tests import golden_util as G
 
 pytestmark = pytest.mark.gpu
 
-# share of a scenario's top-k calls that test_topk_decisions_at_reference_states must verify (the rest are near-ties at
-# that precision: reference margin <= the tolerance)
-MIN_SAME = {"fp32": 1.0, "exact": 1.0, "bf16": 0.75, "f16": 0.9}
 # 16-bit operand precisions: every tolerance made of operand rounding scales with it (fp16: 11 significant bits against 8)
 R16 = {"bf16": 1.0, "f16": 0.125}
 # running log-prob sums of the search against the fp32 reference, per step: the logits of the 16-bit-operand ORACLE sit 0.21 (bf16) /
@@ -32,8 +29,23 @@ SUM_TOL = {"bf16": 0.12, "f16": 0.03}
 # precisions held to the fp32 tolerances and to bit-exact ids: the fp32-MFMA mode and the "exact" mode (fp16 hi/lo operand
 # pairs, three MFMAs per product: include/conette_hip.h CONETTE_PREC_F16X2)
 EXACT = ("fp32", "exact")
-# share of (clip, step) pairs of the greedy fixtures reached with the reference's arg-max chain intact (set from the measured rates)
-GREEDY_FLOOR = {"bf16": 0.0, "f16": 0.0}
+# measured on MI355X (round 4, profiles/r04_topk_rates.txt): per scenario and 16-bit precision [calls above the margin verified,
+# calls identical to the reference's (parents, tokens, order), calls].  The test holds a build to these minus a margin of
+# max(2, 8 % of the calls): last-bit changes of a kernel move a few near-ties, a regression that halves the agreement fails.
+TOPK_MEASURED = {
+    "b1_30s_beam3": {"bf16": [2, 18, 20], "f16": [16, 20, 20]},
+    "b2_1s_beam3": {"bf16": [7, 20, 24], "f16": [21, 23, 24]},
+    "b2_4s_beam8_content_words": {"bf16": [0, 11, 21], "f16": [7, 17, 21]},
+    "b3_mixed_beam2_tasks": {"bf16": [25, 56, 60], "f16": [53, 60, 60]},
+    "b3_mixed_beam3_none": {"bf16": [8, 52, 60], "f16": [50, 59, 60]},
+    "b4_10s_beam1_audiocaps": {"bf16": [59, 71, 71], "f16": [70, 71, 71]},
+    "b4_10s_beam3_clotho": {"bf16": [17, 72, 80], "f16": [68, 78, 80]},
+    "b4_odd_beam5_minpred0": {"bf16": [22, 90, 111], "f16": [79, 109, 111]},
+    "b8_10s_beam3_all": {"bf16": [25, 122, 146], "f16": [111, 144, 146]},
+}
+# share of (clip, step) pairs of the greedy fixtures reached with the reference's arg-max chain intact: measured 26 / 36 and 31 / 36
+# (bf16), 36 / 36 and 36 / 36 (f16) -- held to those rates minus a margin
+GREEDY_FLOOR = {"bf16": 0.6, "f16": 0.9}
 NCHW_TAPS = ["stem", "stage0_block0", "stage0", "down1", "stage1", "down2", "stage2", "down3", "stage3"]
 
 
@@ -239,14 +251,19 @@ def test_topk_decisions_at_reference_states(name, prec, engines, synth_weights, 
         n_checked += 1
     print(f"top-k at reference states {name}/{prec}: {n_checked} of {len(calls)} calls above the margin verified, "
           f"{n_same} of {len(calls)} calls identical (parents, tokens and their order)")
-    # fp32: every call.  bf16: every call whose margin exceeds 0.25 (asserted above; at least one per scenario), and the
-    # share of calls that are IDENTICAL to the reference whatever their margin (this synthetic checkpoint's top-3 picks are
-    # often within 0.1 of each other) must stay above MIN_SAME
-    # (exact precisions: all calls above the 5e-4 margin -- every call but the two near-ties of the beam-8 fixture -- and all
-    # calls, ties included, identical: MIN_SAME = 1)
-    assert n_checked >= (len(calls) - 2 if prec in EXACT else min(1, n_eligible)), (n_checked, len(calls))
-    # (beams wider than 4: the ORDER of 5-8 picks whose consecutive gaps are ~0.05 is part of "identical"; bf16 is held to half)
-    assert n_same >= (MIN_SAME[prec] if beam <= 4 or prec in EXACT else 0.5) * len(calls), (n_same, len(calls))
+    # exact precisions: every call above the 5e-4 margin (all but the two near-ties of the beam-8 fixture) verified, and ALL calls,
+    # ties included, identical to the reference's
+    if prec in EXACT:
+        assert n_checked >= len(calls) - 2 and n_same == len(calls), (n_checked, n_same, len(calls))
+    else:
+        # 16-bit operands: pinned to what this scenario measured (TOPK_MEASURED), not to a global floor ("floors, not
+        # pins": 0.75 x calls and `>= min(1, eligible)` let a build that halves the agreement pass)
+        m_checked, m_same, m_calls = TOPK_MEASURED[name][prec]
+        assert m_calls == len(calls)
+        slack = max(2, (8 * len(calls) + 99) // 100)
+        assert n_same >= m_same - slack, (n_same, m_same, len(calls))
+        assert n_checked >= m_checked - slack, (n_checked, m_checked, n_eligible)
+        assert n_checked >= 1 or m_checked <= slack, (n_checked, n_eligible)
 
 
 def test_one_pass_forcing_is_faster_than_stepwise(engines):
@@ -380,8 +397,6 @@ def test_greedy_search_matches_reference_fixture(name, prec, engines, synth_weig
                 if ga[b, i] != ra[b, i]:
                     break
         print(f"greedy {name}/{prec}: {n_cmp} of {ga.shape[0] * steps} clip-steps compared before a clip's first flipped arg-max")
-        # measured (round 4, both fixtures): bf16 compares >= 70 % of all clip-steps before a chain leaves the reference's, f16 >= 90 %;
-        # the floors below are those rates minus a margin -- a regression that halves the agreement fails here
         assert n_cmp >= GREEDY_FLOOR[prec] * ga.shape[0] * steps, (n_cmp, ga.shape[0] * steps)
 
 
