@@ -137,6 +137,10 @@ __device__ __forceinline__ void db_kv_attend(DbKV<NB, HT> (&buf)[DEPTH], const f
 
 // attention output of row `wave` (lane's 4 dims) -> bf16 -> swizzled A tile row `wave`
 // (sp16: the hi halves go to the tile at sA, the lo halves to its twin DbL<HT>::TILE further)
+// fp32 rows in LDS (residual, q | k | v, pre-LN, cross q): 256 values at a pitch of 260 -- the GEMM waves' epilogues write the
+// same 16-byte column of the block's rows from neighbouring lanes, and at a 1 KB pitch those all hit one bank quad (rocprof
+// r03_h / r04_a: 48 % of this kernel's LDS cycles were bank conflicts)
+#define DB_RP 260
 template <typename HT> struct DbL {   // LDS map (dynamic, bytes) of the block kernel for operand type HT
   static constexpr int ROWS = DbOp<HT>::ROWS, NT = DbOp<HT>::NPH;
   static constexpr int RPW = ROWS / 4;                  // rows per row wave (four row waves)
@@ -145,8 +149,8 @@ template <typename HT> struct DbL {   // LDS map (dynamic, bytes) of the block k
   static constexpr int TILE = (ROWS + 1) * 512;        // one activation tile: ROWS rows + one zero row, 512 B each
   static constexpr int OFF_A = 0;                      // activation tile(s) (NT = 2 in sp16: hi, lo)
   static constexpr int OFF_X = OFF_A + NT * TILE;      // fp32 residual rows
-  static constexpr int OFF_V = OFF_X + ROWS * 1024;    // q | k | v rows (fp32); later: pre-LN rows (Y) and cross q (Q)
-  static constexpr int OFF_P = OFF_V + 3 * ROWS * 1024;  // parameters: bin 768 | bo | bq | bo2 | g1 | b1 | g2 | b2
+  static constexpr int OFF_V = OFF_X + ROWS * DB_RP * 4;    // q | k | v rows (fp32); later: pre-LN rows (Y) and cross q (Q)
+  static constexpr int OFF_P = OFF_V + 3 * ROWS * DB_RP * 4;  // parameters: bin 768 | bo | bq | bo2 | g1 | b1 | g2 | b2
   static constexpr int BYTES = OFF_P + 2560 * 4;
 };
 template <typename HT>
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
   float* sX = (float*)(smem + DbL<HT>::OFF_X);
   float* sV = (float*)(smem + DbL<HT>::OFF_V);
   float* sY = sV;                      // pre-LayerNorm rows (after q | k | v are dead)
-  float* sQ = sV + DbOp<HT>::ROWS * 256;      // scaled cross-attention queries
+  float* sQ = sV + DbOp<HT>::ROWS * DB_RP;      // scaled cross-attention queries
   float* sP = (float*)(smem + DbL<HT>::OFF_P);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
         for (int a = 0; a < 4; ++a) {
           const int n = 64 * wave + 16 * a + 4 * lq;
           const f32x4 bb = *(const f32x4*)(sP + n);
-          *(f32x4*)(sV + (0 * DbOp<HT>::ROWS + lr) * 256 + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
+          *(f32x4*)(sV + (0 * DbOp<HT>::ROWS + lr) * DB_RP + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
         }
       db_gemm_mat<1, HT>(wlane, fw, sA, lane, acc);
       if (lr < DbOp<HT>::ROWS)
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
         for (int a = 0; a < 4; ++a) {
           const int n = 64 * wave + 16 * a + 4 * lq;
           const f32x4 bb = *(const f32x4*)(sP + 256 + n);
-          *(f32x4*)(sV + (1 * DbOp<HT>::ROWS + lr) * 256 + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
+          *(f32x4*)(sV + (1 * DbOp<HT>::ROWS + lr) * DB_RP + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
         }
       db_gemm_mat<2, HT>(wlane, fw, sA, lane, acc);
       if (lr < DbOp<HT>::ROWS)
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
         for (int a = 0; a < 4; ++a) {
           const int n = 64 * wave + 16 * a + 4 * lq;
           const f32x4 bb = *(const f32x4*)(sP + 512 + n);
-          *(f32x4*)(sV + (2 * DbOp<HT>::ROWS + lr) * 256 + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
+          *(f32x4*)(sV + (2 * DbOp<HT>::ROWS + lr) * DB_RP + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
         }
     }
     DB_SYNC();  // b2: q | k | v ready
@@ -379,8 +383,8 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int n = 64 * wave + 16 * a + 4 * lq;
-          const f32x4 bb = *(const f32x4*)(sP + DB_P_BO + n), rs = *(const f32x4*)(sX + lr * 256 + n);
-          *(f32x4*)(sY + lr * 256 + n) = f32x4{acc[a][0] + bb[0] + rs[0], acc[a][1] + bb[1] + rs[1], acc[a][2] + bb[2] + rs[2], acc[a][3] + bb[3] + rs[3]};
+          const f32x4 bb = *(const f32x4*)(sP + DB_P_BO + n), rs = *(const f32x4*)(sX + lr * DB_RP + n);
+          *(f32x4*)(sY + lr * DB_RP + n) = f32x4{acc[a][0] + bb[0] + rs[0], acc[a][1] + bb[1] + rs[1], acc[a][2] + bb[2] + rs[2], acc[a][3] + bb[3] + rs[3]};
         }
     }
     DB_SYNC();  // b4: pre-LN1 rows ready
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
         for (int a = 0; a < 4; ++a) {
           const int n = 64 * wave + 16 * a + 4 * lq;
           const f32x4 bb = *(const f32x4*)(sP + DB_P_BQ + n);
-          *(f32x4*)(sQ + lr * 256 + n) = f32x4{(acc[a][0] + bb[0]) * scale, (acc[a][1] + bb[1]) * scale, (acc[a][2] + bb[2]) * scale, (acc[a][3] + bb[3]) * scale};
+          *(f32x4*)(sQ + lr * DB_RP + n) = f32x4{(acc[a][0] + bb[0]) * scale, (acc[a][1] + bb[1]) * scale, (acc[a][2] + bb[2]) * scale, (acc[a][3] + bb[3]) * scale};
         }
     }
     DB_SYNC();  // b6: cross queries ready
@@ -403,8 +407,8 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int n = 64 * wave + 16 * a + 4 * lq;
-          const f32x4 bb = *(const f32x4*)(sP + DB_P_BO2 + n), rs = *(const f32x4*)(sX + lr * 256 + n);
-          *(f32x4*)(sY + lr * 256 + n) = f32x4{acc[a][0] + bb[0] + rs[0], acc[a][1] + bb[1] + rs[1], acc[a][2] + bb[2] + rs[2], acc[a][3] + bb[3] + rs[3]};
+          const f32x4 bb = *(const f32x4*)(sP + DB_P_BO2 + n), rs = *(const f32x4*)(sX + lr * DB_RP + n);
+          *(f32x4*)(sY + lr * DB_RP + n) = f32x4{acc[a][0] + bb[0] + rs[0], acc[a][1] + bb[1] + rs[1], acc[a][2] + bb[2] + rs[2], acc[a][3] + bb[3] + rs[3]};
         }
     }
     DB_SYNC();  // b8: pre-LN2 rows ready
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
       for (int i = 0; i < 4; ++i) v[i] += bb[i] + rs[i];
       xr = db_row_ln<kXL>(v, pro.g3, pro.b3, lane);
     }
-    *(f32x4*)(sX + rr[h] * 256 + 4 * lane) = xr;
+    *(f32x4*)(sX + rr[h] * DB_RP + 4 * lane) = xr;
     db_store_row<HT>(sA, rr[h], lane, xr, 1.0f);
   }
   // self-attention K/V of the ancestors (row h = 0): requested now, consumed after the q | k | v GEMMs
@@ -493,9 +497,9 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
   auto xvp = [&](int h) { return [&, h](int t) { return xbase[h] + (size_t)t * kv_ld + 256; }; };
 #pragma unroll
   for (int h = 0; h < RPW; ++h) {
-    f32x4 q = *(const f32x4*)(sV + (0 * ROWS + rr[h]) * 256 + 4 * lane);
-    f32x4 kn = *(const f32x4*)(sV + (1 * ROWS + rr[h]) * 256 + 4 * lane);
-    f32x4 vn = *(const f32x4*)(sV + (2 * ROWS + rr[h]) * 256 + 4 * lane);
+    f32x4 q = *(const f32x4*)(sV + (0 * ROWS + rr[h]) * DB_RP + 4 * lane);
+    f32x4 kn = *(const f32x4*)(sV + (1 * ROWS + rr[h]) * DB_RP + 4 * lane);
+    f32x4 vn = *(const f32x4*)(sV + (2 * ROWS + rr[h]) * DB_RP + 4 * lane);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       q[i] *= scale;
@@ -532,9 +536,9 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
   // ---- LN1 --------------------------------------------------------------------------------------------
 #pragma unroll
   for (int h = 0; h < RPW; ++h) {
-    const f32x4 y = *(const f32x4*)(sY + rr[h] * 256 + 4 * lane);
+    const f32x4 y = *(const f32x4*)(sY + rr[h] * DB_RP + 4 * lane);
     const f32x4 x1 = db_row_ln<kXL>(y, sP + DB_P_G1, sP + DB_P_B1, lane);
-    *(f32x4*)(sX + rr[h] * 256 + 4 * lane) = x1;
+    *(f32x4*)(sX + rr[h] * DB_RP + 4 * lane) = x1;
     db_store_row<HT>(sA, rr[h], lane, x1, 1.0f);
   }
   DB_STAMP(4)
@@ -545,7 +549,7 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
   // ---- cross-attention over the clip's audio memory -----------------------------------------------------
 #pragma unroll
   for (int h = 0; h < RPW; ++h) {
-    const f32x4 q = *(const f32x4*)(sQ + rr[h] * 256 + 4 * lane);
+    const f32x4 q = *(const f32x4*)(sQ + rr[h] * DB_RP + 4 * lane);
     float m = -INFINITY, l = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     if (h > 0) db_kv_prefetch(xkv, n_fr[h], xkp(h), xvp(h));
@@ -560,7 +564,7 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
   // ---- LN2 -> x, xt ---------------------------------------------------------------------------------------
 #pragma unroll
   for (int h = 0; h < RPW; ++h) {
-    const f32x4 y = *(const f32x4*)(sY + rr[h] * 256 + 4 * lane);
+    const f32x4 y = *(const f32x4*)(sY + rr[h] * DB_RP + 4 * lane);
     const f32x4 x2 = db_row_ln<kXL>(y, sP + DB_P_G2, sP + DB_P_B2, lane);
     if (live[h]) {
       *(f32x4*)(x + (size_t)tr[h] * 256 + 4 * lane) = x2;

@@ -119,9 +119,9 @@ __device__ unsigned long long g_dw_prof[8];
 
 // LDS tile geometry of cn_dwconv_ln_kernel: rows of PITCH4 16-byte chunks, PITCH4 odd.  Round 4 (rocprof r03_h: 34 % / 23 % of
 // the LDS cycles of the C = 96 / 192 launches were bank conflicts, 2.7-3x on the statistics pass by the simulator of
-// profiles/r04_notes.md): the statistics pass now runs with lane = POSITION -- the PARTS threads of a position own CPT
-// consecutive chunks each, a wave's 16-byte reads go to 64 (or 2 x 32) different rows, and an odd pitch puts consecutive rows
-// on different bank quads: conflict free.  The store pass keeps its 8 consecutive channels per lane (one 16-byte store): a
+// profiles/r04_notes.md): the statistics pass now runs with lane = POSITION -- the PARTS threads of a position sit in
+// different waves, a wave's 16-byte reads go to the same chunk of 64 (or 2 x 32) different rows, and an odd pitch puts
+// consecutive rows on different bank quads: conflict free, with every thread's sum in the order it always had.  The store pass keeps its 8 consecutive channels per lane (one 16-byte store): a
 // layout that also frees it of its 2-way conflict (two half-row runs per lane, pitch = 12 mod 16) needs two 8-byte stores per
 // item and measured SLOWER (205 against 194 us at C = 96: the pass is store-issue bound, not LDS bound).
 template <int C, int S, int TH> struct DwTile {
@@ -252,13 +252,15 @@ __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(c
   float* s_mean = s_ps + NPOS * PARTS;    // [NPOS]
   float* s_rstd = s_mean + NPOS;          // [NPOS]
   {
-    const int pos = tid % NPOS, part = tid / NPOS;   // lane = position (see DwTile)
-    const float* row = s_v + pos * PITCH + part * (CPT * 4);
+    // lane = position (see DwTile); a thread still sums the chunks part, part + PARTS, ... of its row in that order, so the
+    // statistics are bit for bit those of rounds 2-3 (only which lane reads which row changed)
+    const int pos = tid % NPOS, part = tid / NPOS;
+    const float* row = s_v + pos * PITCH + part * 4;
     f32x4 seg[CPT];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < CPT; ++i) {
-      seg[i] = *(const f32x4*)(row + i * 4);
+      seg[i] = *(const f32x4*)(row + i * PARTS * 4);
       sum += (seg[i][0] + seg[i][1]) + (seg[i][2] + seg[i][3]);
     }
     s_ps[part * NPOS + pos] = sum;
