@@ -38,6 +38,7 @@ DEPTHS = (3, 3, 9, 3)
 POS = (252 * 56, 126 * 28, 63 * 14, 31 * 7)  # positions per 10 s clip and stage
 PEAK_BF16_TFLOPS = 2500.0                    # dense MFMA bf16 (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0                        # HBM3E spec (MI355X_MICROARCH.md)
+DEC_GROUP_DEFAULT = 16                       # CN_DEC_GROUP: batches whose beam searches run as one chain (see step_grouped)
 FUSED_STAGES = (0, 1, 2)                     # pw1 + GELU + pw2 run as ONE kernel (mlp_rc2.h), timed under "pw1_gemm"
 # kernel-name fragments of each profiling class in the committed PMC tables (profiles/*_pmc_*.csv)
 PMC_KERNELS = {
@@ -523,12 +524,29 @@ def main() -> None:
     n_enc = int(os.environ.get("CN_ENC_STREAMS", "1"))   # 2: encodes of consecutive batches on alternating streams (the blocks
     # of one batch start on the CUs the previous batch has left; measured 3 % slower than one stream, kept as a knob)
     s_encs = [torch.cuda.Stream(dev, priority=int(os.environ.get("CN_ENC_PRIO", "0"))) for _ in range(max(1, min(n_enc, 2)))]
-    # CN_DEC_STREAMS decode chains in flight (default 2): a decode is a serial chain of ~300 latency-bound launches that
-    # stretches to the length of an encode when it shares the chip with one; with two chains (batches i-1 and i-2 decode
-    # while batch i encodes) a chain may take two steps, and the step is bounded by the encoder again.
-    # (the exact precision's decode is the one-launch-per-sub-layer path, 12 ms alone at B = 64: three chains in flight)
+    # Grouped decode (fixed workload): the beam search of G consecutive batches runs as ONE chain over G x B clips, launched when
+    # the G-th of them has been encoded.  A search is a latency chain whose kernels re-fetch every layer's weights once per
+    # XCD and step whatever the row count, and that traffic is what a decode costs the encoder running beside it
+    # (profiles/r04_notes.md section 3: ~0.1 ms per GB): one chain per G batches moves 1 / G of it per clip and launches 1 / G of
+    # the kernels.  Every step still encodes its own batch of B clips; a batch's captions leave the device up to G steps later.
+    # Captions do not depend on the grouping (row-local kernels; checked step by step against the solo pass like everything else).
+    # G = the largest divisor of --steps with G x B <= 256 clips (and <= CN_DEC_GROUP): a timed window ends on a group boundary, so
+    # every step's decode completes inside its window; beyond ~256 clips per chain the weights are amortised and a longer
+    # chain only adds latency (one box: B = 256: G 1 / 2 / 4 -> 11 030 / 10 868 / 10 805 clips/s; B = 16: G 1 / 4 / 8 / 16 -> 6 567 / 7 049 /
+    # 7 188 / 7 339).  (G x B x beam also stays under the 4 096 rows at which the GEMM tile shapes change.)
+    G = 1
+    if args.workload == "fixed":
+        g_max = max(1, min(int(os.environ.get("CN_DEC_GROUP", str(DEC_GROUP_DEFAULT))), 256 // max(1, B), 4095 // max(1, B * beam)))
+        G = max(g for g in range(1, g_max + 1) if args.steps % g == 0)
+    # CN_DEC_STREAMS decode chains in flight: a decode is a serial chain of ~300 latency-bound launches that stretches to the
+    # length of an encode when it shares the chip with one; ungrouped, two chains (batches i-1 and i-2 decode while batch i
+    # encodes; three in the precisions with the exact decoder) let a chain take two steps, and the step is bounded by the
+    # encoder again.  A chain over G >= 3 batches has G steps to finish: one stream; G = 2: two.  (Measured, one box, bf16 /
+    # mixed16 clips/s: G 1 x 2 streams 10 161-10 261 / 8 849, G 2 x 2 10 849 / 9 757, G 3 x 1 10 893 / 9 866, G 4 x 1 10 877 / 9 946,
+    # G 6 x 1 10 364 / 9 673; four and more chains: 2x slower.)
     # (mixed-length workload: every bucket of a step is a decode chain of its own -- three streams, dealt bucket by bucket)
-    n_dec = max(1, min(int(os.environ.get("CN_DEC_STREAMS", "3" if (args.precision in ("exact", "mixed", "mixed16") or args.workload == "mixed") else "2")), 3))  # (four and more chains: 2x slower, measured)
+    n_dec_default = 1 if G >= 3 else 2 if G == 2 else 3 if (args.precision in ("exact", "mixed", "mixed16") or args.workload == "mixed") else 2
+    n_dec = max(1, min(int(os.environ.get("CN_DEC_STREAMS", str(n_dec_default))), 3))
     dec_cus = int(os.environ.get("CN_DEC_CUS", "0"))   # > 0: the decode chains are confined to this many compute units (CU-masked streams)
     if dec_cus > 0:
         from conette_amd.engine import make_masked_stream
@@ -550,6 +568,43 @@ def main() -> None:
                 enc_done=torch.cuda.Event(), dec_done=torch.cuda.Event()))
     state = {"i": 0, "last": None}
     bos_dev = [bos_all[torch.zeros(w_.shape[0], dtype=torch.long)].to(dev) for w_, _, _ in batches]  # task "clotho"
+
+    if G > 1:
+        w_g, lens_g, t_g = batches[0]
+        gslots = []
+        for sl in range(n_slot):
+            fe_big = eng.decode_input_buffer(G * B, t_g, beam, max_pred, slot=100 + sl)
+            gslots.append(dict(fe=fe_big, clip=torch.empty((B, 527), dtype=torch.float32, device=dev),
+                               enc_done=[torch.cuda.Event() for _ in range(G)], dec_done=torch.cuda.Event()))
+        lens_big, bos_big = lens_g.repeat(G), bos_dev[0].repeat(G)
+
+    def step_grouped():
+        """one pass over this rank's B clips; every G-th call also launches the beam search of the last G batches"""
+        i = state["i"]
+        g, m = i // G, i % G
+        gs = gslots[g % n_slot]
+        s_enc = s_encs[i % len(s_encs)]
+        s_dec = s_decs[g % n_dec]
+        with torch.cuda.stream(s_enc):
+            if m == 0 and g >= n_slot:
+                s_enc.wait_event(gs["dec_done"])              # the group slot's frame buffer is free again
+            eng.encode(w_g, out=(gs["fe"][m * B:(m + 1) * B], gs["clip"]), slot=i & 1)
+            gs["enc_done"][m].record(s_enc)
+        if m == G - 1:
+            with torch.cuda.stream(s_dec):
+                for e_ in gs["enc_done"]:
+                    s_dec.wait_event(e_)
+                out = eng.decode(gs["fe"], lens_big, bos_big, forbid, beam, min_pred, max_pred, clone=False, slot=100 + (g % n_slot))
+                preds, lps = out["best_preds"], out["best_lprobs"]
+                state["last_local"] = (preds[(G - 1) * B:], lps[(G - 1) * B:])   # the captions of this step's own batch
+                if state.get("keep") is not None and i < state["keep"][0].shape[0]:
+                    kp, kl = state["keep"]                                      # steps g G .. g G + G - 1 of the keep tables
+                    kp[g * G:(g + 1) * G].copy_(preds.view(G, B, -1)[:, :, : kp.shape[2]], non_blocking=True)
+                    kl[g * G:(g + 1) * G].copy_(lps.view(G, B), non_blocking=True)
+                gs["dec_done"].record(s_dec)
+            state["last"] = out
+            state["last_stream"] = s_dec
+        state["i"] = i + 1
 
     def step():
         """one pass over this rank's clips: every (length-bucketed) batch once"""
@@ -604,6 +659,9 @@ def main() -> None:
             torch.cuda.synchronize(dev)
 
     warm_used = max(args.warmup, 3 * n_slot)  # >= 3 per slot: the third identical decode call replays its hipGraph
+    if G > 1:
+        warm_used = (max(args.warmup, 3 * n_slot * G) + G - 1) // G * G
+        step_single, step = step, step_grouped
     for _ in range(warm_used):
         step()
     fence()
@@ -772,6 +830,7 @@ def main() -> None:
                       "mixed16": "f16 encoder + f16x2 decoder", "bf16+f16dec": "bf16 encoder + f16 decoder"}[args.precision], "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": B, "global_batch": total_clips, "beam_size": beam,
                        "parallelism": f"dp{world}", "world_size_observed": world,
+                       "decode_group": G, "decode_streams": n_dec,
                        **({"share_gpu_selftest": True} if share else {})},
             "audio_seconds_per_sec": round(audio_seconds_all * args.steps / dt, 1),
             "decode_tokens_per_sec": round(world * best_tokens / (decode_ms * 1e-3), 1),   # solo decode (pre-pass)

@@ -26,6 +26,10 @@ if os.environ.get("CN_NO_SAT8"):   # A/B build: fp16 GELU outputs of the fused M
     FLAGS.append("-DCN_NO_SAT8")
 if os.environ.get("CN_DB_ROWS"):   # A/B build: rows per decoder block kernel (dec_block.h: 4)
     FLAGS.append("-DDB_ROWS=" + os.environ["CN_DB_ROWS"])
+if os.environ.get("CN_DB_ROWS_SP"):   # A/B build: rows per decoder block kernel in the exact precision (dec_block.h: 4)
+    FLAGS.append("-DDB_ROWS_SP=" + os.environ["CN_DB_ROWS_SP"])
+if os.environ.get("CN_DB_XCDS"):   # A/B build: XCDs whose workgroups work in the decoder block kernel (dec_block.h: 8 = all)
+    FLAGS.append("-DDB_XCDS=" + os.environ["CN_DB_XCDS"])
 if os.environ.get("CN_G2_NOACT"):
     FLAGS.append("-DCN_G2_NOACT")
 

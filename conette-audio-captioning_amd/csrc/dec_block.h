@@ -46,6 +46,9 @@
 #ifndef DB_ROWS
 #define DB_ROWS 4   // rows (= row waves) per block, 16-bit operands: many small blocks spread the K/V and weight streams over more CUs
 #endif
+#ifndef DB_XCDS
+#define DB_XCDS 8   // XCDs whose workgroups work in the block kernel (8 = all: the product)
+#endif
 #ifndef DB_ROWS_SP
 #define DB_ROWS_SP 4  // exact precision: the same (eight rows = two per row wave halve the weight re-streaming: solo search 5.3 -> 6.6 ms, mixed16 beside an encoder +0.3 %; profiles/r04_notes.md)
 #endif
@@ -336,7 +339,15 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
   float* sP = (float*)(smem + DbL<HT>::OFF_P);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r0 = blockIdx.x * DbOp<HT>::ROWS;
+  // DB_XCDS < 8 (A/B build knob): only the workgroups dealt to the first DB_XCDS XCDs work (the grid is 8 / DB_XCDS times
+  // larger, the others return at once), so that fewer L2s pull the layer's 768 KB weight stream
+  int bx = blockIdx.x;
+  if (DB_XCDS < 8) {
+    if ((bx & 7) >= DB_XCDS) return;
+    bx = (bx >> 3) * DB_XCDS + (bx & 7);
+    if (bx * DbOp<HT>::ROWS >= R) return;
+  }
+  const int r0 = bx * DbOp<HT>::ROWS;
 
   if (wave < 4) {
     // ======================= GEMM waves ========================================================

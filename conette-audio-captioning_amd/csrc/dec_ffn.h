@@ -43,7 +43,11 @@ __global__ __launch_bounds__(256, 1) void cn_dec_ffn_kernel(const HT* __restrict
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
-  const int r0 = blockIdx.x * DF_ROWS, chunk = blockIdx.y;
+  // blockIdx.x = hidden chunk (the fast index): workgroups are dealt round-robin over the 8 XCDs, so with 8 chunks every block
+  // of a chunk lands on the same XCD and the chunk's 256 KB of weights are pulled into ONE L2 instead of one per row tile
+  // (speed only: rocprof r04_m counted 12.8 MB fetched per launch for 2 MB of weights -- six row tiles of a chunk on six
+  // XCDs -- and the decode's fetch traffic is what it costs an encoder running beside it: profiles/r04_notes.md)
+  const int r0 = blockIdx.y * DF_ROWS, chunk = blockIdx.x;
 
   u32x4 xs[8];  // sp16: the x tile goes through registers (16 bytes = 4 elements per load), split into the hi / lo tiles below
   if constexpr (NPH == 2) {

@@ -907,7 +907,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
           wt.stream = lw.blk_w;
           wt.params = lw.blk_p;
           CN_TRY(cn_dec_block_setup<T>());
-          hipLaunchKernelGGL(cn_dec_block_kernel<T>, dim3(cn_cdiv(R, DbOp<T>::ROWS)), dim3(DbL<T>::THREADS), DbL<T>::BYTES, s, pro, wt, kc, vc,
+          hipLaunchKernelGGL(cn_dec_block_kernel<T>, dim3(DB_XCDS < 8 ? 8 * cn_cdiv(cn_cdiv(R, DbOp<T>::ROWS), DB_XCDS) : cn_cdiv(R, DbOp<T>::ROWS)), dim3(DbL<T>::THREADS), DbL<T>::BYTES, s, pro, wt, kc, vc,
                              w.anc, step, R, beam, maxp, (const T*)kvc, kv_ld, l * 2 * d, frame_lens, Ta, w.x, xt,
                              scale, kvalid, db_debug, gate);
           CN_LAUNCH_CHECK();
@@ -915,7 +915,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
         if (ffn_fused) {
           CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
           CN_TRY(cn_dec_ffn_setup<T>());
-          hipLaunchKernelGGL(cn_dec_ffn_kernel<T>, dim3(cn_cdiv(R, DF_ROWS), dff / 256), dim3(256), DF_LDS_BYTES_T(DbOp<T>::NPH), s, (const T*)xt, R,
+          hipLaunchKernelGGL(cn_dec_ffn_kernel<T>, dim3(dff / 256, cn_cdiv(R, DF_ROWS)), dim3(256), DF_LDS_BYTES_T(DbOp<T>::NPH), s, (const T*)xt, R,
                              lw.ffn_w, lw.ff1_b, w.slabs, slab, gate);
           CN_LAUNCH_CHECK();
         } else if constexpr (CnIsH16<T>::value) {

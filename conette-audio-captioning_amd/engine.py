@@ -165,14 +165,16 @@ def make_partitioned_streams(device: torch.device, decode_share: int = 8, n_cus:
 
 
 def make_masked_stream(device: torch.device, n_share: int, n_cus: int = 256, offset: int = 0):
-    """A stream whose kernels run on ``n_share`` of the ``n_cus`` compute units only (every (n_cus / n_share)-th CU-mask bit from
-    ``offset``): a decode chain confined this way never holds a compute unit one of the encoder's persistent kernels is
-    waiting for, while the encoder's own stream stays unrestricted."""
+    """A stream whose kernels run on ``n_share`` of the ``n_cus`` compute units only: mask bits ``offset .. offset + n_share - 1``.
+    On MI355X bit i of the mask is compute unit i // 8 of XCD i % 8 (measured: tools/lab/cumask_probe.hip), so a contiguous run
+    of bits takes the same n_share / 8 compute units on every XCD; an XCD whose bits are all clear is left UNRESTRICTED by the
+    driver (a mask of every 8th bit therefore restricts nothing).  A decode chain confined this way never holds a compute unit
+    one of the encoder's persistent kernels is waiting for, while the encoder's own stream stays unrestricted."""
     lib = load_library()
     words = (n_cus + 31) // 32
     mask = [0] * words
     for j in range(n_share):
-        i = (offset + (j * n_cus) // n_share) % n_cus
+        i = (offset + j) % n_cus
         mask[i // 32] |= 1 << (i % 32)
     with torch.cuda.device(device):
         h = C.c_void_p()

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Kernel trace of the encoder ALONE (nothing on other streams), per (kernel, grid size): tools/lab/enc_only_trace.sh [precision] [tag]
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out; mkdir -p $OUT
-PREC=${1:-bf16}; TAG=${2:-enc_only}
+PREC=${1:-bf16}; TAG=${2:-enc_only}; BATCH=${3:-64}
 cd /tmp && export TMPDIR=/tmp
-python3 $ROOT/tools/lab/enc_only.py 30 24 $PREC | tail -1
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_trace -o run -- python3 $ROOT/tools/lab/enc_only.py 20 24 $PREC > $OUT/${TAG}.log 2>&1
+python3 $ROOT/tools/lab/enc_only.py 30 24 $PREC $BATCH | tail -1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/${TAG}_trace -o run -- python3 $ROOT/tools/lab/enc_only.py 20 24 $PREC $BATCH > $OUT/${TAG}.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob('$OUT/${TAG}_trace/**/*kernel_trace.csv', recursive=True)[0]
