@@ -262,10 +262,15 @@ __global__ __launch_bounds__(WM * WN * 64) void cn_gemm2_kernel(const bf16_t* __
   constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN);
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int n_tiles = (N + BN - 1) / BN;
-  const int bid = cn_xcd_remap(blockIdx.x, gridDim.x);  // the n-tiles of one A panel share an XCD / L2
-  const int m0 = (bid / n_tiles) * BM;
-  const int n0 = (bid % n_tiles) * BN;
+  const int n_tiles = (N + BN - 1) / BN, m_tiles = (M + BM - 1) / BM;
+  const int bid = cn_xcd_remap(blockIdx.x, gridDim.x);  // every XCD gets a contiguous run of tiles
+  // ... ordered so that the LARGER operand is the one an XCD sees only a slice of: tall products (M >= N, the encoder's) walk the
+  // n-tiles of one A panel first -- an XCD's L2 holds a few A panels and all of W; wide ones (N > M: the decoder's classifier,
+  // 5 632 x 256 weights against a few hundred rows) walk the m-tiles of one W panel first, so each XCD pulls 1 / 8 of the
+  // weights instead of all of them (speed only: which workgroup computes a tile does not change the tile)
+  const bool wide = N > M;
+  const int m0 = (wide ? bid % m_tiles : bid / n_tiles) * BM;
+  const int n0 = (wide ? bid / m_tiles : bid % n_tiles) * BN;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
