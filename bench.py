@@ -671,21 +671,21 @@ def main() -> None:
     B0 = w0.shape[0]
     bos0 = bos_dev[0]
     enc_classes = ("frontend", "stem", "dwconv_ln", "pw1_gemm", "pw2_gemm", "downsample", "heads")
+    eng.profile_enable(enc_classes)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev[0].record()
+    eng.encode(w0, out=(slots[0]["fe"], slots[0]["clip"]))     # (straight behind the warm-up steps: the chip is at its working clock)
+    ev[1].record()
     if G > 1:   # (the grouped pipeline never ran the one-batch search: two calls so that the timed one below replays its graph)
         for _ in range(2):
             eng.decode(slots[0]["fe"], lens0, bos0, forbid, beam, min_pred, max_pred, clone=False, slot=0)
-        torch.cuda.synchronize(dev)
-    eng.profile_enable(enc_classes)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    ev[0].record()
-    eng.encode(w0, out=(slots[0]["fe"], slots[0]["clip"]))
-    ev[1].record()
-    out = eng.decode(slots[0]["fe"], lens0, bos0, forbid, beam, min_pred, max_pred, clone=False, slot=0)
     ev[2].record()
+    out = eng.decode(slots[0]["fe"], lens0, bos0, forbid, beam, min_pred, max_pred, clone=False, slot=0)
+    ev[3].record()
     torch.cuda.synchronize(dev)
     pre = eng.profile_read()
     eng.profile_enable(())
-    encode_ms, decode_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+    encode_ms, decode_ms = ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3])
     stage_ms = {k: round(v[0], 4) for k, v in pre.items()}
     dominant = max(("pw1_gemm", "pw2_gemm", "dwconv_ln"), key=lambda k: pre.get(k, (0.0, 0))[0])
     solo_preds, solo_lps = out["best_preds"].clone(), out["best_lprobs"].clone()  # un-pipelined result of batch 0

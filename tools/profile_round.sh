@@ -9,9 +9,9 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 400 python3 $ROOT/bench.py > $OUT/${TAG}_bench.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o run -- python3 $ROOT/bench.py --steps 10 --cpu-clips 0 --parity-clips 0 > $OUT/${TAG}_trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o run -- python3 $ROOT/bench.py --steps 12 --cpu-clips 0 --parity-clips 0 > $OUT/${TAG}_trace.log 2>&1
 cp $(find $OUT/${TAG}_trace -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_kernel_stats.csv
-P="python3 $ROOT/bench.py --steps 2 --warmup 1 --cpu-clips 0 --parity-clips 0"
+P="python3 $ROOT/bench.py --steps 4 --warmup 1 --cpu-clips 0 --parity-clips 0"   # (4 steps: the default decode group of 4 batches)
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pmc_fetch -o run -- $P > $OUT/${TAG}_pmc_fetch.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pmc_write -o run -- $P > $OUT/${TAG}_pmc_write.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES --output-format csv -d $OUT/${TAG}_pmc_mfma_raw -o run -- $P > $OUT/${TAG}_pmc_mfma.log 2>&1
