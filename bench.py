@@ -77,6 +77,14 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+def choose_decode_group(steps: int, batch: int, beam: int, cap: int = 16) -> int:
+    """Batches whose beam searches run as one chain (bench.py step_grouped): the largest divisor of ``steps`` -- a timed window must
+    end on a group boundary -- with G x batch <= 256 clips, G <= cap and G x batch x beam below the 4 096 rows at which the
+    GEMM tile shapes change."""
+    g_max = max(1, min(cap, 256 // max(1, batch), 4095 // max(1, batch * beam)))
+    return max(g for g in range(1, g_max + 1) if steps % g == 0)
+
+
 def launch_ranks(args) -> int:
     """Start `--gpus N` ranks (one process per GPU) as a child torch.distributed.run and return its exit status.
     Runs BEFORE this process imports torch.cuda or the HIP library: a process that has initialised the GPU must not
@@ -534,10 +542,7 @@ def main() -> None:
     # every step's decode completes inside its window; beyond ~256 clips per chain the weights are amortised and a longer
     # chain only adds latency (one box: B = 256: G 1 / 2 / 4 -> 11 030 / 10 868 / 10 805 clips/s; B = 16: G 1 / 4 / 8 / 16 -> 6 567 / 7 049 /
     # 7 188 / 7 339).  (G x B x beam also stays under the 4 096 rows at which the GEMM tile shapes change.)
-    G = 1
-    if args.workload == "fixed":
-        g_max = max(1, min(int(os.environ.get("CN_DEC_GROUP", str(DEC_GROUP_DEFAULT))), 256 // max(1, B), 4095 // max(1, B * beam)))
-        G = max(g for g in range(1, g_max + 1) if args.steps % g == 0)
+    G = choose_decode_group(args.steps, B, beam, int(os.environ.get("CN_DEC_GROUP", str(DEC_GROUP_DEFAULT)))) if args.workload == "fixed" else 1
     # CN_DEC_STREAMS decode chains in flight: a decode is a serial chain of ~300 latency-bound launches that stretches to the
     # length of an encode when it shares the chip with one; ungrouped, two chains (batches i-1 and i-2 decode while batch i
     # encodes; three in the precisions with the exact decoder) let a chain take two steps, and the step is bounded by the

@@ -101,3 +101,20 @@ def test_bucket_plan_by_cost_is_optimal():
     firsts = [max(lengths[i] for i in bk) for bk in a]
     assert firsts == sorted(firsts)
     assert plan_buckets_by_cost([], 150.0) == []
+
+
+def test_decode_group_choice():
+    """bench.py groups the beam searches of G consecutive batches into one chain: G divides --steps, G x B <= 256 clips."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    assert bench.choose_decode_group(20, 64, 3) == 4 and bench.choose_decode_group(100, 64, 3) == 4
+    assert bench.choose_decode_group(30, 64, 3) == 3 and bench.choose_decode_group(50, 64, 3) == 2 and bench.choose_decode_group(7, 64, 3) == 1
+    assert bench.choose_decode_group(20, 256, 3) == 1 and bench.choose_decode_group(20, 128, 3) == 2
+    assert bench.choose_decode_group(64, 16, 3) == 16 and bench.choose_decode_group(200, 16, 3) == 10
+    assert bench.choose_decode_group(20, 64, 3, cap=1) == 1 and bench.choose_decode_group(20, 64, 3, cap=2) == 2
+    assert bench.choose_decode_group(20, 64, 8) == 4 and bench.choose_decode_group(16, 32, 8) == 8
+    for steps in range(1, 40):
+        for b in (1, 11, 16, 64, 100, 256, 1000):
+            g = bench.choose_decode_group(steps, b, 3)
+            assert steps % g == 0 and (g == 1 or g * b <= 256) and g * b * 3 < 4096 or g == 1
