@@ -245,7 +245,8 @@ static inline int cn_rc2_grid(int n_tiles, int waves_per_block, int max_blocks) 
 }
 
 // ---- resident variant (C = 96): the whole stream (156 KB) lives in LDS; persistent blocks; no barrier, no DMA after the fill
-template <int C, int NW, int NCK, typename HT = bf16_t>
+// ABL (kernel lab only, wrong results): 1 = accumulators start from zero (no residual loads), 2 = nothing stored, 8 = y loaded once
+template <int C, int NW, int NCK, typename HT = bf16_t, int ABL = 0>
 __global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_resident_kernel(const HT* __restrict__ Y, const HT* __restrict__ WS,
                                                                       float* __restrict__ X, int M) {
   typedef Rc2Geom<C, NCK> G;
@@ -272,21 +273,31 @@ __global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_resident_kernel(const HT* 
   const char* wl = smem + lane * 16;
   for (; tile < t_hi; tile += NW) {
     f32x16 O[G::NT2];
-    W::init_o(X, tile * 32, lane, O);
+    if constexpr (ABL & 1) {
+#pragma unroll
+      for (int t = 0; t < G::NT2; ++t) O[t] = W::zero16();
+    } else {
+      W::init_o(X, tile * 32, lane, O);
+    }
 #pragma unroll 1
     for (int j = 0; j < G::NSTEP; ++j) W::step(wl + j * G::STEP_BYTES, fy, ones, O);
-    if (tile + NW < t_hi) W::load_y(Y, (tile + NW) * 32, lane, fy);
-    W::store_o(X, aux, tile * 32, M, lane, O);
+    if constexpr (!(ABL & 8))
+      if (tile + NW < t_hi) W::load_y(Y, (tile + NW) * 32, lane, fy);
+    if constexpr (ABL & 2) {
+      if (O[0][0] == 12345.678f) W::store_o(X, aux, tile * 32, M, lane, O);
+    } else {
+      W::store_o(X, aux, tile * 32, M, lane, O);
+    }
   }
 }
 
-template <int C, int NW, int NCK, typename HT>
+template <int C, int NW, int NCK, int ABL = 0, typename HT>
 static int cn_launch_mlp_rc2_resident(const HT* Y, const HT* WS, float* X, int M, int n_blocks, hipStream_t s) {
   constexpr int SMEM = (int)Rc2Geom<C, NCK>::STREAM_BYTES;
   static_assert(SMEM <= 160 * 1024, "resident variant: the weight stream must fit in LDS");
-  CN_TRY(cn_configure_lds((const void*)cn_mlp_rc2_resident_kernel<C, NW, NCK, HT>, SMEM));
+  CN_TRY(cn_configure_lds((const void*)cn_mlp_rc2_resident_kernel<C, NW, NCK, HT, ABL>, SMEM));
   const int grid = cn_rc2_grid((M + 31) / 32, NW, n_blocks);
-  hipLaunchKernelGGL((cn_mlp_rc2_resident_kernel<C, NW, NCK, HT>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, Y, WS, X, M);
+  hipLaunchKernelGGL((cn_mlp_rc2_resident_kernel<C, NW, NCK, HT, ABL>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, Y, WS, X, M);
   CN_LAUNCH_CHECK();
   return CN_OK;
 }
