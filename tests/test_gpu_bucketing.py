@@ -10,8 +10,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("planner", ["budget", "cost"])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
-def test_bucketed_captions_equal_reference_per_bucket(prec, tmp_path, synth_weights, synth_cfg):
+def test_bucketed_captions_equal_reference_per_bucket(prec, planner, tmp_path, synth_weights, synth_cfg):
     from conette_amd import CoNeTTEModel, synth
     from conette_amd.bucketing import caption_bucketed, padding_waste
     from oracle import cpu_ref as O
@@ -22,7 +23,9 @@ def test_bucketed_captions_equal_reference_per_bucket(prec, tmp_path, synth_weig
     lengths = [int(s * 32000) for s in secs]
     wav = synth.synth_waveforms(len(secs), max(lengths), 9090, lengths=lengths)
     clips = [torch.from_numpy(wav[i, :n].copy())[None] for i, n in enumerate(lengths)]
-    out = caption_bucketed(m, clips, sr=32000, task="clotho", max_padded_seconds=42.0)
+    # (planner "cost": plan_buckets_by_cost with a fixed cost of 8 audio seconds per bucket -- another partition, same contract)
+    kw = dict(max_padded_seconds=42.0) if planner == "budget" else dict(fixed_cost_seconds=8.0)
+    out = caption_bucketed(m, clips, sr=32000, task="clotho", **kw)
     buckets = out["buckets"]
     assert sorted(i for b in buckets for i in b) == list(range(len(secs))) and len(buckets) >= 3
     assert padding_waste(lengths, buckets) < padding_waste(lengths, [list(range(len(secs)))])
