@@ -875,6 +875,12 @@ def main() -> None:
                 "algorithmic_bytes_per_search": dby, "search_steps": n_steps, "graph_nodes_per_search": eng.decode_graph_nodes(),
                 "launches_per_step": round(eng.decode_graph_nodes() / max_pred, 1),
                 "traffic": None}
+            if G > 1:   # the chain the pipeline runs: G batches per search (weights touched once per search, not once per batch)
+                dbg = decode_algorithmic_bytes(G * B0, beam, t0_, n_steps, eng.vocab_size)
+                result["roofline_decode"]["grouped"] = {
+                    "batches_per_search": G, "algorithmic_bytes_per_search": dbg, "search_ms": round(decode_ms_grouped, 3),
+                    "achieved": round(dbg / (decode_ms_grouped * 1e-3) / 1e9, 1), "unit": "GB/s",
+                    "frac": round(dbg / (decode_ms_grouped * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
 
     # ---- CPU baseline (rank 0, N = 1 only): the oracle restatement on host cores; its outputs are KEPT as the checker ----
     ora = None
