@@ -71,9 +71,10 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: CPU self-test of the launcher / sharding / gather path (no GPU work, no timing)")
     ap.add_argument("--master-port", type=int, default=0)
-    ap.add_argument("--also", default="bf16+f16dec,f16,mixed16,exact",
+    ap.add_argument("--also", default="bf16:g1,bf16+f16dec,f16,mixed16,exact",
                     help="N = 1, fixed workload, bf16 only: after the run, the SAME pipelined benchmark at these precisions (one child "
-                         "process each, 3 windows, no CPU / parity legs), reported under `also_pipelined` ('' = skip)")
+                         "process each, 3 windows, no CPU / parity legs), reported under `also_pipelined` ('' = skip); `PREC:g1` = that "
+                         "precision with one beam search per batch (CN_DEC_GROUP=1) instead of the grouped decode")
     return ap.parse_args(argv)
 
 
@@ -318,12 +319,17 @@ def also_pipelined(args, batch):
     import subprocess
     out = {}
     for name in [n for n in args.also.split(",") if n]:
-        cmd = [sys.executable, os.path.abspath(__file__), "--precision", name, "--steps", str(args.steps), "--warmup", str(args.warmup),
+        prec, _, opt = name.partition(":")     # "bf16:g1" = the bf16 pipeline with ONE beam search per batch (round 3's schedule)
+        env = dict(os.environ)
+        if opt == "g1":
+            env["CN_DEC_GROUP"] = "1"
+        cmd = [sys.executable, os.path.abspath(__file__), "--precision", prec, "--steps", str(args.steps), "--warmup", str(args.warmup),
                "--repeat", "3", "--batch", str(batch), "--beam", str(args.beam), "--cpu-clips", "0", "--parity-clips", "0", "--also", ""]
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
             d = json.loads(r.stdout.strip().splitlines()[-1])
             out[name] = {"clips_per_sec": d["value"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
+                         "decode_group": d["config"].get("decode_group"), "decode_streams": d["config"].get("decode_streams"),
                          "windows_clips_per_sec": d["windows"]["clips_per_sec"], "pipeline_consistent": d["pipeline_consistent"]}
         except Exception as e:  # a failed child does not void the line: it is reported as such
             out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
