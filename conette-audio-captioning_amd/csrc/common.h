@@ -232,6 +232,44 @@ __device__ __forceinline__ f32x4 cn_gelu_fast4(f32x4 x) {
   return f32x4{a[0], a[1], b[0], b[1]};
 }
 
+// GELU with ONE transcendental (round 5).  With a = |x|:   gelu(x) = x Phi(x) = max(x, 0) - a Phi(-a)   (both signs), and
+// log2 Phi(-a) is smooth, concave and polynomial-like on a >= 0 (-1 at 0, ~ -a^2 / 2 log2 e beyond): Phi(-a) = 2^P(a) with P
+// a minimax fit of the ABSOLUTE error of a 2^P(a) on [0, 10] (tools/lab/fit_gelu.py).  P decreases monotonically for every
+// a >= 0: no clamp, 2^P underflows to 0 and gelu(x) -> max(x, 0).
+//   degree 3: max |error| 5.5e-5 against the exact erf form   -- 5 VALU + 1 transcendental
+//   degree 5: max |error| 8.6e-7 (fp32 evaluation)           -- 7 VALU + 1 transcendental
+// against 7 VALU + 2 transcendentals (v_exp, v_rcp: 8 issue cycles each, MI355X guide) for the sigmoid form of rounds 2-4.
+// The function takes h = x / 2 (the fused MLP kernels fold the factor into the packed W1 / b1 operands: a power of two, so
+// every product and sum is the same bits, halved):   max(x, 0) = h + |h|  is ONE v_add with a source modifier -- fmaxf(x, 0)
+// costs two instructions, a canonicalising `v_max x, x` first, because the accumulator of an MFMA is not known to be quiet --
+// and   gelu(x) = (h + |h|) - |h| 2^(P(2 |h|) + 1):   3 (5) fma + v_exp + v_add + fma, nothing but compiler-visible
+// instructions (inline-asm forms of v_max / v_fma were tried: the hazard recogniser does not see into them, and they read
+// MFMA results before the matrix pipe had written them).  The bf16 kernels use degree 3 (their result is rounded to 8 bits:
+// half an ulp is 1e-3 at 0.5), the fp16 kernels degree 5 (half an ulp 1.2e-4).
+template <int DEG> __device__ __forceinline__ float cn_gelu_e1_half(float h) {
+  const float a = __builtin_fabsf(h);
+  float p;
+  if constexpr (DEG == 3) {
+    p = fmaf(a, 8.0f * -0.02487156353890896f, 4.0f * -0.49887558817863464f);
+    p = fmaf(p, a, 2.0f * -1.1291841268539429f);
+    p = fmaf(p, a, 1.0f - 1.0035500526428223f);
+  } else {
+    static_assert(DEG == 5, "degree 3 or 5");
+    p = fmaf(a, 32.0f * -0.0004728270578198135f, 16.0f * 0.007081141695380211f);
+    p = fmaf(p, a, 8.0f * -0.05181875079870224f);
+    p = fmaf(p, a, 4.0f * -0.4600019156932831f);
+    p = fmaf(p, a, 2.0f * -1.1507835388183594f);
+    p = fmaf(p, a, 1.0f - 1.0000382661819458f);
+  }
+  float g = fmaf(-a, __builtin_amdgcn_exp2f(p), h + a);
+  // (an empty asm: the result is an opaque scalar, so the SLP vectoriser -- seeded by the v_cvt_pk that packs two neighbouring
+  // results -- does not pair the elements' closing instructions into v_pk_add_f32 / v_pk_fma_f32: those cannot take |h| as a
+  // modifier, need a v_and per element to materialise it, and are an anti-lever beside MFMAs, MI355X guide)
+  asm("" : "+v"(g));
+  return g;
+}
+template <int DEG> __device__ __forceinline__ float cn_gelu_e1(float x) { return cn_gelu_e1_half<DEG>(0.5f * x); }
+
 // XCD-aware block remap (cdna guide T1, bijective form): workgroups are dealt round-robin over the
 // 8 XCDs, each with a private L2, so blocks b and b+8 share an L2.  Give every XCD one CONTIGUOUS
 // chunk of the logical grid so that neighbouring tiles (shared halos / shared A panels) hit in L2

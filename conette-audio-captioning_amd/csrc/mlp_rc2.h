@@ -39,6 +39,24 @@ __device__ __forceinline__ float cn_gelu_sig2(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// (cn_gelu_e1<DEG>: common.h -- the one-transcendental form of round 5)
+// The GELU of the fused MLP kernels.  Unless this is an A/B build of the sigmoid form, the packed W1 / b1 operands carry a factor
+// 1/2 (CN_MLP_XSCALE, applied by the packers below) and the accumulator of GEMM1 is x / 2.
+#if defined(CN_GELU_SIG2)
+#define CN_MLP_XSCALE 1.0f
+#else
+#define CN_MLP_XSCALE 0.5f
+#endif
+template <typename HT> __device__ __forceinline__ float cn_gelu_mlp(float x) {
+#if defined(CN_GELU_SIG2)   // A/B builds: the two-transcendental sigmoid form of rounds 2-4
+  return cn_gelu_sig2(x);
+#elif defined(CN_GELU_E1_DEG)
+  return cn_gelu_e1_half<CN_GELU_E1_DEG>(x);
+#else
+  return cn_gelu_e1_half<__is_same(HT, half_t) ? 5 : 3>(x);
+#endif
+}
+
 // two elements at once: v_pk_mul / v_pk_fma / v_pk_add carry both (the two min, exp2 and rcp stay scalar)
 __device__ __forceinline__ f32x2 cn_gelu_sig2_pk(f32x2 x) {
   constexpr float L2E = 1.4426950408889634f;
@@ -67,9 +85,9 @@ static __global__ void pk_mlp_rc2(const float* __restrict__ W1, const float* __r
     const int j = st * NCK + q / F1, s = q % F1;
     if (s < KS1) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = W1[(size_t)(32 * j + r) * C + 16 * s + 8 * h + i];
+      for (int i = 0; i < 8; ++i) v[i] = CN_MLP_XSCALE * W1[(size_t)(32 * j + r) * C + 16 * s + 8 * h + i];
     } else {
-      const float b = b1[32 * j + r];
+      const float b = CN_MLP_XSCALE * b1[32 * j + r];
       const float hi = (float)(HT)b;
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = 0.f;
@@ -113,7 +131,7 @@ template <int C, int NCK, typename HT = bf16_t> struct Rc2Wave {
   static __device__ __forceinline__ hx8 gelu8(const f32x16& X, int o) {
     float g[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) g[i] = cn_gelu_sig2(X[o + i]);
+    for (int i = 0; i < 8; ++i) g[i] = cn_gelu_mlp<HT>(X[o + i]);
     return cn_sat8<HT>(cn_pack8<HT>(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]));
   }
   static __device__ __forceinline__ f32x16 zero16() {
@@ -143,7 +161,7 @@ template <int C, int NCK, typename HT = bf16_t> struct Rc2Wave {
   }
   template <int Q, int I, int E>
   static __device__ __forceinline__ void gelu_slices(State& st) {  // (compile-time recursion: every index is a constant)
-#ifdef CN_RC2_GELU_PK
+#if defined(CN_RC2_GELU_PK) && defined(CN_GELU_SIG2)
     if constexpr ((E & 1) == 0 && gelu_at(I, E) == Q) {  // pairs (E, E + 1) ride together behind MFMA gelu_at(I, E)
       const f32x2 r = cn_gelu_sig2_pk(f32x2{st.X[I][E], st.X[I][E + 1]});
       st.g[I][E] = r[0];
@@ -152,7 +170,7 @@ template <int C, int NCK, typename HT = bf16_t> struct Rc2Wave {
     if constexpr (gelu_at(I, E & ~1) == Q) {
 #else
     if constexpr (gelu_at(I, E) == Q) {
-      st.g[I][E] = cn_gelu_sig2(st.X[I][E]);
+      st.g[I][E] = cn_gelu_mlp<HT>(st.X[I][E]);
 #endif
       if constexpr ((E & 7) == 7) {
         constexpr int o = E - 7;

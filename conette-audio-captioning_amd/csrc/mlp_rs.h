@@ -53,9 +53,9 @@ static __global__ void pk_mlp_rs(const float* __restrict__ W1, const float* __re
     const int j = e, s = q;
     if (s < KS1) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = W1[(size_t)(32 * j + r) * C + 16 * s + 8 * h + i];
+      for (int i = 0; i < 8; ++i) v[i] = CN_MLP_XSCALE * W1[(size_t)(32 * j + r) * C + 16 * s + 8 * h + i];
     } else {  // bias k-step: fp32 b1 as hi + lo bf16 against a "ones" fragment
-      const float b = b1[32 * j + r];
+      const float b = CN_MLP_XSCALE * b1[32 * j + r];
       const float hi = (float)(HT)b;
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = 0.f;
@@ -100,9 +100,14 @@ template <int C, int NP, int ABL = 0, typename HT = bf16_t> struct RsWave {
   template <int Q, int E>
   static __device__ __forceinline__ void a_gelu(const f32x16& Xp, AState& st) {
     if constexpr (gelu_at(E) == Q) {
+#if defined(CN_GELU_SIG2)
       const f32x2 r = (ABL & 2) ? f32x2{Xp[E], Xp[E + 1]} : cn_gelu_sig2_pk(f32x2{Xp[E], Xp[E + 1]});
       st.g[E] = r[0];
       st.g[E + 1] = r[1];
+#else
+      st.g[E] = (ABL & 2) ? Xp[E] : cn_gelu_mlp<HT>(Xp[E]);
+      st.g[E + 1] = (ABL & 2) ? Xp[E + 1] : cn_gelu_mlp<HT>(Xp[E + 1]);
+#endif
     }
     if constexpr (E + 2 < 16) a_gelu<Q, E + 2>(Xp, st);
   }
