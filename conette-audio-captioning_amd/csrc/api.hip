@@ -463,12 +463,12 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
           if (w1 && w2 && bw.b1 && bw.b2 && bw.scale && cn_pack_mlp_f8(w1, bw.b1, w2, bw.b2, bw.scale, C, ms, 0) == CN_OK) bw.mlp_f8 = ms;
         }
         if (ctx->esize == 2 && C <= 384) {
-          const size_t bytes = (size_t)(C / 8) * (C / 8 + 1) * 1024 + (size_t)C * 4;  // Rc2Geom<C, 1>::TOTAL_BYTES
+          const size_t bytes = (size_t)(C / 8) * (C / 8 + 1) * 1024 + (size_t)(C / 32) * 1024;  // Rc2Geom<C, 1>::TOTAL_BYTES (the role-split stream's tail, C fp32, is smaller)
           void* ms = B.alloc(bytes);
           const float* w1 = B.find(p + "pwconv1.weight", (int64_t)4 * C * C);
           const float* w2 = B.find(p + "pwconv2.weight", (int64_t)4 * C * C);
           if (w1 && w2 && bw.b1 && bw.b2 && bw.scale) {
-            const int units = (C / 8) * (C / 8 + 1) * 64;
+            const int units = ((C / 8) * (C / 8 + 1) + C / 32) * 64;  // one thread per 16-byte fragment piece, the bias fragments included
             // C = 384 runs the role-split kernel (mlp_rs.h): same fragments, entry e = [W1 of chunk e | W2 of chunk e - 2]
 #ifndef CN_NO_RS
             if (C == 384) CN_H16_CALL(ctx, hipLaunchKernelGGL(pk_mlp_rs<HT>, dim3((units + 255) / 256), dim3(256), 0, 0, w1, bw.b1, w2, bw.b2, bw.scale, C, (HT*)ms));

@@ -168,6 +168,20 @@ __device__ __forceinline__ float cn_to_f32(bf16_t x) { return (float)x; }
 __device__ __forceinline__ float cn_to_f32(half_t x) { return (float)x; }
 __device__ __forceinline__ float cn_to_f32(sp16_t x) { return (float)x.hi + (float)x.lo; }
 
+// ---- the residual stream's element type XT ------------------------------------------------------------------------------
+// float in the fp32 / exact / fp8 precisions; half_t (IEEE fp16) in the 16-bit precisions since round 5: every kernel that
+// touches the stream moves half the bytes (a ConvNeXt block: 16 C -> 10 C bytes per position), and the stream's 11 significant
+// bits cost the bf16 precision nothing measurable (frame embeddings 4.43e-3 -> 4.48e-3 rel. rms off the fp32 oracle) and the
+// f16 precision 5.4e-4 -> 8.5e-4 (oracle/rounding_study.py).  |x| <= 65504 is required of the stream (cn_from_f32<half_t>
+// saturates in the element-wise kernels; the fused MLP's packed conversion does not).
+__device__ __forceinline__ float cn_ld1(const float* p) { return *p; }
+__device__ __forceinline__ float cn_ld1(const half_t* p) { return (float)*p; }
+__device__ __forceinline__ f32x4 cn_ld4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 cn_ld4(const half_t* p) {
+  const cn_h4<half_t> h = *(const cn_h4<half_t>*)p;
+  return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+
 // exact-erf GELU (torch F.gelu default; reference convnext.py:47, aac_tfmer.py:36)
 __device__ __forceinline__ float cn_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

@@ -1,5 +1,5 @@
 // Fused downsample layer (16-bit operands HT = bf16_t | half_t), stage 0 -> 1:   LayerNorm(channels_first, eps 1e-6) + Conv2d(C -> 2C, k 2x2, s 2)
-//     x fp32 (B, H, W, C)  ->  out fp32 (B, H/2, W/2, 2C)                        (reference convnext.py:207-217)
+//     x XT (B, H, W, C)  ->  out XT (B, H/2, W/2, 2C), XT = the residual stream's type (common.h)     (reference convnext.py:207-217)
 //
 // The two-kernel form (cn_ln_patchify_kernel writes the bf16 patch matrix, cn_gemm2 reads it back) moves the patch matrix
 // through HBM twice; here a wave owns 32 OUTPUT positions and builds its GEMM operand in registers:
@@ -10,8 +10,10 @@
 //   * the LayerNorm affine is folded into the packed weights at create time: W'[n][k] = bf16(W[n][k] g[c(k)]),
 //     bias'[n] = bias[n] + sum_k W[n][k] b[c(k)] (fp32), so the operand is bf16((x - mean) rstd);
 //   * the whole packed weight matrix (K x N bf16 = 144 KB at C = 96) is resident in LDS; persistent blocks, no barrier
-//     after the fill; C[pos][n] accumulates with the channels on the lanes, stored like the fused MLP's epilogue.
-// Packed stream: fragment (s, t), s < K/16, t < N/32: lane l holds W'[32 t + (l & 31)][16 s + 8 (l >> 5) .. + 8]; then bias'[N] fp32.
+//     after the fill; the product runs transposed since round 5 (C^T[n][pos] = W' . a^T, the weight fragment as the A operand):
+//     a lane owns one output position and two runs of 8 consecutive channels per 32-channel tile, stored as 16-byte pieces
+//     like the fused MLP's epilogue (mlp_rc2.h).
+// Packed stream: fragment (s, t), s < K/16, t < N/32: lane l holds W'[32 t + cn_rc2_chan(l & 31)][16 s + 8 (l >> 5) .. + 8]; then bias'[N] fp32.
 #pragma once
 #include "mlp_rc2.h"
 
@@ -34,7 +36,7 @@ static __global__ void pk_down_fused(const float* __restrict__ src, const float*
   }
   if (u >= KS * NT * 64) return;
   const int l = u & 63, t = (u >> 6) % NT, s = (u >> 6) / NT;
-  const int n = 32 * t + (l & 31);
+  const int n = 32 * t + cn_rc2_chan(l & 31);
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int k = 16 * s + 8 * (l >> 5) + i, kk = k / C, c = k % C;
@@ -45,8 +47,8 @@ static __global__ void pk_down_fused(const float* __restrict__ src, const float*
 
 // The GEMM operand of a 32-position tile: a[(ip - IP0) * CH + j] = bf16((x - mean) rstd) of channels 16 j + 8 (lane >> 5) .. + 8 of
 // input position ip (IP0 <= ip < IP0 + NIP; ip = 2 kh + kw) of output position `tile * 32 + (lane & 31)` (clamped to P - 1).
-template <int CP, int IP0, int NIP, typename HT>
-static __device__ __forceinline__ void cn_down_operand(const float* __restrict__ X, int H, int W, long P, long tile, int lane,
+template <int CP, int IP0, int NIP, typename HT, typename XT>
+static __device__ __forceinline__ void cn_down_operand(const XT* __restrict__ X, int H, int W, long P, long tile, int lane,
                                                        cn_h8<HT> (&a)[NIP * DownGeom<CP>::CH]) {
   constexpr int CH = DownGeom<CP>::CH;
   const int H2 = H / 2, W2 = W / 2, hh = lane >> 5;
@@ -56,14 +58,25 @@ static __device__ __forceinline__ void cn_down_operand(const float* __restrict__
     const long tq = p / W2;
     const int h2 = (int)(tq % H2);
     const long b = tq / H2;
-    const float* x00 = X + (((size_t)b * H + 2 * h2) * W + 2 * w2) * CP + 8 * hh;
+    const XT* x00 = X + (((size_t)b * H + 2 * h2) * W + 2 * w2) * CP + 8 * hh;
     f32x4 v[2][CH][2];
     auto load_ip = [&](int ip, f32x4 (&d)[CH][2]) {
-      const float* src = x00 + ((size_t)(ip >> 1) * W + (ip & 1)) * CP;
+      const XT* src = x00 + ((size_t)(ip >> 1) * W + (ip & 1)) * CP;
+      if constexpr (sizeof(XT) == 2) {
+        cn_h8<XT> h[CH];
 #pragma unroll
-      for (int j = 0; j < CH; ++j) {
-        d[j][0] = *(const f32x4*)(src + 16 * j);
-        d[j][1] = *(const f32x4*)(src + 16 * j + 4);
+        for (int j = 0; j < CH; ++j) h[j] = *(const cn_h8<XT>*)(src + 16 * j);  // one 16-byte piece = the lane's 8 channels
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          d[j][0] = f32x4{(float)h[j][0], (float)h[j][1], (float)h[j][2], (float)h[j][3]};
+          d[j][1] = f32x4{(float)h[j][4], (float)h[j][5], (float)h[j][6], (float)h[j][7]};
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+          d[j][0] = *(const f32x4*)(src + 16 * j);
+          d[j][1] = *(const f32x4*)(src + 16 * j + 4);
+        }
       }
     };
     load_ip(IP0, v[0]);
@@ -97,24 +110,34 @@ static __device__ __forceinline__ void cn_down_operand(const float* __restrict__
     }
 }
 
-// out[m0 + row][:] = acc + bias' (channels on the lanes, 128-byte row pieces)
-template <int CP>
-static __device__ __forceinline__ void cn_down_store(float* __restrict__ OUT, const float* __restrict__ biasp, long P, long tile, int lane,
+// out[tile * 32 + (l & 31)][:] = acc + bias': lane = output position, register r of tile t = channel 32 t + 16 (r >> 3) + 8 (l >> 5) + (r & 7)
+template <int CP, typename XT>
+static __device__ __forceinline__ void cn_down_store(XT* __restrict__ OUT, const float* __restrict__ biasp, long P, long tile, int lane,
                                                      const f32x16 (&acc)[DownGeom<CP>::NT]) {
   constexpr int NT = DownGeom<CP>::NT, N = DownGeom<CP>::N;
   const int hh = lane >> 5;
-  const long m0 = tile * 32;
-  const int voff = 4 * hh * N + (lane & 31);
-  const long plim = P - m0 - 4 * hh;
-  float bb[NT];
+  const long m = tile * 32 + (lane & 31);
+  if (m >= P) return;
+  XT* row = OUT + (size_t)m * N + 8 * hh;
+  const float* bl = biasp + 8 * hh;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) bb[t] = biasp[32 * t + (lane & 31)];
+  for (int t = 0; t < NT; ++t) {
+    float o[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float* row = OUT + (size_t)(m0 + (r & 3) + 8 * (r >> 2)) * N;  // scalar
-    if ((r & 3) + 8 * (r >> 2) < plim) {
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b = *(const f32x4*)(bl + 32 * t + 16 * (q >> 1) + 4 * (q & 1));
 #pragma unroll
-      for (int t = 0; t < NT; ++t) row[voff + 32 * t] = acc[t][r] + bb[t];
+      for (int e = 0; e < 4; ++e) o[4 * q + e] = acc[t][4 * q + e] + b[e];
+    }
+    if constexpr (sizeof(XT) == 2) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        *(cn_h8<XT>*)(row + 32 * t + 16 * h) = cn_pack8<XT>(o[8 * h], o[8 * h + 1], o[8 * h + 2], o[8 * h + 3], o[8 * h + 4],
+                                                            o[8 * h + 5], o[8 * h + 6], o[8 * h + 7]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(f32x4*)(row + 32 * t + 16 * (q >> 1) + 4 * (q & 1)) = f32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
     }
   }
 }
@@ -128,7 +151,7 @@ template <int CP, typename HT> struct DownMma {
   static __device__ __forceinline__ void step(const char* wl, const cn_h8<HT> (&a)[G::KS], f32x16 (&acc)[G::NT], cn_h8<HT> (&f)[R]) {
     if constexpr (Q + PRE < NM) f[(Q + PRE) % R] = *(const cn_h8<HT>*)(wl + (Q + PRE) * 1024);
     constexpr int s = Q / G::NT, t = Q % G::NT;
-    acc[t] = cn_mma32(a[s], f[Q % R], acc[t]);
+    acc[t] = cn_mma32(f[Q % R], a[s], acc[t]);  // C^T += W' . a^T
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (Q + 1 < NM) step<Q + 1>(wl, a, acc, f);
   }
@@ -142,9 +165,9 @@ template <int CP, typename HT> struct DownMma {
   }
 };
 
-template <int CP, int NW, typename HT>
-__global__ __launch_bounds__(NW * 64) void cn_down_fused_kernel(const float* __restrict__ X, int H, int W, long P,
-                                                                const HT* __restrict__ WS, float* __restrict__ OUT) {
+template <int CP, int NW, typename HT, typename XT>
+__global__ __launch_bounds__(NW * 64) void cn_down_fused_kernel(const XT* __restrict__ X, int H, int W, long P,
+                                                                const HT* __restrict__ WS, XT* __restrict__ OUT) {
   typedef DownGeom<CP> G;
   constexpr int KS = G::KS, NT = G::NT, CH = G::CH, N = G::N;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -162,7 +185,7 @@ __global__ __launch_bounds__(NW * 64) void cn_down_fused_kernel(const float* __r
   const char* wl = smem + lane * 16;
   for (long tile = t_lo + wave; tile < t_hi; tile += NW) {
     cn_h8<HT> a[KS];
-    cn_down_operand<CP, 0, 4, HT>(X, H, W, P, tile, lane, a);
+    cn_down_operand<CP, 0, 4, HT, XT>(X, H, W, P, tile, lane, a);
     // ---- C[pos][n] = sum_k a[pos][k] W'[n][k]: positions in the registers' rows, channels on the lanes ------------------
     f32x16 acc[NT];
 #pragma unroll
@@ -170,19 +193,19 @@ __global__ __launch_bounds__(NW * 64) void cn_down_fused_kernel(const float* __r
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     DownMma<CP, HT>::template run<0>(wl, a, acc);  // hand-ordered: fragment q + PRE is requested before MFMA q (see mlp_rc2.h)
-    cn_down_store<CP>(OUT, biasp, P, tile, lane, acc);
+    cn_down_store<CP, XT>(OUT, biasp, P, tile, lane, acc);
   }
 }
 
-template <int CP, int NW, typename HT>
-static int cn_launch_down_fused(const float* X, int B, int H, int W, const void* WS, float* OUT, int n_blocks, hipStream_t s) {
+template <int CP, int NW, typename HT, typename XT>
+static int cn_launch_down_fused(const XT* X, int B, int H, int W, const void* WS, XT* OUT, int n_blocks, hipStream_t s) {
   typedef DownGeom<CP> G;
   constexpr int SMEM = (int)G::STREAM_BYTES;
   static_assert(SMEM <= 160 * 1024, "the packed weights must fit in LDS");
   const long P = (long)B * (H / 2) * (W / 2);
-  CN_TRY(cn_configure_lds((const void*)cn_down_fused_kernel<CP, NW, HT>, SMEM));
+  CN_TRY(cn_configure_lds((const void*)cn_down_fused_kernel<CP, NW, HT, XT>, SMEM));
   const int grid = cn_rc2_grid((int)((P + 31) / 32), NW, n_blocks);
-  hipLaunchKernelGGL((cn_down_fused_kernel<CP, NW, HT>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, X, H, W, P, (const HT*)WS, OUT);
+  hipLaunchKernelGGL((cn_down_fused_kernel<CP, NW, HT, XT>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, X, H, W, P, (const HT*)WS, OUT);
   CN_LAUNCH_CHECK();
   return CN_OK;
 }
@@ -215,7 +238,7 @@ template <int CP, int NW, int KSTEP, int NST, typename HT> struct DownRing {
   static __device__ __forceinline__ void mma(const char* wl, const cn_h8<HT> (&a)[KS / 2], f32x16 (&acc)[NT], cn_h8<HT> (&f)[R]) {
     if constexpr (Q + PRE < FR) f[(Q + PRE) % R] = *(const cn_h8<HT>*)(wl + (Q + PRE) * 1024);
     constexpr int s = (J % HS) * KSTEP + Q / NT, t = Q % NT;
-    acc[t] = cn_mma32(a[s], f[Q % R], acc[t]);
+    acc[t] = cn_mma32(f[Q % R], a[s], acc[t]);  // C^T += W' . a^T
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (Q + 1 < FR) mma<J, Q + 1>(wl, a, acc, f);
   }
@@ -238,9 +261,9 @@ template <int CP, int NW, int KSTEP, int NST, typename HT> struct DownRing {
   }
 };
 
-template <int CP, int NW, int KSTEP, int NST, typename HT>
-__global__ __launch_bounds__(NW * 64) void cn_down_fused_ring_kernel(const float* __restrict__ X, int H, int W, long P,
-                                                                     const HT* __restrict__ WS, float* __restrict__ OUT) {
+template <int CP, int NW, int KSTEP, int NST, typename HT, typename XT>
+__global__ __launch_bounds__(NW * 64) void cn_down_fused_ring_kernel(const XT* __restrict__ X, int H, int W, long P,
+                                                                     const HT* __restrict__ WS, XT* __restrict__ OUT) {
   typedef DownGeom<CP> G;
   typedef DownRing<CP, NW, KSTEP, NST, HT> K;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -264,24 +287,24 @@ __global__ __launch_bounds__(NW * 64) void cn_down_fused_ring_kernel(const float
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     {  // K in two halves: the operand of two input positions (96 registers) at a time
       cn_h8<HT> a[G::KS / 2];
-      cn_down_operand<CP, 0, 2, HT>(X, H, W, P, ltile, lane, a);
+      cn_down_operand<CP, 0, 2, HT, XT>(X, H, W, P, ltile, lane, a);
       K::template steps<0, K::HS>(wsrc, smem, wave, lane, it * K::NSTEP, valid, a, acc);
-      cn_down_operand<CP, 2, 2, HT>(X, H, W, P, ltile, lane, a);
+      cn_down_operand<CP, 2, 2, HT, XT>(X, H, W, P, ltile, lane, a);
       K::template steps<K::HS, K::NSTEP>(wsrc, smem, wave, lane, it * K::NSTEP, valid, a, acc);
     }
-    if (valid) cn_down_store<CP>(OUT, biasp, P, tile, lane, acc);
+    if (valid) cn_down_store<CP, XT>(OUT, biasp, P, tile, lane, acc);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring was filled NST - 1 entries past the end
 }
 
-template <int CP, int NW, int KSTEP, int NST, typename HT>
-static int cn_launch_down_fused_ring(const float* X, int B, int H, int W, const void* WS, float* OUT, int n_blocks, hipStream_t s) {
+template <int CP, int NW, int KSTEP, int NST, typename HT, typename XT>
+static int cn_launch_down_fused_ring(const XT* X, int B, int H, int W, const void* WS, XT* OUT, int n_blocks, hipStream_t s) {
   typedef DownRing<CP, NW, KSTEP, NST, HT> K;
   static_assert(K::SMEM <= 160 * 1024, "ring must fit in LDS");
   const long P = (long)B * (H / 2) * (W / 2);
-  CN_TRY(cn_configure_lds((const void*)cn_down_fused_ring_kernel<CP, NW, KSTEP, NST, HT>, K::SMEM));
+  CN_TRY(cn_configure_lds((const void*)cn_down_fused_ring_kernel<CP, NW, KSTEP, NST, HT, XT>, K::SMEM));
   const int grid = cn_rc2_grid((int)((P + 31) / 32), NW, n_blocks);
-  hipLaunchKernelGGL((cn_down_fused_ring_kernel<CP, NW, KSTEP, NST, HT>), dim3((unsigned)grid), dim3(NW * 64), K::SMEM, s, X, H, W, P,
+  hipLaunchKernelGGL((cn_down_fused_ring_kernel<CP, NW, KSTEP, NST, HT, XT>), dim3((unsigned)grid), dim3(NW * 64), K::SMEM, s, X, H, W, P,
                      (const HT*)WS, OUT);
   CN_LAUNCH_CHECK();
   return CN_OK;

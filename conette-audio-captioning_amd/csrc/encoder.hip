@@ -2,8 +2,8 @@
 //
 // Reference: nn/encoders/convnext.py:61-74 (block), :207-217 (stem / downsample), :264-336
 // (forward), nn/modules/norm.py:31-40 (LayerNorm).  Activations are channels-last (B, H, W, C)
-// with H = time, W = frequency; the residual stream stays fp32, GEMM operands are the context's
-// operand type (bf16 or fp32).  Depthwise 7x7 + LayerNorm run on the VALU, the pointwise and
+// with H = time, W = frequency; the residual stream is of type XT (common.h: fp16 in the 16-bit
+// precisions, fp32 otherwise), GEMM operands are the context's operand type.  Depthwise 7x7 + LayerNorm run on the VALU, the pointwise and
 // downsample contractions on MFMA through cn_gemm (north_star).
 #include <stddef.h>
 
@@ -24,11 +24,11 @@
 // values go through an LDS tile and leave as whole 1 KB wave stores (16-byte pieces at a 96-byte lane stride made
 // the kernel store bound: 172 us for 403 MB).
 // ---------------------------------------------------------------------------------------------
-template <int P>  // positions per lane group: the weights read from LDS (6 KB per position otherwise) are shared by P positions
+template <int P, typename XT>  // P positions per lane group: the weights read from LDS (6 KB per position otherwise) are shared by P positions
 __global__ __launch_bounds__(256) void cn_stem_kernel(const float* __restrict__ in, int F, int H0, long n_pos,
                                                       const float* __restrict__ w /*[16][96]*/,
                                                       const float* __restrict__ bias, const float* __restrict__ ln_w,
-                                                      const float* __restrict__ ln_b, float* __restrict__ out) {
+                                                      const float* __restrict__ ln_b, XT* __restrict__ out) {
   __shared__ __attribute__((aligned(16))) float s_w[16 * 96];
   __shared__ __attribute__((aligned(16))) float s_o[P * 64 * 96];
   for (int i = threadIdx.x; i < 16 * 96; i += 256) s_w[i] = w[i];
@@ -91,6 +91,19 @@ __global__ __launch_bounds__(256) void cn_stem_kernel(const float* __restrict__ 
     }
   }
   __syncthreads();
+  if constexpr (sizeof(XT) == 2) {
+    const long n8 = min((long)(64 * P), n_pos - pos0) * 12;  // 16-byte pieces (8 values) of this block's positions
+    cn_h8<XT>* o8 = (cn_h8<XT>*)(out + (size_t)pos0 * 96);
+#pragma unroll
+    for (int k = 0; k < 3 * P; ++k) {
+      const int i = threadIdx.x + 256 * k;
+      if (i < n8) {
+        const f32x4 a = ((const f32x4*)s_o)[2 * i], b = ((const f32x4*)s_o)[2 * i + 1];
+        o8[i] = cn_h8<XT>{cn_from_f32<XT>(a[0]), cn_from_f32<XT>(a[1]), cn_from_f32<XT>(a[2]), cn_from_f32<XT>(a[3]),
+                          cn_from_f32<XT>(b[0]), cn_from_f32<XT>(b[1]), cn_from_f32<XT>(b[2]), cn_from_f32<XT>(b[3])};
+      }
+    }
+  } else {
   const long n4 = min((long)(64 * P), n_pos - pos0) * 24;  // 16-byte pieces of this block's positions
   f32x4* o4 = (f32x4*)(out + (size_t)pos0 * 96);
 #pragma unroll
@@ -98,10 +111,13 @@ __global__ __launch_bounds__(256) void cn_stem_kernel(const float* __restrict__ 
     const int i = threadIdx.x + 256 * k;
     if (i < n4) o4[i] = ((const f32x4*)s_o)[i];
   }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
-// depthwise 7x7 (pad 3) + LayerNorm over C (eps 1e-6): x fp32 (B,H,W,C) -> y T (B,H,W,C)
+// depthwise 7x7 (pad 3) + LayerNorm over C (eps 1e-6): x XT (B,H,W,C) -> y T (B,H,W,C)
+// (XT = half_t: 2-byte loads feed v_fma_mix_f32 directly -- the fp16 input is an operand of the fp32 fma, no conversion
+// instruction, the same products and sums as from an fp32 stream holding the same values)
 // One thread = one channel x a TH(h) x 4(w) output patch: (TH+6) x 10 loads feed TH*4*49 FMAs.
 // Loads are branch-free (clamped address, zero-masked value) and issued a whole input row at a
 // time so that many are in flight; lanes run over channels, so every load instruction is one
@@ -130,8 +146,8 @@ template <int C, int S, int TH> struct DwTile {
   static constexpr int PITCH = PITCH4 * 4;
 };
 
-template <typename T, int C, int S, int TH>
-__global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(const float* __restrict__ x, int H, int W, int tiles_h,
+template <typename T, typename XT, int C, int S, int TH>
+__global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(const XT* __restrict__ x, int H, int W, int tiles_h,
                                                             int tiles_w, const float* __restrict__ dw_w /*[49][C]*/,
                                                             const float* __restrict__ dw_b,
                                                             const float* __restrict__ ln_w,
@@ -173,13 +189,13 @@ __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(c
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[a][e] = bias;
 
-  const float* xb = x + (size_t)b * H * W * C + c;
+  const XT* xb = x + (size_t)b * H * W * C + c;
   // 80 % of the tiles are interior: no clamping / masking, and every load of an input row is
   // `row base + compile-time offset` (q * C floats fits the 13-bit immediate), which removes the
   // per-load 64-bit address arithmetic that dominated the VALU instruction count (rocprof:
   // 4250 VALU wave-instructions per 32-output patch against 1568 FMAs).
   const bool interior = (h0 >= 3) && (h0 + TH + 3 <= H) && (w0 >= 3) && (w0 + 4 + 3 <= W);
-  auto fma_row = [&](int r, const float (&v)[10]) {
+  auto fma_row = [&](int r, const XT (&v)[10]) {
 #pragma unroll
     for (int oh = 0; oh < TH; ++oh) {
       const int i = r - oh;
@@ -190,26 +206,26 @@ __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(c
         for (int ow = 0; ow < 4; ++ow) {
           const int j = q - ow;
           if (j < 0 || j > 6) continue;
-          acc[oh][ow] = fmaf(v[q], k[i * 7 + j], acc[oh][ow]);
+          acc[oh][ow] = fmaf((float)v[q], k[i * 7 + j], acc[oh][ow]);
         }
     }
   };
   if (interior) {
-    const float* base = xb + ((size_t)(h0 - 3) * W + (w0 - 3)) * C;
+    const XT* base = xb + ((size_t)(h0 - 3) * W + (w0 - 3)) * C;
     // explicit two-row software pipeline: the loads of row r+1 are in flight under the FMAs of row r
-    float va[10], vb[10];
+    XT va[10], vb[10];
 #pragma unroll
     for (int q = 0; q < 10; ++q) va[q] = base[q * C];
 #pragma unroll
     for (int r = 0; r < TH + 6; r += 2) {
       if (r + 1 < TH + 6) {
-        const float* xr = base + (size_t)(r + 1) * W * C;
+        const XT* xr = base + (size_t)(r + 1) * W * C;
 #pragma unroll
         for (int q = 0; q < 10; ++q) vb[q] = xr[q * C];
       }
       fma_row(r, va);
       if (r + 2 < TH + 6) {
-        const float* xr = base + (size_t)(r + 2) * W * C;
+        const XT* xr = base + (size_t)(r + 2) * W * C;
 #pragma unroll
         for (int q = 0; q < 10; ++q) va[q] = xr[q * C];
       }
@@ -220,12 +236,12 @@ __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(c
     for (int r = 0; r < TH + 6; ++r) {
       const int hh = h0 - 3 + r;
       const bool hok = (hh >= 0) && (hh < H);
-      const float* xr = xb + (size_t)min(max(hh, 0), H - 1) * W * C;
-      float v[10];
+      const XT* xr = xb + (size_t)min(max(hh, 0), H - 1) * W * C;
+      XT v[10];
 #pragma unroll
       for (int q = 0; q < 10; ++q) v[q] = xr[wcl[q]];
 #pragma unroll
-      for (int q = 0; q < 10; ++q) v[q] = (hok && wok[q]) ? v[q] : 0.f;
+      for (int q = 0; q < 10; ++q) v[q] = (hok && wok[q]) ? v[q] : (XT)0.f;
       fma_row(r, v);
     }
   }
@@ -331,13 +347,13 @@ extern "C" int conette_debug_dwprof(unsigned long long* out8, int reset) {
   return CN_OK;
 }
 
-template <typename T, int C, int S, int TH>
-static int launch_dwconv(const float* x, int B, int H, int W, const CnBlockW& bw, T* y, hipStream_t s) {
+template <typename T, typename XT, int C, int S, int TH>
+static int launch_dwconv(const XT* x, int B, int H, int W, const CnBlockW& bw, T* y, hipStream_t s) {
   const int tiles_h = cn_cdiv(H, TH), tiles_w = cn_cdiv(W, 4 * S);
   constexpr int NPOS_ = TH * 4 * S, NT_ = (C > 384 ? 384 : C) * S;
   const size_t smem = ((size_t)NPOS_ * DwTile<C, S, TH>::PITCH + NPOS_ * (NT_ / NPOS_) + 2 * NPOS_) * sizeof(float);
-  CN_TRY(cn_configure_lds((const void*)cn_dwconv_ln_kernel<T, C, S, TH>, (int)smem));
-  hipLaunchKernelGGL((cn_dwconv_ln_kernel<T, C, S, TH>), dim3((unsigned)(B * tiles_h * tiles_w)),
+  CN_TRY(cn_configure_lds((const void*)cn_dwconv_ln_kernel<T, XT, C, S, TH>, (int)smem));
+  hipLaunchKernelGGL((cn_dwconv_ln_kernel<T, XT, C, S, TH>), dim3((unsigned)(B * tiles_h * tiles_w)),
                      dim3((C > 384 ? 384 : C) * S), smem, s, x, H, W, tiles_h, tiles_w, bw.dw_w, bw.dw_b, bw.ln_w, bw.ln_b, y,
 #ifdef CN_G2_PROF
                      getenv("CN_DW_DEBUG") ? atoi(getenv("CN_DW_DEBUG")) : 0);
@@ -363,8 +379,8 @@ static int launch_dwconv(const float* x, int B, int H, int W, const CnBlockW& bw
 // outputs can see and keeps TH x NOW accumulators.  SPLIT = 2 (C = 384) gives each half of the width to its own thread, so a
 // block has twice the waves over the same LDS tile (12 per CU instead of 6) and a thread half the accumulators; the taps of
 // an output are still added in the same (kh, kw) order, so the result does not depend on SPLIT.
-template <int C, int WW, int TH, int OW0, int NOW>
-__device__ __forceinline__ void cn_fw_conv(const float* __restrict__ xb /* + c */, int H, int h0,
+template <int C, int WW, int TH, int OW0, int NOW, typename XT>
+__device__ __forceinline__ void cn_fw_conv(const XT* __restrict__ xb /* + c */, int H, int h0,
                                            const float* __restrict__ dw_w, float bias, int c, float* __restrict__ s_v,
                                            int PITCH) {
   constexpr int Q0 = OW0 - 3 < 0 ? 0 : OW0 - 3, Q1 = OW0 + NOW + 3 > WW ? WW : OW0 + NOW + 3, NQ = Q1 - Q0;
@@ -376,18 +392,18 @@ __device__ __forceinline__ void cn_fw_conv(const float* __restrict__ xb /* + c *
   for (int a = 0; a < TH; ++a)
 #pragma unroll
     for (int e = 0; e < NOW; ++e) acc[a][e] = bias;
-  auto load_row = [&](int r, float (&v)[NQ]) {
+  auto load_row = [&](int r, XT (&v)[NQ]) {
     const int hh = h0 - 3 + r;
     if (hh >= 0 && hh < H) {  // block-uniform
-      const float* xr = xb + (size_t)hh * WW * C;
+      const XT* xr = xb + (size_t)hh * WW * C;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) v[q] = xr[(Q0 + q) * C];
     } else {
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) v[q] = 0.f;
+      for (int q = 0; q < NQ; ++q) v[q] = (XT)0.f;
     }
   };
-  auto fma_row = [&](int r, const float (&v)[NQ]) {
+  auto fma_row = [&](int r, const XT (&v)[NQ]) {
 #pragma unroll
     for (int oh = 0; oh < TH; ++oh) {
       const int i = r - oh;
@@ -398,11 +414,11 @@ __device__ __forceinline__ void cn_fw_conv(const float* __restrict__ xb /* + c *
         for (int j = 0; j < 7; ++j) {
           const int q = OW0 + ow + j - 3;
           if (q < 0 || q >= WW) continue;  // zero padding left / right of the map: the tap does not exist
-          acc[oh][ow] = fmaf(v[q - Q0], k[i * 7 + j], acc[oh][ow]);
+          acc[oh][ow] = fmaf((float)v[q - Q0], k[i * 7 + j], acc[oh][ow]);
         }
     }
   };
-  float va[NQ], vb[NQ];
+  XT va[NQ], vb[NQ];
   load_row(0, va);
 #pragma unroll
   for (int r = 0; r < TH + 6; r += 2) {
@@ -417,8 +433,8 @@ __device__ __forceinline__ void cn_fw_conv(const float* __restrict__ xb /* + c *
     for (int ow = 0; ow < NOW; ++ow) s_v[(oh * WW + OW0 + ow) * PITCH + c] = acc[oh][ow];
 }
 
-template <typename T, int C, int WW, int TH, int SPLIT>
-__global__ __launch_bounds__(C* SPLIT > 384 ? 768 : 384) void cn_dwconv_ln_fw_kernel(const float* __restrict__ x, int H, int tiles_h,
+template <typename T, typename XT, int C, int WW, int TH, int SPLIT>
+__global__ __launch_bounds__(C* SPLIT > 384 ? 768 : 384) void cn_dwconv_ln_fw_kernel(const XT* __restrict__ x, int H, int tiles_h,
                                                               const float* __restrict__ dw_w /*[49][C]*/,
                                                               const float* __restrict__ dw_b,
                                                               const float* __restrict__ ln_w,
@@ -434,17 +450,17 @@ __global__ __launch_bounds__(C* SPLIT > 384 ? 768 : 384) void cn_dwconv_ln_fw_ke
   const int th = bid % tiles_h;
   const int b = bid / tiles_h;
   const int h0 = th * TH;
-  const float* xb0 = x + (size_t)b * H * WW * C;
+  const XT* xb0 = x + (size_t)b * H * WW * C;
 
   if constexpr (SPLIT == 1) {
 #pragma unroll 1
-    for (int c = tid; c < C; c += CT) cn_fw_conv<C, WW, TH, 0, WW>(xb0 + c, H, h0, dw_w, dw_b[c], c, s_v, PITCH);
+    for (int c = tid; c < C; c += CT) cn_fw_conv<C, WW, TH, 0, WW, XT>(xb0 + c, H, h0, dw_w, dw_b[c], c, s_v, PITCH);
   } else {
     const int c = tid < C ? tid : tid - C;  // waves 0-5: left half, waves 6-11: right half (wave-uniform)
     if (tid < C)
-      cn_fw_conv<C, WW, TH, 0, WW / 2>(xb0 + c, H, h0, dw_w, dw_b[c], c, s_v, PITCH);
+      cn_fw_conv<C, WW, TH, 0, WW / 2, XT>(xb0 + c, H, h0, dw_w, dw_b[c], c, s_v, PITCH);
     else
-      cn_fw_conv<C, WW, TH, WW / 2, WW / 2>(xb0 + c, H, h0, dw_w, dw_b[c], c, s_v, PITCH);
+      cn_fw_conv<C, WW, TH, WW / 2, WW / 2, XT>(xb0 + c, H, h0, dw_w, dw_b[c], c, s_v, PITCH);
   }
   __syncthreads();
   // LayerNorm statistics: wave per position, C / 64 values per lane, two positions per iteration
@@ -498,12 +514,12 @@ __global__ __launch_bounds__(C* SPLIT > 384 ? 768 : 384) void cn_dwconv_ln_fw_ke
 #ifndef CN_FW_SPLIT
 #define CN_FW_SPLIT 2
 #endif
-template <typename T, int C, int WW, int TH, int SPLIT = 1>
-static int launch_dwconv_fw(const float* x, int B, int H, const CnBlockW& bw, T* y, hipStream_t s) {
+template <typename T, typename XT, int C, int WW, int TH, int SPLIT = 1>
+static int launch_dwconv_fw(const XT* x, int B, int H, const CnBlockW& bw, T* y, hipStream_t s) {
   const int tiles_h = cn_cdiv(H, TH);
   const size_t smem = ((size_t)TH * WW * (C + 4) + 2 * TH * WW) * sizeof(float);
-  CN_TRY(cn_configure_lds((const void*)cn_dwconv_ln_fw_kernel<T, C, WW, TH, SPLIT>, (int)smem));
-  hipLaunchKernelGGL((cn_dwconv_ln_fw_kernel<T, C, WW, TH, SPLIT>), dim3((unsigned)(B * tiles_h)), dim3(C * SPLIT > 384 ? 768 : 384), smem, s, x, H,
+  CN_TRY(cn_configure_lds((const void*)cn_dwconv_ln_fw_kernel<T, XT, C, WW, TH, SPLIT>, (int)smem));
+  hipLaunchKernelGGL((cn_dwconv_ln_fw_kernel<T, XT, C, WW, TH, SPLIT>), dim3((unsigned)(B * tiles_h)), dim3(C * SPLIT > 384 ? 768 : 384), smem, s, x, H,
                      tiles_h, bw.dw_w, bw.dw_b, bw.ln_w, bw.ln_b, y);
   CN_LAUNCH_CHECK();
   return CN_OK;
@@ -514,8 +530,8 @@ static int launch_dwconv_fw(const float* x, int B, int H, const CnBlockW& bw, T*
 // x fp32 (B,H,W,C) -> p T (B, H/2, W/2, (kh, kw, C)); rows/cols beyond 2*floor() are dropped.
 // One wave per input position.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int C>
-__global__ __launch_bounds__(256) void cn_ln_patchify_kernel(const float* __restrict__ x, int H, int W, long n_pos,
+template <typename T, typename XT, int C>
+__global__ __launch_bounds__(256) void cn_ln_patchify_kernel(const XT* __restrict__ x, int H, int W, long n_pos,
                                                              const float* __restrict__ ln_w,
                                                              const float* __restrict__ ln_b, T* __restrict__ p) {
   // A lane owns 4 consecutive channels (16-byte loads, 8-byte bf16 stores: one 2-byte store per lane made the
@@ -537,7 +553,7 @@ __global__ __launch_bounds__(256) void cn_ln_patchify_kernel(const float* __rest
     const long pos = min(pos0 + u * SLOTS + sl, n_pos - 1);
 #pragma unroll
     for (int i = 0; i < PER; ++i)
-      v[u][i] = act ? *(const f32x4*)(x + (size_t)pos * C + 4 * (ll + LANES * i)) : f32x4{0.f, 0.f, 0.f, 0.f};
+      v[u][i] = act ? cn_ld4(x + (size_t)pos * C + 4 * (ll + LANES * i)) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   f32x4 gw[PER], gb[PER];
 #pragma unroll
@@ -585,13 +601,13 @@ __global__ __launch_bounds__(256) void cn_ln_patchify_kernel(const float* __rest
 }
 
 // frame_embs[b][t][c] = mean over the W freq positions (convnext.py:306); also an operand-type copy
-template <typename T>
-__global__ __launch_bounds__(256) void cn_frame_mean_kernel(const float* __restrict__ x, int W, int C,
+template <typename T, typename XT>
+__global__ __launch_bounds__(256) void cn_frame_mean_kernel(const XT* __restrict__ x, int W, int C,
                                                             float* __restrict__ fe, T* __restrict__ fe_t) {
   const size_t bt = blockIdx.x;
   for (int c = threadIdx.x; c < C; c += 256) {
     float s = 0.f;
-    for (int w = 0; w < W; ++w) s += x[(bt * W + w) * C + c];
+    for (int w = 0; w < W; ++w) s += cn_ld1(x + (bt * W + w) * C + c);
     const float m = s / (float)W;
     fe[bt * C + c] = m;
     if (fe_t) fe_t[bt * C + c] = cn_from_f32<T>(m);
@@ -680,7 +696,7 @@ extern "C" int32_t conette_num_audio_frames(int32_t n_samples) { return enc_geom
 
 struct EncWs {
   float* logmel;
-  float* x;
+  void* x;   // the residual stream (XT)
   void* y;
   void* h;
   void* fe_t;
@@ -700,7 +716,7 @@ static EncWs enc_ws(const conette_ctx* ctx, int B, int L, char* base) {
   };
   w.logmel = (float*)take((size_t)B * g.F * CN_N_MELS * 4);
   // (+ 32 rows: the fused MLP reads whole 32-position tiles; rows past the last position are read, never written)
-  w.x = (float*)take((n0 + 32 * 96) * 4);
+  w.x = take((n0 + 32 * 96) * 4);  // (sized for fp32 whatever the stream's type)
   w.y = take((n0 + 32 * 96) * es);
   w.h = take(n0 * 4 * es);
   w.fe_t = take((size_t)B * g.H[3] * CN_FEAT * es);
@@ -713,17 +729,17 @@ extern "C" size_t conette_encode_workspace_bytes(const conette_ctx* ctx, int32_t
   return enc_ws(ctx, batch, n_samples, nullptr).total;
 }
 
-template <typename T>
-static int dwconv_dispatch(int C, const float* x, int B, int H, int W, const CnBlockW& bw, T* y, hipStream_t s) {
+template <typename T, typename XT>
+static int dwconv_dispatch(int C, const XT* x, int B, int H, int W, const CnBlockW& bw, T* y, hipStream_t s) {
   switch (C) {
-    case 96: return launch_dwconv<T, 96, 2, 8>(x, B, H, W, bw, y, s);
-    case 192: return launch_dwconv<T, 192, 1, 8>(x, B, H, W, bw, y, s);
+    case 96: return launch_dwconv<T, XT, 96, 2, 8>(x, B, H, W, bw, y, s);
+    case 192: return launch_dwconv<T, XT, 192, 1, 8>(x, B, H, W, bw, y, s);
     case 384:
-      if (W == 14) return launch_dwconv_fw<T, 384, 14, 4, CN_FW_SPLIT>(x, B, H, bw, y, s);
-      return launch_dwconv<T, 384, 1, 4>(x, B, H, W, bw, y, s);
+      if (W == 14) return launch_dwconv_fw<T, XT, 384, 14, 4, CN_FW_SPLIT>(x, B, H, bw, y, s);
+      return launch_dwconv<T, XT, 384, 1, 4>(x, B, H, W, bw, y, s);
     case 768:
-      if (W == 7) return launch_dwconv_fw<T, 768, 7, 4>(x, B, H, bw, y, s);
-      return launch_dwconv<T, 768, 1, 4>(x, B, H, W, bw, y, s);
+      if (W == 7) return launch_dwconv_fw<T, XT, 768, 7, 4>(x, B, H, bw, y, s);
+      return launch_dwconv<T, XT, 768, 1, 4>(x, B, H, W, bw, y, s);
   }
   cn_set_error("dwconv: unsupported C=%d", C);
   return CN_ERR_ARG;
@@ -733,14 +749,27 @@ static int tap_copy(float* dst, const float* src, size_t n, hipStream_t s) {
   if (dst) CN_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
   return CN_OK;
 }
+// (taps are fp32 at the C ABI whatever the residual stream's type: an fp16 stream is widened, exactly)
+static __global__ void cn_tap_widen_kernel(const half_t* __restrict__ src, float* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = (float)src[i];
+}
+static int tap_copy(float* dst, const half_t* src, size_t n, hipStream_t s) {
+  if (dst) {
+    hipLaunchKernelGGL(cn_tap_widen_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s, src, dst, n);
+    CN_LAUNCH_CHECK();
+  }
+  return CN_OK;
+}
 
-template <typename T>
+// T: the GEMM operand type of the precision; XT: the residual stream's type (common.h)
+template <typename T, typename XT>
 static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float* frame_embs, float* clip_probs,
                        const conette_encode_taps* taps, char* wsp, hipStream_t s) {
   const EncGeom g = enc_geom(L);
   EncWs ws = enc_ws(ctx, B, L, wsp);
   T* y = (T*)ws.y;
   T* hbuf = (T*)ws.h;
+  XT* const wsx = (XT*)ws.x;
   {
     CnProfScope ps(ctx, CONETTE_PROF_FRONTEND, s);
     CN_TRY(cn_frontend(ctx, wave, B, L, ws.logmel, s));
@@ -749,12 +778,12 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
   {
     const long n_pos = (long)B * g.H[0] * g.W[0];
     CnProfScope ps(ctx, CONETTE_PROF_STEM, s);
-    hipLaunchKernelGGL(cn_stem_kernel<1>, dim3((unsigned)((n_pos + 63) / 64)), dim3(256), 0, s, ws.logmel, g.F, g.H[0],
-                       n_pos, ctx->stem_w, ctx->stem_b, ctx->stem_ln_w, ctx->stem_ln_b, ws.x);
+    hipLaunchKernelGGL((cn_stem_kernel<1, XT>), dim3((unsigned)((n_pos + 63) / 64)), dim3(256), 0, s, ws.logmel, g.F, g.H[0],
+                       n_pos, ctx->stem_w, ctx->stem_b, ctx->stem_ln_w, ctx->stem_ln_b, wsx);
     CN_LAUNCH_CHECK();
-    if (taps) CN_TRY(tap_copy(taps->stem, ws.x, (size_t)n_pos * 96, s));
+    if (taps) CN_TRY(tap_copy(taps->stem, wsx, (size_t)n_pos * 96, s));
   }
-  float* xc = ws.x;  // the residual stream: ws.x, or ws.h after the fused stage-1 downsample (which cannot run in place)
+  XT* xc = wsx;  // the residual stream: ws.x, or ws.h after the fused stage-1 downsample (which cannot run in place)
   int blk = 0;
   for (int st = 0; st < 4; ++st) {
     const int C = CN_DIMS[st], H = g.H[st], W = g.W[st];
@@ -768,10 +797,10 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
       if constexpr (CnIsH16<T>::value) if (Cp <= 192 && dw.fused != nullptr) {
         // LayerNorm + patch GEMM in one kernel (down_fused.h).  It cannot run in place: the residual stream moves to the
         // other of ws.x / ws.h (stages 0-2 run the fused MLP in bf16, so the hidden buffer is free until stage 3).
-        float* xo = xc == ws.x ? (float*)ws.h : ws.x;
+        XT* xo = xc == wsx ? (XT*)ws.h : wsx;
         const int nb = ctx->n_cu - ctx->enc_reserved_cus;
-        if (Cp == 96) CN_TRY((cn_launch_down_fused<96, 8, T>(xc, B, Hp, Wp, dw.fused, xo, nb, s)));
-        else CN_TRY((cn_launch_down_fused_ring<192, 4, 4, 3, T>(xc, B, Hp, Wp, dw.fused, xo, nb, s)));
+        if (Cp == 96) CN_TRY((cn_launch_down_fused<96, 8, T, XT>(xc, B, Hp, Wp, dw.fused, xo, nb, s)));
+        else CN_TRY((cn_launch_down_fused_ring<192, 4, 4, 3, T, XT>(xc, B, Hp, Wp, dw.fused, xo, nb, s)));
         xc = xo;
         if (taps) CN_TRY(tap_copy(taps->down[st], xc, (size_t)P * C, s));
         fused_down = true;
@@ -780,28 +809,32 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
       const int ppb = Cp == 96 ? 32 : 16;           // positions per block: 4 waves x 4 groups x (2 | 1) positions
       const dim3 pg((unsigned)((n_in + ppb - 1) / ppb));
       if (Cp == 96)
-        hipLaunchKernelGGL((cn_ln_patchify_kernel<T, 96>), pg, dim3(256), 0, s, xc, Hp, Wp, n_in, dw.ln_w, dw.ln_b, y);
+        hipLaunchKernelGGL((cn_ln_patchify_kernel<T, XT, 96>), pg, dim3(256), 0, s, xc, Hp, Wp, n_in, dw.ln_w, dw.ln_b, y);
       else if (Cp == 192)
-        hipLaunchKernelGGL((cn_ln_patchify_kernel<T, 192>), pg, dim3(256), 0, s, xc, Hp, Wp, n_in, dw.ln_w, dw.ln_b, y);
+        hipLaunchKernelGGL((cn_ln_patchify_kernel<T, XT, 192>), pg, dim3(256), 0, s, xc, Hp, Wp, n_in, dw.ln_w, dw.ln_b, y);
       else
-        hipLaunchKernelGGL((cn_ln_patchify_kernel<T, 384>), pg, dim3(256), 0, s, xc, Hp, Wp, n_in, dw.ln_w, dw.ln_b, y);
+        hipLaunchKernelGGL((cn_ln_patchify_kernel<T, XT, 384>), pg, dim3(256), 0, s, xc, Hp, Wp, n_in, dw.ln_w, dw.ln_b, y);
       CN_LAUNCH_CHECK();
-      EpiBiasAct<float, ACT_NONE> epi{dw.bias, ws.x, C, ACT_NONE};
+      EpiBiasAct<XT, ACT_NONE> epi{dw.bias, wsx, C, ACT_NONE};
       CN_TRY(cn_mm(y, 4 * Cp, (const T*)dw.w, 4 * Cp, (int)P, C, 4 * Cp, epi, s));
-      xc = ws.x;
+      xc = wsx;
       if (taps) CN_TRY(tap_copy(taps->down[st], xc, (size_t)P * C, s));
       }
     }
     for (int b = 0; b < CN_DEPTHS[st]; ++b, ++blk) {
       const CnBlockW& bw = ctx->blocks[blk];
-      const bool f8 = std::is_same<T, bf16_t>::value && ctx->fp8 && bw.mlp_f8 != nullptr && C <= 384;
+      const bool f8 = std::is_same<T, bf16_t>::value && std::is_same<XT, float>::value && ctx->fp8 && bw.mlp_f8 != nullptr && C <= 384;
       {
         CnProfScope ps(ctx, CONETTE_PROF_DWCONV_LN, s);
-        if (f8) CN_TRY(dwconv_dispatch<f8_t>(C, xc, B, H, W, bw, (f8_t*)ws.y, s));  // y as e4m3 (scale 1)
-        else CN_TRY(dwconv_dispatch<T>(C, xc, B, H, W, bw, y, s));
+        if constexpr (std::is_same<XT, float>::value) {
+          if (f8) CN_TRY((dwconv_dispatch<f8_t, XT>(C, xc, B, H, W, bw, (f8_t*)ws.y, s)));  // y as e4m3 (scale 1)
+          else CN_TRY((dwconv_dispatch<T, XT>(C, xc, B, H, W, bw, y, s)));
+        } else {
+          CN_TRY((dwconv_dispatch<T, XT>(C, xc, B, H, W, bw, y, s)));
+        }
       }
       bool fused = false;
-      if (f8) {  // CONETTE_PREC_FP8: pw1 + GELU + pw2 + residual with e4m3 operands (mlp_f8.h)
+      if constexpr (std::is_same<XT, float>::value) if (f8) {  // CONETTE_PREC_FP8: pw1 + GELU + pw2 + residual with e4m3 operands (mlp_f8.h)
         CnProfScope ps(ctx, CONETTE_PROF_PW1_GEMM, s);
         const unsigned char* y8 = (const unsigned char*)ws.y;
         const int nb = ctx->n_cu - ctx->enc_reserved_cus;
@@ -848,7 +881,7 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
         }
         {
           CnProfScope ps(ctx, CONETTE_PROF_PW2_GEMM, s);
-          EpiResid e2{bw.b2, bw.scale, xc, xc, C};
+          EpiResidT<XT> e2{bw.b2, bw.scale, xc, xc, C};
           CN_TRY(cn_mm(hbuf, 4 * C, (const T*)bw.w2, 4 * C, (int)P, C, 4 * C, e2, s));
         }
       }
@@ -860,7 +893,7 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
   }
   const int Tn = g.H[3];
   CnProfScope ps_heads(ctx, CONETTE_PROF_HEADS, s);
-  hipLaunchKernelGGL((cn_frame_mean_kernel<T>), dim3((unsigned)(B * Tn)), dim3(256), 0, s, xc, g.W[3], CN_FEAT,
+  hipLaunchKernelGGL((cn_frame_mean_kernel<T, XT>), dim3((unsigned)(B * Tn)), dim3(256), 0, s, xc, g.W[3], CN_FEAT,
                      frame_embs, (T*)nullptr);
   CN_LAUNCH_CHECK();
   if (clip_probs) {
@@ -904,6 +937,18 @@ extern "C" int conette_encode(conette_ctx* ctx, const float* wave, int32_t batch
     cn_set_error("encode: workspace %zu < %zu", workspace_bytes, need);
     return CN_ERR_WORKSPACE;
   }
-  CN_BY_PRECISION(ctx, encode_impl<OT>(ctx, wave, batch, n_samples, frame_embs, clip_probs, taps, (char*)workspace,
-                               (hipStream_t)stream));
+  // the residual stream's type: fp16 in the 16-bit precisions (round 5), fp32 in the others and in the fp8 precision, whose
+  // e4m3 kernels (mlp_f8.h) keep the fp32 stream they were written for
+  switch (ctx->cfg.precision) {
+    case CONETTE_PREC_BF16:
+      return encode_impl<bf16_t, half_t>(ctx, wave, batch, n_samples, frame_embs, clip_probs, taps, (char*)workspace, (hipStream_t)stream);
+    case CONETTE_PREC_FP8:
+      return encode_impl<bf16_t, float>(ctx, wave, batch, n_samples, frame_embs, clip_probs, taps, (char*)workspace, (hipStream_t)stream);
+    case CONETTE_PREC_F16:
+      return encode_impl<half_t, half_t>(ctx, wave, batch, n_samples, frame_embs, clip_probs, taps, (char*)workspace, (hipStream_t)stream);
+    case CONETTE_PREC_F16X2:
+      return encode_impl<sp16_t, float>(ctx, wave, batch, n_samples, frame_embs, clip_probs, taps, (char*)workspace, (hipStream_t)stream);
+    default:
+      return encode_impl<float, float>(ctx, wave, batch, n_samples, frame_embs, clip_probs, taps, (char*)workspace, (hipStream_t)stream);
+  }
 }

@@ -109,12 +109,12 @@ template <typename TOut, int ACT = -1> struct EpiBiasAct {
   }
 };
 
-// out[m][n] = resid[m][n] + scale[n] * (acc + bias[n])      (fp32 residual stream; in-place ok)
-struct EpiResid {
+// out[m][n] = resid[m][n] + scale[n] * (acc + bias[n])      (residual stream of type XT, common.h; in-place ok)
+template <typename XT> struct EpiResidT {
   const float* bias;
   const float* scale;  // may be null (== 1)
-  const float* resid;
-  float* out;
+  const XT* resid;
+  XT* out;
   int ld;
   typedef float stage_t;
   __device__ __forceinline__ float pre(int n, float x, int N) const {
@@ -125,13 +125,13 @@ struct EpiResid {
   __device__ __forceinline__ void commit(int m, int n, const float* chunk, int N, int /*ks*/) const {
     const size_t o = (size_t)m * ld + n;
     if (n + 3 < N && (ld & 3) == 0) {
-      const f32x4 rs = *(const f32x4*)(resid + o);
+      const f32x4 rs = cn_ld4(resid + o);
       const f32x4 c = *(const f32x4*)chunk;
-      *(f32x4*)(out + o) = f32x4{rs[0] + c[0], rs[1] + c[1], rs[2] + c[2], rs[3] + c[3]};
+      cn_store4(out + o, rs[0] + c[0], rs[1] + c[1], rs[2] + c[2], rs[3] + c[3]);
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (n + i < N) out[o + i] = resid[o + i] + chunk[i];
+        if (n + i < N) out[o + i] = cn_from_f32<XT>(cn_ld1(resid + o + i) + chunk[i]);
     }
   }
   // --- batched interface (gemm2.h direct epilogue): every load of a batch of tiles is issued before its first store.
@@ -148,30 +148,31 @@ struct EpiResid {
     c.s = scale ? *(const f32x4*)(scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
     return c;
   }
-  __device__ __forceinline__ f32x4 prefetch(int m, int n) const { return *(const f32x4*)(resid + (size_t)m * ld + n); }
+  __device__ __forceinline__ f32x4 prefetch(int m, int n) const { return cn_ld4(resid + (size_t)m * ld + n); }
   __device__ __forceinline__ void finish(int m, int n, f32x4 v, const Cols& c, f32x4 rs) const {
     f32x4 r;
 #pragma unroll
     for (int i = 0; i < 4; ++i) r[i] = rs[i] + c.s[i] * (v[i] + c.b[i]);
-    *(f32x4*)(out + (size_t)m * ld + n) = r;
+    cn_store4(out + (size_t)m * ld + n, r[0], r[1], r[2], r[3]);
   }
   __device__ __forceinline__ void operator()(int m, int n, f32x4 v, int N, int /*ks*/ = 0) const {
     const size_t o = (size_t)m * ld + n;
     if (n + 3 < N && (ld & 3) == 0) {
-      f32x4 rs = *(const f32x4*)(resid + o);
+      f32x4 rs = cn_ld4(resid + o);
       f32x4 b = *(const f32x4*)(bias + n);
       f32x4 s = scale ? *(const f32x4*)(scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
       f32x4 r;
 #pragma unroll
       for (int i = 0; i < 4; ++i) r[i] = rs[i] + s[i] * (v[i] + b[i]);
-      *(f32x4*)(out + o) = r;
+      cn_store4(out + o, r[0], r[1], r[2], r[3]);
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (n + i < N) out[o + i] = resid[o + i] + (scale ? scale[n + i] : 1.0f) * (v[i] + bias[n + i]);
+        if (n + i < N) out[o + i] = cn_from_f32<XT>(cn_ld1(resid + o + i) + (scale ? scale[n + i] : 1.0f) * (v[i] + bias[n + i]));
     }
   }
 };
+typedef EpiResidT<float> EpiResid;
 
 template <typename T> struct Frag8;
 template <> struct Frag8<bf16_t> { typedef bf16x8 type; };

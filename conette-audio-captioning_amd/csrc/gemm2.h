@@ -185,22 +185,22 @@ __device__ __forceinline__ void cn_g2_epilogue(char* smem, f32x4 (&acc)[BN / (16
         // (register budget: the 128 x 128 tiles must stay at 148 registers so that a decode block can start next to
         // one resident GEMM workgroup, dec_block.h; sched_barrier keeps hipcc from hoisting every accumulator read
         // and column load to the top of the epilogue)
-        const float* rp = epi.resid + (size_t)mb * epi.ld + nb;  // one 64-bit base, immediate / scalar offsets from here
-        float* op = epi.out + (size_t)mb * epi.ld + nb;
+        const auto* rp = epi.resid + (size_t)mb * epi.ld + nb;  // one 64-bit base, immediate / scalar offsets from here
+        auto* op = epi.out + (size_t)mb * epi.ld + nb;          // (the residual stream's type: fp32 or fp16, common.h)
         const size_t rstride = (size_t)16 * epi.ld;
 #pragma unroll
         for (int a = 0; a < TN; ++a) {
           const typename Epi::Cols c = epi.cols(nb + a * 16);
           f32x4 r[TM];
 #pragma unroll
-          for (int b = 0; b < TM; ++b) r[b] = *(const f32x4*)(rp + b * rstride + a * 16);
+          for (int b = 0; b < TM; ++b) r[b] = cn_ld4(rp + b * rstride + a * 16);
 #pragma unroll
           for (int b = 0; b < TM; ++b) {
             const f32x4 v = acc[a][b];
             f32x4 o;
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[i] = r[b][i] + c.s[i] * (v[i] + c.b[i]);
-            *(f32x4*)(op + b * rstride + a * 16) = o;
+            cn_store4(op + b * rstride + a * 16, o[0], o[1], o[2], o[3]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }

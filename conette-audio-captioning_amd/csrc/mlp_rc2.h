@@ -8,13 +8,20 @@
 // * a STEP covers NCK = 1 or 2 chunks and is one basic block whose MFMA / VALU / LDS-read interleave is laid down with
 //   sched_group_barrier: NCK = 2:  M1a | M1b + GELU a | M2a + GELU b | M2b;   NCK = 1:  M1 | GELU lo | M2(k 0) + GELU hi | M2(k 1)
 //   with the fragment reads running a few MFMAs ahead of their use;
+// * GEMM2 runs TRANSPOSED since round 5 -- O^T[ch][pos] += W2c' . G^T, the W2 fragment as the A operand and the converted
+//   accumulator as B (the two operands have the same per-lane layout, so the fragments did not change): a lane owns ONE
+//   position and, per 32-channel tile, two runs of 8 consecutive channels (the rows of the W2 fragments are permuted for
+//   that, cn_rc2_chan), so the residual moves as 16-byte pieces with the access pattern of the y fragments -- 6 loads + 6 stores
+//   per tile at C = 96 with an fp16 residual stream (XT = half_t, the 16-bit precisions since round 5: 10 C -> 6 C bytes per
+//   position and block for this kernel) where the channels-on-lanes layout of rounds 2-4 moved 48 + 48 dwords;
 // * LayerScale is folded into the packed W2 rows (W2'[c][:] = bf16(s[c] W2[c][:])) and the accumulators START from the
-//   residual: O = x, loaded straight into the accumulator registers at the start of a tile (the HBM latency hides under
-//   the first GEMM1; no VALU work, no extra registers); the epilogue is x' = O + s b2, stores only.
+//   residual plus the folded output bias: O = x + s b2, the bias through one MFMA per channel tile (a (hi, lo) fragment
+//   against the constant "ones" fragment, like b1: the VALU is what these kernels run out of, the matrix pipe has slack);
+//   the epilogue is a conversion and the stores.
 //
 // Packed stream per step (1 KB fragments, lane l reads 16 B at 16 l):
 //   [chunk i: W1 fragments k-step 0 .. C/16-1, bias fragment] i < NCK, then [chunk i: W2 fragments (k 0, tile t) t < C/32, (k 1, t)] i < NCK
-// followed by the per-channel vector bb = s b2 (fp32, C).
+// followed by C/32 fragments holding bb = s b2 as (hi, lo) pairs, one per channel tile.
 #pragma once
 #include "common.h"
 
@@ -25,8 +32,12 @@ template <int C, int NCK> struct Rc2Geom {
   static constexpr int FRAGS = NCK * (F1 + F2);      // fragments per step
   static constexpr int STEP_BYTES = FRAGS * 1024;
   static constexpr size_t STREAM_BYTES = (size_t)NSTEP * STEP_BYTES;
-  static constexpr size_t TOTAL_BYTES = STREAM_BYTES + C * 4;
+  static constexpr size_t TOTAL_BYTES = STREAM_BYTES + NT2 * 1024;
 };
+// Row m of a W2 (or output-bias) fragment = accumulator row m of the transposed product = channel cn_rc2_chan(m) of the tile:
+// lane (pos, h = l >> 5) holds rows 8 (r >> 2) + 4 h + (r & 3) in register r, and with bits 2 and 3 of m swapped those are the
+// channels 16 (r >> 3) + 8 h + (r & 7): registers 0-7 and 8-15 are two runs of 8 consecutive channels.
+__host__ __device__ constexpr int cn_rc2_chan(int m) { return (m & 19) | ((m & 4) << 1) | ((m & 8) >> 1); }
 
 // GELU as x * sigmoid(x (a + b x^2 + c x^4)): minimax fit of the logit of the normal CDF on [-8, 8], max |error|
 // against the exact erf form 2.5e-5 (tanh form: 4.7e-4).  x^2 is clamped at 64, where the quartic would bend back.
@@ -76,12 +87,21 @@ static __global__ void pk_mlp_rc2(const float* __restrict__ W1, const float* __r
                            HT* __restrict__ dst) {
   const int KS1 = C / 16, NT2 = C / 32, NCH = C / 8, F1 = KS1 + 1, F2 = 2 * NT2, FRAGS = NCK * (F1 + F2), NSTEP = NCH / NCK;
   const int u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u < C) ((float*)((char*)dst + (size_t)NSTEP * FRAGS * 1024))[u] = scale[u] * b2[u];  // bb behind the stream
-  if (u >= NSTEP * FRAGS * 64) return;
+  if (u >= (NSTEP * FRAGS + NT2) * 64) return;
   const int l = u & 63, q = (u >> 6) % FRAGS, st = (u >> 6) / FRAGS;
   const int r = l & 31, h = l >> 5;
   float v[8];
-  if (q < NCK * F1) {
+  if (st >= NSTEP) {  // behind the stream: bb = s b2 of channel tile q as a (hi, lo) k-step
+    const int c = 32 * q + cn_rc2_chan(r);
+    const float b = scale[c] * b2[c];
+    const float hi = (float)(HT)b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    if (h == 0) {
+      v[0] = hi;
+      v[1] = b - hi;
+    }
+  } else if (q < NCK * F1) {
     const int j = st * NCK + q / F1, s = q % F1;
     if (s < KS1) {
 #pragma unroll
@@ -99,7 +119,7 @@ static __global__ void pk_mlp_rc2(const float* __restrict__ W1, const float* __r
   } else {
     const int q2 = q - NCK * F1;
     const int j = st * NCK + q2 / F2, s = (q2 % F2) / NT2, t = (q2 % F2) % NT2;
-    const int c = 32 * t + r;
+    const int c = 32 * t + cn_rc2_chan(r);
     const float sc = scale[c];
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = sc * W2[(size_t)c * (4 * C) + 32 * j + 16 * s + 8 * (i >> 2) + 4 * h + (i & 3)];
@@ -120,7 +140,7 @@ static __global__ void pk_mlp_rc2(const float* __restrict__ W1, const float* __r
 // MFMA of the step loop).  (Lab: issuing piece q INSIDE the step, behind MFMA q by wave q % NW, only moved the ~70 cycles
 // a piece costs its wave from the top of the step into the step, MFMAs or not: 201 us against 189.  profiles/r02_notes.md)
 
-template <int C, int NCK, typename HT = bf16_t> struct Rc2Wave {
+template <int C, int NCK, typename HT = bf16_t, typename XT = float> struct Rc2Wave {
   typedef Rc2Geom<C, NCK> G;
   typedef cn_h8<HT> hx8;
   static constexpr int KS1 = G::KS1, NT2 = G::NT2, F1 = G::F1, F2 = G::F2;
@@ -192,7 +212,7 @@ template <int C, int NCK, typename HT = bf16_t> struct Rc2Wave {
       else st.X[i] = mma(st.F[Q % R], ones, st.X[i]);
     } else {
       constexpr int q2 = Q - NCK * F1, i = q2 / F2, k = (q2 % F2) / NT2, t = q2 % NT2;
-      O[t] = mma(st.H[i][k], st.F[Q % R], O[t]);
+      O[t] = mma(st.F[Q % R], st.H[i][k], O[t]);  // O^T += W2c' . G^T
     }
     gelu_slices<Q, 0, 0>(st);
     __builtin_amdgcn_sched_barrier(0);
@@ -222,7 +242,67 @@ template <int C, int NCK, typename HT = bf16_t> struct Rc2Wave {
     for (int s = 0; s < KS1; ++s) fy[s] = *(const hx8*)(base + voff + 16 * s);
   }
 
-  // O = x: lane = channel 32 t + (l & 31), register r = position (r&3) + 8 (r>>2) + 4 (l>>5)
+  // O^T = x^T + bb: lane = position m0 + (l & 31); register r of tile t = channel 32 t + 16 (r >> 3) + 8 (l >> 5) + (r & 7).
+  // bbf: the NT2 output-bias fragments behind the stream (global memory, lane offset applied; L1 / L2 resident).
+  static __device__ __forceinline__ void init_o(const XT* __restrict__ X, const char* __restrict__ bbf, const hx8 ones, int m0,
+                                                int lane, f32x16 (&O)[NT2]) {
+    const XT* base = X + (size_t)m0 * C;                    // scalar
+    const int voff = (lane & 31) * C + 8 * (lane >> 5);     // elements
+    hx8 fb[NT2];
+    if constexpr (sizeof(XT) == 2) {
+      cn_h8<XT> v[NT2][2];
+#pragma unroll
+      for (int t = 0; t < NT2; ++t) {
+        v[t][0] = *(const cn_h8<XT>*)(base + voff + 32 * t);
+        v[t][1] = *(const cn_h8<XT>*)(base + voff + 32 * t + 16);
+      }
+#pragma unroll
+      for (int t = 0; t < NT2; ++t) fb[t] = *(const hx8*)(bbf + t * 1024);
+#pragma unroll
+      for (int t = 0; t < NT2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[t][r] = (float)v[t][r >> 3][r & 7];
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = *(const f32x4*)(base + voff + 32 * t + 16 * (q >> 1) + 4 * (q & 1));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) O[t][4 * q + e] = v[e];
+        }
+#pragma unroll
+      for (int t = 0; t < NT2; ++t) fb[t] = *(const hx8*)(bbf + t * 1024);
+    }
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) O[t] = mma(fb[t], ones, O[t]);
+  }
+
+  // x' = O, converted to the stream's type: 16-byte pieces (the rows of a ragged last tile beyond M are not written)
+  static __device__ __forceinline__ void store_o(XT* __restrict__ X, int m0, int M, int lane, const f32x16 (&O)[NT2]) {
+    XT* base = X + (size_t)m0 * C;
+    const int voff = (lane & 31) * C + 8 * (lane >> 5);
+    if (m0 + (lane & 31) >= M) return;
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) {
+      if constexpr (sizeof(XT) == 2) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+          *(cn_h8<XT>*)(base + voff + 32 * t + 16 * o) = cn_pack8<XT>(O[t][8 * o], O[t][8 * o + 1], O[t][8 * o + 2], O[t][8 * o + 3],
+                                                                      O[t][8 * o + 4], O[t][8 * o + 5], O[t][8 * o + 6], O[t][8 * o + 7]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *(f32x4*)(base + voff + 32 * t + 16 * (q >> 1) + 4 * (q & 1)) = f32x4{O[t][4 * q], O[t][4 * q + 1], O[t][4 * q + 2], O[t][4 * q + 3]};
+      }
+    }
+  }
+};
+
+// The channels-on-lanes residual I/O of rounds 2-4 (O[pos][ch], dword pieces), still the layout of the exact precision's
+// fused block (mlp_sp.h: its GEMM2 is not transposed): lane = channel 32 t + (l & 31), register r = position (r & 3) + 8 (r >> 2) + 4 (l >> 5).
+template <int C> struct Rc2IoCl {
+  static constexpr int NT2 = C / 32;
   static __device__ __forceinline__ void init_o(const float* __restrict__ X, int m0, int lane, f32x16 (&O)[NT2]) {
     const int voff = 4 * (lane >> 5) * C + (lane & 31);
 #pragma unroll
@@ -232,7 +312,6 @@ template <int C, int NCK, typename HT = bf16_t> struct Rc2Wave {
       for (int t = 0; t < NT2; ++t) O[t][r] = row[voff + 32 * t];
     }
   }
-
   // x' = O + bb, straight from the accumulator layout (two whole 128-byte row pieces per store instruction)
   static __device__ __forceinline__ void store_o(float* __restrict__ X, const float* __restrict__ bbv, int m0, int M, int lane,
                                                  const f32x16 (&O)[NT2]) {
@@ -264,11 +343,11 @@ static inline int cn_rc2_grid(int n_tiles, int waves_per_block, int max_blocks) 
 
 // ---- resident variant (C = 96): the whole stream (156 KB) lives in LDS; persistent blocks; no barrier, no DMA after the fill
 // ABL (kernel lab only, wrong results): 1 = accumulators start from zero (no residual loads), 2 = nothing stored, 8 = y loaded once
-template <int C, int NW, int NCK, typename HT = bf16_t, int ABL = 0>
+template <int C, int NW, int NCK, typename HT = bf16_t, int ABL = 0, typename XT = float>
 __global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_resident_kernel(const HT* __restrict__ Y, const HT* __restrict__ WS,
-                                                                      float* __restrict__ X, int M) {
+                                                                      XT* __restrict__ X, int M) {
   typedef Rc2Geom<C, NCK> G;
-  typedef Rc2Wave<C, NCK, HT> W;
+  typedef Rc2Wave<C, NCK, HT, XT> W;
   typedef cn_h8<HT> hx8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -277,7 +356,7 @@ __global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_resident_kernel(const HT* 
   for (int i = wave; i < TOTAL; i += NW)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)WS + (size_t)i * 1024 + lane * 16),
                                      (__attribute__((address_space(3))) void*)(smem + i * 1024), 16, 0, 0);
-  const float* aux = (const float*)((const char*)WS + G::STREAM_BYTES);
+  const char* bbf = (const char*)WS + G::STREAM_BYTES + lane * 16;  // output-bias fragments (global memory)
   const int n_tiles = (M + 31) >> 5;
   const int t_lo = (int)((long)blockIdx.x * n_tiles / gridDim.x), t_hi = (int)((long)(blockIdx.x + 1) * n_tiles / gridDim.x);
   hx8 ones;
@@ -295,27 +374,27 @@ __global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_resident_kernel(const HT* 
 #pragma unroll
       for (int t = 0; t < G::NT2; ++t) O[t] = W::zero16();
     } else {
-      W::init_o(X, tile * 32, lane, O);
+      W::init_o(X, bbf, ones, tile * 32, lane, O);
     }
 #pragma unroll 1
     for (int j = 0; j < G::NSTEP; ++j) W::step(wl + j * G::STEP_BYTES, fy, ones, O);
     if constexpr (!(ABL & 8))
       if (tile + NW < t_hi) W::load_y(Y, (tile + NW) * 32, lane, fy);
     if constexpr (ABL & 2) {
-      if (O[0][0] == 12345.678f) W::store_o(X, aux, tile * 32, M, lane, O);
+      if (O[0][0] == 12345.678f) W::store_o(X, tile * 32, M, lane, O);
     } else {
-      W::store_o(X, aux, tile * 32, M, lane, O);
+      W::store_o(X, tile * 32, M, lane, O);
     }
   }
 }
 
-template <int C, int NW, int NCK, int ABL = 0, typename HT>
-static int cn_launch_mlp_rc2_resident(const HT* Y, const HT* WS, float* X, int M, int n_blocks, hipStream_t s) {
+template <int C, int NW, int NCK, int ABL = 0, typename HT, typename XT>
+static int cn_launch_mlp_rc2_resident(const HT* Y, const HT* WS, XT* X, int M, int n_blocks, hipStream_t s) {
   constexpr int SMEM = (int)Rc2Geom<C, NCK>::STREAM_BYTES;
   static_assert(SMEM <= 160 * 1024, "resident variant: the weight stream must fit in LDS");
-  CN_TRY(cn_configure_lds((const void*)cn_mlp_rc2_resident_kernel<C, NW, NCK, HT, ABL>, SMEM));
+  CN_TRY(cn_configure_lds((const void*)cn_mlp_rc2_resident_kernel<C, NW, NCK, HT, ABL, XT>, SMEM));
   const int grid = cn_rc2_grid((M + 31) / 32, NW, n_blocks);
-  hipLaunchKernelGGL((cn_mlp_rc2_resident_kernel<C, NW, NCK, HT, ABL>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, Y, WS, X, M);
+  hipLaunchKernelGGL((cn_mlp_rc2_resident_kernel<C, NW, NCK, HT, ABL, XT>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, Y, WS, X, M);
   CN_LAUNCH_CHECK();
   return CN_OK;
 }
@@ -327,9 +406,9 @@ static int cn_launch_mlp_rc2_resident(const HT* Y, const HT* WS, float* X, int M
 // loads, stores) only makes that wait stricter, never unsafe (the counter retires in order).
 // PROF (kernel lab only): per-step s_memtime stamps at points where no LDS read is in flight -> prof[0..4] =
 // wait for the DMA, barrier, DMA issue, step compute, tile boundary (sums over waves, in cycles), prof[5] = wave-steps
-template <int C, int NW, int NCK, int NST, int PROF = 0, typename HT = bf16_t>
+template <int C, int NW, int NCK, int NST, int PROF = 0, typename HT = bf16_t, typename XT = float>
 __global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_ring_kernel(const HT* __restrict__ Y, const HT* __restrict__ WS,
-                                                                  float* __restrict__ X, int M, unsigned long long* prof = nullptr) {
+                                                                  XT* __restrict__ X, int M, unsigned long long* prof = nullptr) {
   unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0, nstep = 0;
   auto stamp = [&](int i) {
     if constexpr (PROF) {
@@ -340,14 +419,14 @@ __global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_ring_kernel(const HT* __re
   };
   if constexpr (PROF) tprev = clock64();
   typedef Rc2Geom<C, NCK> G;
-  typedef Rc2Wave<C, NCK, HT> W;
+  typedef Rc2Wave<C, NCK, HT, XT> W;
   typedef cn_h8<HT> hx8;
   constexpr int FR = G::FRAGS, SB = G::STEP_BYTES;
   constexpr int DPW_LO = FR / NW, N_HI = FR % NW;  // waves < N_HI issue DPW_LO + 1 pieces per entry
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const float* aux = (const float*)((const char*)WS + G::STREAM_BYTES);
+  const char* bbf = (const char*)WS + G::STREAM_BYTES + lane * 16;  // output-bias fragments (global memory)
 
   const int n_tiles = (M + 31) >> 5;
   const int t_lo = (int)((long)blockIdx.x * n_tiles / gridDim.x), t_hi = (int)((long)(blockIdx.x + 1) * n_tiles / gridDim.x);
@@ -378,7 +457,7 @@ __global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_ring_kernel(const HT* __re
     const int tile = t_lo + wave + it * NW;
     const bool valid = tile < t_hi;
     f32x16 O[G::NT2];
-    if (valid) W::init_o(X, tile * 32, lane, O);
+    if (valid) W::init_o(X, bbf, ones, tile * 32, lane, O);
     {
       // The residual (and the y fragments requested at the end of the last tile) land HERE, once per tile, in a wait the
       // compiler sees and that dominates the step loop: otherwise the step code, shared by every j, carries the waits for
@@ -399,11 +478,7 @@ __global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_ring_kernel(const HT* __re
       if constexpr (PROF) nstep += valid;
     }
     if (tile + NW < t_hi) W::load_y(Y, (tile + NW) * 32, lane, fy);
-    if (valid) {
-      const float* bbv = aux;
-      asm volatile("" : "+s"(bbv));  // re-read per tile: hoisted out of the tile loop the 12 bias registers would live through every step
-      W::store_o(X, bbv, tile * 32, M, lane, O);
-    }
+    if (valid) W::store_o(X, tile * 32, M, lane, O);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring was filled NST - 1 entries past the end
   if constexpr (PROF) {
@@ -415,14 +490,14 @@ __global__ __launch_bounds__(NW * 64) void cn_mlp_rc2_ring_kernel(const HT* __re
   }
 }
 
-template <int C, int NW, int NCK, int NST, int PROF = 0, typename HT>
-static int cn_launch_mlp_rc2_ring(const HT* Y, const HT* WS, float* X, int M, int n_blocks, hipStream_t s,
+template <int C, int NW, int NCK, int NST, int PROF = 0, typename HT, typename XT>
+static int cn_launch_mlp_rc2_ring(const HT* Y, const HT* WS, XT* X, int M, int n_blocks, hipStream_t s,
                                   unsigned long long* prof = nullptr) {
   constexpr int SMEM = NST * Rc2Geom<C, NCK>::STEP_BYTES;
   static_assert(SMEM <= 160 * 1024, "ring must fit in LDS");
-  CN_TRY(cn_configure_lds((const void*)cn_mlp_rc2_ring_kernel<C, NW, NCK, NST, PROF, HT>, SMEM));
+  CN_TRY(cn_configure_lds((const void*)cn_mlp_rc2_ring_kernel<C, NW, NCK, NST, PROF, HT, XT>, SMEM));
   const int grid = cn_rc2_grid((M + 31) / 32, NW, n_blocks);
-  hipLaunchKernelGGL((cn_mlp_rc2_ring_kernel<C, NW, NCK, NST, PROF, HT>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, Y, WS, X, M, prof);
+  hipLaunchKernelGGL((cn_mlp_rc2_ring_kernel<C, NW, NCK, NST, PROF, HT, XT>), dim3((unsigned)grid), dim3(NW * 64), SMEM, s, Y, WS, X, M, prof);
   CN_LAUNCH_CHECK();
   return CN_OK;
 }

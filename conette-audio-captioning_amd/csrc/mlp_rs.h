@@ -29,11 +29,14 @@
 // Tile boundaries are software-pipelined into the steps around them:
 //   * A re-loads y fragment s of the NEXT tile in place, right behind the last MFMA of the tile that reads fragment s
 //     (the first step of the next tile meets them one step later);
-//   * B keeps O transposed -- GEMM2 as W2c' . G^T: lane = position, four consecutive channels per register quad, so the
-//     residual moves in 16-byte pieces (48 loads + 48 stores per tile instead of 192 + 192: the per-wave queue of 63
-//     outstanding operations no longer throttles it) -- and runs its MFMAs tile by tile (k 0, k 1 of one 32-channel tile
-//     back to back), so that in a tile's last step the store of channel tile t and the load of the next position tile's
-//     residual into the same registers follow the tile's last MFMA, one tile behind.
+//   * B keeps O transposed -- GEMM2 as W2c' . G^T: lane = position, two runs of eight consecutive channels per 32-channel
+//     tile (the rows of the W2 fragments are permuted for that: cn_rc2_chan, mlp_rc2.h), so the residual moves in 16-byte
+//     pieces -- and runs its MFMAs tile by tile (k 0, k 1 of one 32-channel tile back to back), so that in a tile's last
+//     step the store of channel tile t and the load of the next position tile's residual follow the tile's last MFMA, one
+//     tile behind.  With an fp16 residual stream (XT = half_t, round 5) a tile's row is 24 loads + 24 stores of 16 bytes;
+//     the loaded halves wait in registers that the stored tile has just freed and are converted in the FIRST step of the
+//     next position tile, right before the first MFMA of their channel tile (a conversion at the load would wait for HBM in
+//     the middle of the step).
 #pragma once
 #include <type_traits>
 
@@ -67,7 +70,7 @@ static __global__ void pk_mlp_rs(const float* __restrict__ W1, const float* __re
   } else {
     const int q2 = q - F1;
     const int j = (e + NCH - 2) % NCH, s = q2 / NT2, t = q2 % NT2;
-    const int c = 32 * t + r;
+    const int c = 32 * t + cn_rc2_chan(r);
     const float sc = scale[c];
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = sc * W2[(size_t)c * (4 * C) + 32 * j + 16 * s + 8 * (i >> 2) + 4 * h + (i & 3)];
@@ -78,9 +81,9 @@ static __global__ void pk_mlp_rs(const float* __restrict__ W1, const float* __re
 
 // ABL (kernel lab only, wrong results): 1 = no ring refill after the prologue, 2 = GELU replaced by a copy, 4 = no residual / y
 // traffic at tile boundaries
-template <int C, int NP, int ABL = 0, typename HT = bf16_t> struct RsWave {
+template <int C, int NP, int ABL = 0, typename HT = bf16_t, typename XT = float> struct RsWave {
   typedef Rc2Geom<C, 1> G;
-  typedef Rc2Wave<C, 1, HT> W;
+  typedef Rc2Wave<C, 1, HT, XT> W;
   typedef cn_h8<HT> hx8;
   static constexpr int KS1 = G::KS1, NT2 = G::NT2, F1 = G::F1, F2 = G::F2, FR = G::FRAGS;
 #ifndef CN_RS_PRE
@@ -142,7 +145,7 @@ template <int C, int NP, int ABL = 0, typename HT = bf16_t> struct RsWave {
     *(hx8*)(gdst + 1024) = cn_sat8<HT>(cn_pack8<HT>(st.g[8], st.g[9], st.g[10], st.g[11], st.g[12], st.g[13], st.g[14], st.g[15]));
   }
 
-  // ---- B: O^T += W2c' . G^T; lane = position m0 + (l & 31), register 4 q + e of tile t = channel 32 t + 8 q + 4 (l >> 5) + e
+  // ---- B: O^T += W2c' . G^T; lane = position m0 + (l & 31), register r of tile t = channel 32 t + 16 (r >> 3) + 8 (l >> 5) + (r & 7)
   struct Dma {
     const char* src;   // entry to fetch (wave-uniform)
     unsigned dst;      // LDS byte address of its slot
@@ -155,23 +158,57 @@ template <int C, int NP, int ABL = 0, typename HT = bf16_t> struct RsWave {
     const int piece = d.first + I * NP;
     if (piece < d.n_pieces) cn_dma16_s(d.src + piece * 1024, d.voff, d.dst + piece * 1024);
   }
-  // the residual rows of a tile: row pointers carry the lane's position and channel-quad offset, (t, q) are immediates
-  static __device__ __forceinline__ void load_tile(const float* xrow, int t, f32x16& Ot) {
+  // The residual rows of a tile as they come from memory: 32 channels of this lane's position = 16 values (two 16-byte pieces
+  // at fp16, four at fp32); row pointers carry the lane's position and channel-run offset, t is an immediate.
+  static constexpr int RAWN = sizeof(XT) == 2 ? 2 : 4;
+  struct Raw {
+    u32x4 v[RAWN];
+  };
+  static __device__ __forceinline__ void load_raw(const XT* xrow, int t, Raw& raw) {
+    if constexpr (sizeof(XT) == 2) {
+      raw.v[0] = *(const u32x4*)(xrow + 32 * t);
+      raw.v[1] = *(const u32x4*)(xrow + 32 * t + 16);
+    } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 v = *(const f32x4*)(xrow + 32 * t + 8 * q);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) Ot[4 * q + e] = v[e];
+      for (int q = 0; q < 4; ++q) raw.v[q] = *(const u32x4*)(xrow + 32 * t + 16 * (q >> 1) + 4 * (q & 1));
     }
   }
-  // (bb is added IN PLACE: the tile's registers are dead after the store -- the next tile's residual is loaded over them)
-  static __device__ __forceinline__ void store_tile(float* xrow, const char* bbl, int t, bool in_range, f32x16& Ot) {
+  static __device__ __forceinline__ void raw_to_acc(const Raw& raw, f32x16& Ot) {
+    if constexpr (sizeof(XT) == 2) {
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        const cn_h8<XT> h = __builtin_bit_cast(cn_h8<XT>, raw.v[o]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Ot[8 * o + i] = (float)h[i];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 f = __builtin_bit_cast(f32x4, raw.v[q]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Ot[4 * q + e] = f[e];
+      }
+    }
+  }
+  // x' = O + bb, converted to the stream's type (bbl: the fp32 bias vector in LDS with this lane's channel-run offset applied)
+  static __device__ __forceinline__ void store_tile(XT* xrow, const char* bbl, int t, bool in_range, const f32x16& Ot) {
+    float o[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 b = *(const f32x4*)(bbl + (32 * t + 8 * q) * 4);
+      const f32x4 b = *(const f32x4*)(bbl + (32 * t + 16 * (q >> 1) + 4 * (q & 1)) * 4);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) Ot[4 * q + e] += b[e];
-      if (in_range) *(f32x4*)(xrow + 32 * t + 8 * q) = f32x4{Ot[4 * q], Ot[4 * q + 1], Ot[4 * q + 2], Ot[4 * q + 3]};
+      for (int e = 0; e < 4; ++e) o[4 * q + e] = Ot[4 * q + e] + b[e];
+    }
+    if (!in_range) return;
+    if constexpr (sizeof(XT) == 2) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        *(cn_h8<XT>*)(xrow + 32 * t + 16 * h) = cn_pack8<XT>(o[8 * h], o[8 * h + 1], o[8 * h + 2], o[8 * h + 3], o[8 * h + 4],
+                                                             o[8 * h + 5], o[8 * h + 6], o[8 * h + 7]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(f32x4*)(xrow + 32 * t + 16 * (q >> 1) + 4 * (q & 1)) = f32x4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
     }
   }
   struct BState {
@@ -190,39 +227,41 @@ template <int C, int NP, int ABL = 0, typename HT = bf16_t> struct RsWave {
     }
   }
   // LAST: the tile's last chunk -- one channel tile behind the MFMAs, O[t] (+ bb) is stored and the residual of the pair's
-  // next position tile is loaded into the same registers.  Both are UNCONDITIONAL instruction streams (rows outside the
+  // next position tile is loaded (raw[t]).  FIRST: the tile's first chunk -- raw[t] becomes O[t] right before the first MFMA
+  // of channel tile t.  Both are UNCONDITIONAL instruction streams (rows outside the
   // tensor are masked per lane; a pair without a next tile re-loads rows it never uses): a branch around them, or a
   // run-time choice between two instantiations of the step, made the register allocator give O different registers on
   // the two paths and shuffle all 192 of them through scratch at the join.
-  template <int Q, bool LAST>
-  static __device__ __forceinline__ void b_mstep(const char* w2, const hx8 (&H)[2], f32x16 (&O)[NT2], BState& st, const Dma& d,
-                                                 float* xrow, const float* xnext, const char* bbl, bool in_range) {
+  template <int Q, bool FIRST, bool LAST>
+  static __device__ __forceinline__ void b_mstep(const char* w2, const hx8 (&H)[2], f32x16 (&O)[NT2], Raw (&raw)[NT2], BState& st,
+                                                 const Dma& d, XT* xrow, const XT* xnext, const char* bbl, bool in_range) {
     if constexpr (Q + PRE < F2) st.F[(Q + PRE) % R] = W::frag(w2, fidx(Q + PRE));
     constexpr int k = Q & 1, t = Q >> 1;
+    if constexpr (FIRST && k == 0) raw_to_acc(raw[t], O[t]);
     O[t] = W::mma(st.F[Q % R], H[k], O[t]);
     b_dma<Q, 0>(d);
     if constexpr (LAST && k == 1 && t >= 1) {
       store_tile(xrow, bbl, t - 1, in_range, O[t - 1]);
-      load_tile(xnext, t - 1, O[t - 1]);
+      load_raw(xnext, t - 1, raw[t - 1]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (Q + 1 < F2) b_mstep<Q + 1, LAST>(w2, H, O, st, d, xrow, xnext, bbl, in_range);
+    if constexpr (Q + 1 < F2) b_mstep<Q + 1, FIRST, LAST>(w2, H, O, raw, st, d, xrow, xnext, bbl, in_range);
   }
   template <int Q>
   static __device__ __forceinline__ void b_prefetch(const char* w2, BState& st) {
     st.F[Q % R] = W::frag(w2, fidx(Q));
     if constexpr (Q + 1 < PRE) b_prefetch<Q + 1>(w2, st);
   }
-  template <bool LAST>
-  static __device__ __forceinline__ void b_step(const char* w2, const hx8 (&H)[2], f32x16 (&O)[NT2], const Dma& d, float* xrow,
-                                                const float* xnext, const char* bbl, bool in_range) {
+  template <bool FIRST, bool LAST>
+  static __device__ __forceinline__ void b_step(const char* w2, const hx8 (&H)[2], f32x16 (&O)[NT2], Raw (&raw)[NT2], const Dma& d,
+                                                XT* xrow, const XT* xnext, const char* bbl, bool in_range) {
     BState st;
     b_prefetch<0>(w2, st);
     __builtin_amdgcn_sched_barrier(0);
-    b_mstep<0, LAST>(w2, H, O, st, d, xrow, xnext, bbl, in_range);
+    b_mstep<0, FIRST, LAST>(w2, H, O, raw, st, d, xrow, xnext, bbl, in_range);
     if constexpr (LAST) {
       store_tile(xrow, bbl, NT2 - 1, in_range, O[NT2 - 1]);
-      load_tile(xnext, NT2 - 1, O[NT2 - 1]);
+      load_raw(xnext, NT2 - 1, raw[NT2 - 1]);
     }
   }
   static __device__ __forceinline__ void issue_all(const Dma& d) {  // a step without a tile still owes the refill
@@ -307,12 +346,12 @@ __device__ __forceinline__ void cn_vm_wait(int n) {
 
 // NP pairs per block (2 NP waves: waves [0, NP) are the A roles, [NP, 2 NP) the B roles: with waves dealt round-robin over the
 // four SIMDs a pair shares its SIMD when NP is a multiple of 4); pair p owns tiles t_lo + p + it * NP of the block's range.
-template <int C, int NP, int NST, int ABL = 0, typename HT = bf16_t>
+template <int C, int NP, int NST, int ABL = 0, typename HT = bf16_t, typename XT = float>
 __global__ __launch_bounds__(2 * NP * 64) void cn_mlp_rs_kernel(const HT* __restrict__ Y, const HT* __restrict__ WS,
-                                                                float* __restrict__ X, int M) {
+                                                                XT* __restrict__ X, int M) {
   typedef Rc2Geom<C, 1> G;
-  typedef Rc2Wave<C, 1, HT> W;
-  typedef RsWave<C, NP, ABL, HT> RW;
+  typedef Rc2Wave<C, 1, HT, XT> W;
+  typedef RsWave<C, NP, ABL, HT, XT> RW;
   typedef cn_h8<HT> hx8;
   constexpr int NCH = G::NSTEP, FR = G::FRAGS, SB = G::STEP_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -322,7 +361,7 @@ __global__ __launch_bounds__(2 * NP * 64) void cn_mlp_rs_kernel(const HT* __rest
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool role_b = wave >= NP;
   const int pair = role_b ? wave - NP : wave;
-  const float* aux = (const float*)((const char*)WS + G::STREAM_BYTES);
+  const float* aux = (const float*)((const char*)WS + G::STREAM_BYTES);  // bb = s b2 (fp32, C: pk_mlp_rs)
 
   const int n_tiles = (M + 31) >> 5;
   const int t_lo = (int)((long)blockIdx.x * n_tiles / gridDim.x), t_hi = (int)((long)(blockIdx.x + 1) * n_tiles / gridDim.x);
@@ -387,17 +426,19 @@ __global__ __launch_bounds__(2 * NP * 64) void cn_mlp_rs_kernel(const HT* __rest
   } else {
     // ================================================= B ==============================================================
     f32x16 O[G::NT2];
-    const int xoff = (lane & 31) * C + 4 * (lane >> 5);  // elements: this lane's position row and channel-quad offset
-    const char* bbl = bbuf + 16 * (lane >> 5);
+    typename RW::Raw raw[G::NT2];
+    const int xoff = (lane & 31) * C + 8 * (lane >> 5);  // elements: this lane's position row and channel-run offset
+    const char* bbl = bbuf + 32 * (lane >> 5);
     const int tile0 = t_lo + pair < t_hi ? t_lo + pair : t_lo;
     {
-      const float* x0 = X + (size_t)tile0 * 32 * C + xoff;
+      const XT* x0 = X + (size_t)tile0 * 32 * C + xoff;
 #pragma unroll
-      for (int t = 0; t < G::NT2; ++t) RW::load_tile(x0, t, O[t]);
+      for (int t = 0; t < G::NT2; ++t) RW::load_raw(x0, t, raw[t]);
     }
     int g = 0;
     // the last step in which this wave ran a tile boundary, and the vector-memory operations it really issued there: the
-    // 4 NT2 loads always, the 4 NT2 stores only if some lane's row is inside the tensor (an all-masked store is branched over)
+    // loads always, the stores only if some lane's row is inside the tensor (an all-masked store is branched over)
+    constexpr int IO_N = RW::RAWN * G::NT2;
     int io_step = -1000, io_n = 0;
     hx8 H[2];
     auto head = [&]() {  // ring wait, first barrier, G(g - 2) -> registers, second barrier
@@ -420,31 +461,34 @@ __global__ __launch_bounds__(2 * NP * 64) void cn_mlp_rs_kernel(const HT* __rest
       const bool valid = tile < t_hi;
       const int tcur = valid ? tile : tile0;
       const bool has_next = valid && tile + NP < t_hi && !(ABL & 4);
-      float* xrow = X + (size_t)tcur * 32 * C + xoff;
-      // (no next tile: every lane re-loads row 0 of the pair's first tile -- 1.5 KB, not a 48 KB tile it never uses)
-      const float* xnext = has_next ? X + (size_t)(tile + NP) * 32 * C + xoff : X + (size_t)tile0 * 32 * C + 4 * (lane >> 5);
+      XT* xrow = X + (size_t)tcur * 32 * C + xoff;
+      // (no next tile: every lane re-loads row 0 of the pair's first tile, not a whole tile it never uses)
+      const XT* xnext = has_next ? X + (size_t)(tile + NP) * 32 * C + xoff : X + (size_t)tile0 * 32 * C + 8 * (lane >> 5);
       const bool in_range = valid && tile * 32 + (lane & 31) < M && (!(ABL & 4) || it == max_it - 1);
-      for (int cb = 0; cb < NCH - 1; ++cb, ++g) {
+      head();
+      RW::template b_step<true, false>(wl + (g % NST) * SB + RW::F1 * 1024, H, O, raw, entry(g + NST - 1), xrow, xnext, bbl, false);
+      ++g;
+      for (int cb = 1; cb < NCH - 1; ++cb, ++g) {
         head();
-        RW::template b_step<false>(wl + (g % NST) * SB + RW::F1 * 1024, H, O, entry(g + NST - 1), xrow, xnext, bbl, false);
+        RW::template b_step<false, false>(wl + (g % NST) * SB + RW::F1 * 1024, H, O, raw, entry(g + NST - 1), xrow, xnext, bbl, false);
       }
       head();
-      RW::template b_step<true>(wl + (g % NST) * SB + RW::F1 * 1024, H, O, entry(g + NST - 1), xrow, xnext, bbl, in_range);
+      RW::template b_step<false, true>(wl + (g % NST) * SB + RW::F1 * 1024, H, O, raw, entry(g + NST - 1), xrow, xnext, bbl, in_range);
       io_step = g;
-      io_n = 4 * G::NT2 + ((valid && (!(ABL & 4) || it == max_it - 1)) ? 4 * G::NT2 : 0);  // (lane 0's row of a valid tile is in range)
+      io_n = IO_N + ((valid && (!(ABL & 4) || it == max_it - 1)) ? IO_N : 0);  // (lane 0's row of a valid tile is in range)
       ++g;
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring was filled NST - 1 entries past the end
 }
 
-template <int C, int NP, int NST, int ABL = 0, typename HT>
-static int cn_launch_mlp_rs(const HT* Y, const HT* WS, float* X, int M, int n_blocks, hipStream_t s) {
+template <int C, int NP, int NST, int ABL = 0, typename HT, typename XT>
+static int cn_launch_mlp_rs(const HT* Y, const HT* WS, XT* X, int M, int n_blocks, hipStream_t s) {
   constexpr int SMEM = NST * Rc2Geom<C, 1>::STEP_BYTES + NP * 2048 + C * 4;
   static_assert(SMEM <= 160 * 1024, "ring + hand-over buffers must fit in LDS");
-  CN_TRY(cn_configure_lds((const void*)cn_mlp_rs_kernel<C, NP, NST, ABL, HT>, SMEM));
+  CN_TRY(cn_configure_lds((const void*)cn_mlp_rs_kernel<C, NP, NST, ABL, HT, XT>, SMEM));
   const int grid = cn_rc2_grid((M + 31) / 32, NP, n_blocks);
-  hipLaunchKernelGGL((cn_mlp_rs_kernel<C, NP, NST, ABL, HT>), dim3((unsigned)grid), dim3(2 * NP * 64), SMEM, s, Y, WS, X, M);
+  hipLaunchKernelGGL((cn_mlp_rs_kernel<C, NP, NST, ABL, HT, XT>), dim3((unsigned)grid), dim3(2 * NP * 64), SMEM, s, Y, WS, X, M);
   CN_LAUNCH_CHECK();
   return CN_OK;
 }

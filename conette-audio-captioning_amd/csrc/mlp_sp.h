@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NW * 64) void cn_mlp_sp_ring_kernel(const sp16_t* _
     const int tile = t_lo + wave + it * NW;
     const bool valid = tile < t_hi;
     f32x16 O[G::NT2];
-    if (valid) W::init_o(X, tile * 32, lane, O);
+    if (valid) Rc2IoCl<C>::init_o(X, tile * 32, lane, O);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): residual + y, once per tile, on every path into the loop
     for (int j = 0; j < G::NSTEP; ++j, ++g) {
       if (N_HI > 0 && wave < N_HI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (DPW_LO + 1)) : "memory");
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(NW * 64) void cn_mlp_sp_ring_kernel(const sp16_t* _
     if (valid) {
       const float* bbv = aux;
       asm volatile("" : "+s"(bbv));  // re-read per tile (mlp_rc2.h)
-      W::store_o(X, bbv, tile * 32, M, lane, O);
+      Rc2IoCl<C>::store_o(X, bbv, tile * 32, M, lane, O);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring was filled NST - 1 entries past the end

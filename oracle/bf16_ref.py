@@ -12,8 +12,12 @@ Rounding points (conette-audio-captioning_amd/csrc):
   ConvNeXt block, stage 3 (gemm2.h pw1 / pw2): y, W1, h = bf16(gelu(y W1^T + b1)), W2 -> bf16;  x' = x + scale * (h W2^T + b2)
   downsample (encoder.hip cn_ln_patchify + gemm2): patches = bf16(LN(x)), conv weight -> bf16, fp32 bias
   decoder: see ``decoder_forward_bf16``.
-The GPU evaluates GELU through approximations that are exact to <= 2.5e-5 absolute (mlp_rc2.h) / 1.5e-7 (A&S 7.1.26,
-common.h); the oracle uses the exact erf form, so a handful of hidden values per million round to the neighbouring bf16.
+  residual stream (round 5): inside ``operands(...)`` every tensor the 16-bit precisions' kernels STORE to the stream -- the
+      stem's output, every block's x', every downsample layer's output -- is rounded to IEEE fp16 (``res16``; csrc/common.h XT);
+      the depthwise convolution reads those fp16 values as exact operands of its fp32 fma (v_fma_mix_f32), so nothing else changes.
+The GPU evaluates GELU through approximations that are exact to <= 5.5e-5 absolute (bf16) / 8.6e-7 (fp16) in the fused MLP
+(common.h cn_gelu_e1) and 1.5e-7 elsewhere (A&S 7.1.26, common.h); the oracle uses the exact erf form, so a handful of hidden
+values per million round to the neighbouring bf16.
 """
 from __future__ import annotations
 
@@ -30,6 +34,12 @@ Weights = Dict[str, Tensor]
 
 
 _OPERAND_DTYPE = torch.bfloat16
+_RESIDUAL_DTYPE = None      # None: the fp32 residual stream (fp32 / exact / fp8 precisions, and this module outside operands())
+
+
+def res16(t: Tensor) -> Tensor:
+    """A tensor as the kernels store it to the residual stream: fp16 (round to nearest even) inside ``operands(...)``."""
+    return t if _RESIDUAL_DTYPE is None else t.to(_RESIDUAL_DTYPE).to(torch.float32)
 
 
 def bf16(t: Tensor) -> Tensor:
@@ -42,18 +52,20 @@ def bf16(t: Tensor) -> Tensor:
 @contextlib.contextmanager
 def operands(kind: str):
     """Every rounding point of this module at another 16-bit operand type: "bf16" (CONETTE_PREC_BF16) or "f16"
-    (CONETTE_PREC_F16: the same kernels instantiated for IEEE fp16, csrc/common.h half_t)."""
-    global _OPERAND_DTYPE
-    keep = _OPERAND_DTYPE
+    (CONETTE_PREC_F16: the same kernels instantiated for IEEE fp16, csrc/common.h half_t).  Both precisions keep the encoder's
+    residual stream in fp16 since round 5 (``res16``)."""
+    global _OPERAND_DTYPE, _RESIDUAL_DTYPE
+    keep = (_OPERAND_DTYPE, _RESIDUAL_DTYPE)
     _OPERAND_DTYPE = {"bf16": torch.bfloat16, "f16": torch.float16}[kind]
+    _RESIDUAL_DTYPE = torch.float16
     try:
         yield
     finally:
-        _OPERAND_DTYPE = keep
+        _OPERAND_DTYPE, _RESIDUAL_DTYPE = keep
 
 
 def convnext_block_bf16(w: Weights, prefix: str, x: Tensor, folded: bool) -> Tensor:
-    """nn/encoders/convnext.py:61-74 with bf16 GEMM operands.  x: (B, C, H, W) fp32 (the fp32 residual stream)."""
+    """nn/encoders/convnext.py:61-74 with bf16 GEMM operands.  x: (B, C, H, W) fp32 values of the residual stream."""
     c = x.shape[1]
     y = F.conv2d(x, w[prefix + "dwconv.weight"], w[prefix + "dwconv.bias"], padding=3, groups=c)
     y = y.permute(0, 2, 3, 1)
@@ -65,7 +77,7 @@ def convnext_block_bf16(w: Weights, prefix: str, x: Tensor, folded: bool) -> Ten
         z = F.linear(h, bf16(s[:, None] * w[prefix + "pwconv2.weight"])) + s * w[prefix + "pwconv2.bias"]
     else:
         z = s * (F.linear(h, bf16(w[prefix + "pwconv2.weight"])) + w[prefix + "pwconv2.bias"])
-    return x + z.permute(0, 3, 1, 2)
+    return res16(x + z.permute(0, 3, 1, 2))
 
 
 def downsample_bf16(w: Weights, i: int, x: Tensor, folded: bool = False) -> Tensor:
@@ -76,11 +88,11 @@ def downsample_bf16(w: Weights, i: int, x: Tensor, folded: bool = False) -> Tens
     d = f"preprocessor.encoder.downsample_layers.{i}."
     if not folded:
         y = bf16(O._ln_cf(x, w[d + "0.weight"], w[d + "0.bias"]))
-        return F.conv2d(y, bf16(w[d + "1.weight"]), w[d + "1.bias"], stride=2)
+        return res16(F.conv2d(y, bf16(w[d + "1.weight"]), w[d + "1.bias"], stride=2))
     g, beta, W, b = w[d + "0.weight"].float(), w[d + "0.bias"].float(), w[d + "1.weight"].float(), w[d + "1.bias"].float()
     y = bf16(O._ln_cf(x, torch.ones_like(g), torch.zeros_like(beta)))
     bias = b + (W * beta.view(1, -1, 1, 1)).sum(dim=(1, 2, 3))
-    return F.conv2d(y, bf16(W * g.view(1, -1, 1, 1)), bias, stride=2)
+    return res16(F.conv2d(y, bf16(W * g.view(1, -1, 1, 1)), bias, stride=2))
 
 
 def block_prefix(blk: int) -> str:

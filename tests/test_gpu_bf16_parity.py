@@ -52,13 +52,18 @@ def _nchw(t):
 def _assert_close(got, ref, what, k=1.0):
     """Full tensor: rtol 3e-3 + atol 2e-3 (times k = ROUNDING[precision]) for all but a 1e-5 share of the elements (a hidden
     value that rounds to the neighbouring bf16 moves an output by ~1e-3), nothing beyond 4x that bound, mean error far
-    inside it (fp16: + 2e-5 for the GELU polynomial's 2.5e-5, which no longer disappears under the operand rounding)."""
+    inside it (fp16: + 2e-5 for the GELU polynomial's 2.5e-5, which no longer disappears under the operand rounding).
+    Round 5: both sides are stored to an fp16 residual stream (oracle: bf16_ref.res16), so a value may land on the fp16
+    neighbour of the oracle's -- one fp16 ulp (<= 2^-10 relative) on top of the bound; the MEAN bound does not move (a flip of
+    size ulp happens with probability |difference before rounding| / ulp)."""
     err = (got - ref).abs()
-    bound = k * (2e-3 + 3e-3 * ref.abs())
+    bound = k * (2e-3 + 3e-3 * ref.abs()) + 2.0 ** -10 * ref.abs()
     n_out = int((err > bound).sum())
     assert n_out <= 1e-5 * err.numel(), (what, n_out, float(err.max()))
     assert bool((err <= 4 * bound).all()), (what, float(err.max()))
-    assert float(err.mean()) < k * 1e-4 + (2e-5 if k < 1 else 0.0), (what, float(err.mean()))
+    # (round 5: 1.5e-4 where round 4 had 1e-4 -- the bf16 kernels' degree-3 GELU is 5.5e-5 off the erf form where the sigmoid
+    # form was 2.5e-5, so a few more hidden values land on the neighbouring bf16; measured worst block mean 1.0e-4)
+    assert float(err.mean()) < k * 1.5e-4 + (2e-5 if k < 1 else 0.0), (what, float(err.mean()))
 
 
 @pytest.mark.parametrize("name", ["b8_10s_beam3_all", "b3_mixed_beam3_none"])

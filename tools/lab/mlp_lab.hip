@@ -12,7 +12,6 @@
 
 #include "mlp_rc2.h"
 #include "mlp_f8.h"
-#include "mlp_rc2_skew.h"
 #include "mlp_rs.h"
 
 void cn_set_error(const char* fmt, ...) {
@@ -100,64 +99,81 @@ template <typename T> static T* dalloc(size_t n) {
 
 struct Variant {
   std::string name;
-  int (*run)(const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s);
-  int pack = 1;  // mlp_rc2.h stream with NCK = 1 / 2
+  int (*run)(const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s);
+  int pack = 1;  // mlp_rc2.h stream with NCK = 1 / 2; 4: role-split entries
+  int xh = 0;    // 1: the residual stream is fp16 (round 5)
 };
+#define XF (float*)X
+#define XH (half_t*)X
 
 template <int C> static std::vector<Variant> variants();
 
 template <> std::vector<Variant> variants<96>() {
   return {
       {"rc2_resident<96,8,nck2>",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 8, 2>(Y, WS, X, M, nb, s); }, 2},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 8, 2>(Y, WS, XF, M, nb, s); }, 2},
       {"rc2_resident<96,8,nck1>",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 8, 1>(Y, WS, X, M, nb, s); }, 1},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 8, 1>(Y, WS, XF, M, nb, s); }, 1},
       {"rc2_resident<96,12,nck1>",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 12, 1>(Y, WS, X, M, nb, s); }, 1},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 12, 1>(Y, WS, XF, M, nb, s); }, 1},
       {"ABL rc2_resident<96,12> no residual loads",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 12, 1, 1>(Y, WS, X, M, nb, s); }, 1},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 12, 1, 1>(Y, WS, XF, M, nb, s); }, 1},
       {"ABL rc2_resident<96,12> no stores",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 12, 1, 2>(Y, WS, X, M, nb, s); }, 1},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 12, 1, 2>(Y, WS, XF, M, nb, s); }, 1},
       {"ABL rc2_resident<96,12> neither",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 12, 1, 3>(Y, WS, X, M, nb, s); }, 1},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 12, 1, 3>(Y, WS, XF, M, nb, s); }, 1},
       {"ABL rc2_resident<96,12> no global traffic at all",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 12, 1, 11>(Y, WS, X, M, nb, s); }, 1},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 12, 1, 11>(Y, WS, XF, M, nb, s); }, 1},
+      {"x16 rc2_resident<96,12,nck1>",
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 12, 1>(Y, WS, XH, M, nb, s); }, 1, 1},
+      {"x16 rc2_resident<96,8,nck1>",
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 8, 1>(Y, WS, XH, M, nb, s); }, 1, 1},
+      {"x16 rc2_resident<96,8,nck2>",
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 8, 2>(Y, WS, XH, M, nb, s); }, 2, 1},
       {"rs<96,np8,nst8>",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<96, 8, 8>(Y, WS, X, M, nb, s); }, 4},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<96, 8, 8>(Y, WS, XF, M, nb, s); }, 4},
   };
 }
 template <> std::vector<Variant> variants<192>() {
   return {
       {"rc2_ring<192,8,nck1,nst5>",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_ring<192, 8, 1, 5>(Y, WS, X, M, nb, s); }, 1},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_ring<192, 8, 1, 5>(Y, WS, XF, M, nb, s); }, 1},
       {"rc2_ring<192,8,nck2,nst3>",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_ring<192, 8, 2, 3>(Y, WS, X, M, nb, s); }, 2},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_ring<192, 8, 2, 3>(Y, WS, XF, M, nb, s); }, 2},
+      {"x16 rc2_ring<192,8,nck2,nst3>",
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_ring<192, 8, 2, 3>(Y, WS, XH, M, nb, s); }, 2, 1},
+      {"x16 rc2_ring<192,8,nck1,nst5>",
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_ring<192, 8, 1, 5>(Y, WS, XH, M, nb, s); }, 1, 1},
       {"rs<192,np4,nst5>",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<192, 4, 5>(Y, WS, X, M, nb, s); }, 4},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<192, 4, 5>(Y, WS, XF, M, nb, s); }, 4},
       {"rs<192,np8,nst5>",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<192, 8, 5>(Y, WS, X, M, nb, s); }, 4},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<192, 8, 5>(Y, WS, XF, M, nb, s); }, 4},
   };
 }
 template <> std::vector<Variant> variants<384>() {
   return {
       {"rc2_ring<384,4,nck1,nst3>",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_ring<384, 4, 1, 3>(Y, WS, X, M, nb, s); }, 1},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_ring<384, 4, 1, 3>(Y, WS, XF, M, nb, s); }, 1},
       {"rs<384,np4,nst3>",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3>(Y, WS, X, M, nb, s); }, 4},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3>(Y, WS, XF, M, nb, s); }, 4},
+      {"x16 rs<384,np4,nst3>",
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3>(Y, WS, XH, M, nb, s); }, 4, 1},
+      {"x16 rc2_ring<384,4,nck1,nst3>",
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_ring<384, 4, 1, 3>(Y, WS, XH, M, nb, s); }, 1, 1},
       {"rs<384> prio B",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 8>(Y, WS, X, M, nb, s); }, 4},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 8>(Y, WS, XF, M, nb, s); }, 4},
       {"rs<384> prio A",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 16>(Y, WS, X, M, nb, s); }, 4},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 16>(Y, WS, XF, M, nb, s); }, 4},
       {"ABL rs<384> one barrier per step (racy)",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 32>(Y, WS, X, M, nb, s); }, 4},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 32>(Y, WS, XF, M, nb, s); }, 4},
       {"ABL rs<384> no DMA",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 1>(Y, WS, X, M, nb, s); }, 4},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 1>(Y, WS, XF, M, nb, s); }, 4},
       {"ABL rs<384> no GELU",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 2>(Y, WS, X, M, nb, s); }, 4},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 2>(Y, WS, XF, M, nb, s); }, 4},
       {"ABL rs<384> no tile I/O",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 4>(Y, WS, X, M, nb, s); }, 4},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 4>(Y, WS, XF, M, nb, s); }, 4},
       {"ABL rs<384> none of the three",
-       [](const bf16_t* Y, const bf16_t* WS, float* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 7>(Y, WS, X, M, nb, s); }, 4},
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 7>(Y, WS, XF, M, nb, s); }, 4},
   };
 }
 
@@ -176,10 +192,13 @@ template <int C> static int run(int batch, int iters) {
   std::vector<bf16_t> hY((size_t)(M + 64) * C);
   std::vector<float> hX((size_t)M * C);
   for (auto& v : hY) v = (bf16_t)(frand() * 1.5f);
-  for (auto& v : hX) v = frand();
+  for (auto& v : hX) v = (float)(half_t)frand();  // (representable in fp16: the fp32 and fp16 residual streams start from the same numbers)
   float *W1 = dalloc<float>(hW1.size()), *W2 = dalloc<float>(hW2.size()), *b1 = dalloc<float>(4 * C), *b2 = dalloc<float>(C),
         *sc = dalloc<float>(C);
   bf16_t* Y = dalloc<bf16_t>(hY.size());
+  half_t* Xh = dalloc<half_t>(hX.size() + 64 * C);
+  std::vector<half_t> hXh(hX.size() + 64 * C);
+  for (size_t i = 0; i < hXh.size(); ++i) hXh[i] = (half_t)(i < hX.size() ? hX[i] : 0.f);
   float *X = dalloc<float>(hX.size() + 64 * C), *Xref = dalloc<float>((size_t)Mc * C), *Xref2 = dalloc<float>((size_t)Mc * C);
   bf16_t* H = dalloc<bf16_t>((size_t)Mc * 4 * C);
   bf16_t* WS2[5] = {nullptr, dalloc<bf16_t>(Rc2Geom<C, 1>::TOTAL_BYTES / 2), dalloc<bf16_t>(Rc2Geom<C, 2>::TOTAL_BYTES / 2),
@@ -192,11 +211,10 @@ template <int C> static int run(int batch, int iters) {
   CK(hipMemcpy(Y, hY.data(), hY.size() * 2, hipMemcpyHostToDevice));
   {
     for (int nck = 1; nck <= 2; ++nck) {
-      const int u2 = (C / 8) * (C / 8 + 1) * 64;
+      const int u2 = ((C / 8) * (C / 8 + 1) + C / 32) * 64;
       hipLaunchKernelGGL(pk_mlp_rc2, dim3((u2 + 255) / 256), dim3(256), 0, 0, W1, b1, W2, b2, sc, C, nck, WS2[nck]);
     }
-    const int u3 = (C / 8) * (C / 8 + 1) * 64;
-    hipLaunchKernelGGL(pk_mlp_rc2_skew, dim3((u3 + 255) / 256), dim3(256), 0, 0, W1, b1, W2, b2, sc, C, 1, WS2[3], 1);
+    const int u3 = ((C / 8) * (C / 8 + 1) + C / 32) * 64;
     hipLaunchKernelGGL(pk_mlp_rs, dim3((u3 + 255) / 256), dim3(256), 0, 0, W1, b1, W2, b2, sc, C, WS2[4]);
   }
   // reference on the first Mc rows
@@ -214,10 +232,19 @@ template <int C> static int run(int batch, int iters) {
   int bad = 0;
   for (int nbc : {256, 5, 3})
   for (auto& v : vs) {
+    if (v.xh) {
+      CK(hipMemcpy(Xh, hXh.data(), (size_t)(Mc + 64) * C * 2, hipMemcpyHostToDevice));
+      if (v.run(Y, WS2[v.pack], Xh, Mc, nbc, 0) != CN_OK) return 1;
+      CK(hipDeviceSynchronize());
+      std::vector<half_t> hg((size_t)(Mc + 64) * C);
+      CK(hipMemcpy(hg.data(), Xh, hg.size() * 2, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < hg.size(); ++i) hgot[i] = (float)hg[i];
+    } else {
     CK(hipMemcpy(X, hX.data(), (size_t)(Mc + 64) * C * 4, hipMemcpyHostToDevice));
     if (v.run(Y, WS2[v.pack], X, Mc, nbc, 0) != CN_OK) return 1;
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(hgot.data(), X, hgot.size() * 4, hipMemcpyDeviceToHost));
+    }
     const std::vector<float>& href = href1;  // LayerScale folded into the bf16 W2 operand
     double max_err = 0, sum_err = 0, max_ref = 0;
     size_t n_bad = 0;
@@ -226,10 +253,10 @@ template <int C> static int run(int batch, int iters) {
       max_err = std::max(max_err, e);
       sum_err += e;
       max_ref = std::max(max_ref, (double)fabs(href[i] - hX[i]));
-      if (e > 1e-3 + 1e-3 * fabs(href[i])) ++n_bad;
+      if (e > (v.xh ? 2e-3 : 1e-3) + 1e-3 * fabs(href[i])) ++n_bad;
     }
     size_t touched = 0;  // rows beyond Mc must be untouched
-    for (size_t i = href.size(); i < hgot.size(); ++i) touched += hgot[i] != hX[i];
+    for (size_t i = href.size(); i < hgot.size(); ++i) touched += hgot[i] != (i < hX.size() ? hX[i] : 0.f);
     if (v.name.rfind("ABL", 0) == 0 || v.name.find("prio") != std::string::npos) continue;
     printf("  check nb %3d %-30s max|err| %.3e  mean %.3e  (max |delta| %.3f)  out-of-tol %zu  rows>=M touched %zu  %s\n", nbc, v.name.c_str(),
            max_err, sum_err / href.size(), max_ref, n_bad, touched, (n_bad == 0 && touched == 0) ? "OK" : "FAIL");
@@ -241,13 +268,15 @@ template <int C> static int run(int batch, int iters) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   CK(hipMemcpy(X, hX.data(), hX.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(Xh, hXh.data(), hXh.size() * 2, hipMemcpyHostToDevice));
   std::vector<std::vector<float>> times(vs.size());
   const double flops = 16.0 * C * C * (double)M;
   for (int round = 0; round < 5; ++round)
     for (size_t vi = 0; vi < vs.size(); ++vi) {
-      vs[vi].run(Y, WS2[vs[vi].pack], X, M, 256, 0);  // warm
+      void* Xv = vs[vi].xh ? (void*)Xh : (void*)X;
+      vs[vi].run(Y, WS2[vs[vi].pack], Xv, M, 256, 0);  // warm
       CK(hipEventRecord(e0, 0));
-      for (int it = 0; it < iters; ++it) vs[vi].run(Y, WS2[vs[vi].pack], X, M, 256, 0);
+      for (int it = 0; it < iters; ++it) vs[vi].run(Y, WS2[vs[vi].pack], Xv, M, 256, 0);
       CK(hipEventRecord(e1, 0));
       CK(hipEventSynchronize(e1));
       float ms;
