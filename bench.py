@@ -487,6 +487,17 @@ def main() -> None:
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    # What the process group itself saw (not the WORLD_SIZE variable): its size, and the sum of one `1` per rank through the
+    # collective backend -- the first real N-GPU line proves RCCL joined N ranks.
+    world_observed, ones_sum = 1, 1
+    if world > 1:
+        world_observed = dist.get_world_size()
+        one = torch.ones(1, dtype=torch.int32, device=cdev)
+        dist.all_reduce(one)
+        ones_sum = int(one.item())
+        if world_observed != world or ones_sum != world:
+            raise SystemExit(f"bench: the process group has {world_observed} ranks and an all-reduce of ones gives {ones_sum}, but --gpus is {world}")
+
     from conette_amd.dist import gather_caption_windows, shard_bounds, trim_captions
     from conette_amd.engine import Engine
 
@@ -530,6 +541,13 @@ def main() -> None:
         t_audio = eng.lib.conette_num_audio_frames(L)
         batches = [(wave, torch.full((B,), t_audio, dtype=torch.int32, device=dev), t_audio)]
         audio_seconds = float(B * CLIP_S)
+    # Fixed workload: the timed steps walk round-robin over NB DISTINCT input batches (a real stream never re-reads its input;
+    # one 82 MB waveform tensor encoded every step would be served from the 256 MiB Infinity Cache -- VERDICT r04).  Clip j of
+    # rotation k is seeded by its global index j + k x total clips, so a sharded job sees the clips of the single-GPU job.
+    NB = max(1, int(os.environ.get("CN_BENCH_ROTATE", "4"))) if args.workload == "fixed" else 1
+    waves = None
+    if args.workload == "fixed":
+        waves = [wave] + [torch.from_numpy(synth.synth_waveforms(B, L, 1234 + clip0 + k * total_clips)).to(dev) for k in range(1, NB)]
 
     # Two pipeline slots and two HIP streams: the decode of batch i (small latency-bound launches, replayed from a
     # hipGraph) overlaps the encode of batch i+1 (big MFMA / VALU kernels; their persistent kernels leave
@@ -556,14 +574,19 @@ def main() -> None:
     # mixed16 clips/s: G 1 x 2 streams 10 161-10 261 / 8 849, G 2 x 2 10 849 / 9 757, G 3 x 1 10 893 / 9 866, G 4 x 1 10 877 / 9 946,
     # G 6 x 1 10 364 / 9 673; four and more chains: 2x slower.)
     # (mixed-length workload: every bucket of a step is a decode chain of its own -- three streams, dealt bucket by bucket)
-    n_dec_default = 1 if G >= 3 else 2 if G == 2 else 3 if (args.precision in ("exact", "mixed", "mixed16") or args.workload == "mixed") else 2
+    # two schedules exist side by side when G > 1: the grouped one (n_decg chains, n_slotg group slots) and the one-search-per-
+    # batch one (n_dec chains, n_slot slots); which of them runs the timed region is MEASURED below (on the
+    # driver's box G = 1 won for bf16 while the rule picked G = 4)
+    n_decg = max(1, min(int(os.environ.get("CN_DEC_STREAMS", "1" if G >= 3 else "2")), 3))
+    n_slotg = n_decg + 1
+    n_dec_default = 3 if (args.precision in ("exact", "mixed", "mixed16") or args.workload == "mixed") else 2
     n_dec = max(1, min(int(os.environ.get("CN_DEC_STREAMS", str(n_dec_default))), 3))
     dec_cus = int(os.environ.get("CN_DEC_CUS", "0"))   # > 0: the decode chains are confined to this many compute units (CU-masked streams)
     if dec_cus > 0:
         from conette_amd.engine import make_masked_stream
-        s_decs = [make_masked_stream(dev, dec_cus) for _ in range(n_dec)]
+        s_decs = [make_masked_stream(dev, dec_cus) for _ in range(max(n_dec, n_decg))]
     else:
-        s_decs = [torch.cuda.Stream(dev, priority=prio) for _ in range(n_dec)]
+        s_decs = [torch.cuda.Stream(dev, priority=prio) for _ in range(max(n_dec, n_decg))]
     n_slot = n_dec + 1
     from conette_amd.engine import MAX_DECODE_GRAPHS
     if len(batches) * n_slot > MAX_DECODE_GRAPHS:
@@ -583,7 +606,7 @@ def main() -> None:
     if G > 1:
         w_g, lens_g, t_g = batches[0]
         gslots = []
-        for sl in range(n_slot):
+        for sl in range(n_slotg):
             fe_big = eng.decode_input_buffer(G * B, t_g, beam, max_pred, slot=100 + sl)
             gslots.append(dict(fe=fe_big, clip=torch.empty((B, 527), dtype=torch.float32, device=dev),
                                enc_done=[torch.cuda.Event() for _ in range(G)], dec_done=torch.cuda.Event()))
@@ -593,19 +616,21 @@ def main() -> None:
         """one pass over this rank's B clips; every G-th call also launches the beam search of the last G batches"""
         i = state["i"]
         g, m = i // G, i % G
-        gs = gslots[g % n_slot]
+        gs = gslots[g % n_slotg]
         s_enc = s_encs[i % len(s_encs)]
-        s_dec = s_decs[g % n_dec]
+        s_dec = s_decs[g % n_decg]
         with torch.cuda.stream(s_enc):
-            if m == 0 and g >= n_slot:
-                s_enc.wait_event(gs["dec_done"])              # the group slot's frame buffer is free again
-            eng.encode(w_g, out=(gs["fe"][m * B:(m + 1) * B], gs["clip"]), slot=i & 1)
+            if g >= n_slotg:
+                # the group slot's frame buffer is free again.  EVERY encode of the group waits: with two encoder streams
+                # (CN_ENC_STREAMS=2) the m >= 1 encodes run on the stream that did not wait at m == 0 (ADVICE r04)
+                s_enc.wait_event(gs["dec_done"])
+            eng.encode(waves[i % NB], out=(gs["fe"][m * B:(m + 1) * B], gs["clip"]), slot=i & 1)
             gs["enc_done"][m].record(s_enc)
         if m == G - 1:
             with torch.cuda.stream(s_dec):
                 for e_ in gs["enc_done"]:
                     s_dec.wait_event(e_)
-                out = eng.decode(gs["fe"], lens_big, bos_big, forbid, beam, min_pred, max_pred, clone=False, slot=100 + (g % n_slot))
+                out = eng.decode(gs["fe"], lens_big, bos_big, forbid, beam, min_pred, max_pred, clone=False, slot=100 + (g % n_slotg))
                 preds, lps = out["best_preds"], out["best_lprobs"]
                 state["last_local"] = (preds[(G - 1) * B:], lps[(G - 1) * B:])   # the captions of this step's own batch
                 if state.get("keep") is not None and i < state["keep"][0].shape[0]:
@@ -617,41 +642,48 @@ def main() -> None:
             state["last_stream"] = s_dec
         state["i"] = i + 1
 
+    # this rank's captions of a step, staged per pipeline slot: every bucket copies its rows on ITS OWN decode stream before it
+    # records dec_done -- the slot's persistent output buffers may be overwritten by decode(i + n_slot) as soon as that event
+    # has fired, whatever another stream is still doing (the concatenation used to run later, on the last stream)
+    local_p = torch.zeros((n_slot, B, max_pred), dtype=torch.int32, device=dev)
+    local_l = torch.zeros((n_slot, B), dtype=torch.float32, device=dev)
+    bucket_off = [0]
+    for w_, _, _ in batches:
+        bucket_off.append(bucket_off[-1] + w_.shape[0])
+
     def step():
         """one pass over this rank's clips: every (length-bucketed) batch once"""
         i = state["i"]
-        res = []
+        lp_s, ll_s = local_p[i % n_slot], local_l[i % n_slot]
+        keep = state.get("keep") if (state.get("keep") is not None and i < state["keep"][0].shape[0]) else None
         for k, (w_, lens_, t_) in enumerate(batches):
             sl = slots[n_slot * k + (i % n_slot)]
             bos = bos_dev[k]
             s_enc = s_encs[i % len(s_encs)]
             s_dec = s_decs[(i * len(batches) + k) % n_dec]   # consecutive buckets decode on different streams
+            o0, o1 = bucket_off[k], bucket_off[k + 1]
             with torch.cuda.stream(s_enc):
                 if i >= n_slot:
-                    s_enc.wait_event(sl["dec_done"])          # slot's frame buffer is free again
-                eng.encode(w_, out=(sl["fe"], sl["clip"]), slot=i & 1)
+                    s_enc.wait_event(sl["dec_done"])          # slot's frame buffer (and its staging rows) are free again
+                eng.encode(w_ if waves is None else waves[i % NB], out=(sl["fe"], sl["clip"]), slot=i & 1)
                 sl["enc_done"].record(s_enc)
             with torch.cuda.stream(s_dec):
                 s_dec.wait_event(sl["enc_done"])
                 out = eng.decode(sl["fe"], lens_, bos, forbid, beam, min_pred, max_pred, clone=False, slot=n_slot * k + (i % n_slot))
-                res.append((out["best_preds"], out["best_lprobs"]))
+                preds, lps = out["best_preds"], out["best_lprobs"]
+                wcp = min(preds.shape[1], lp_s.shape[1])
+                lp_s[o0:o1, :wcp].copy_(preds[:, :wcp], non_blocking=True)
+                ll_s[o0:o1].copy_(lps, non_blocking=True)
+                if keep is not None:   # every local caption of every timed step: compared with the solo pass after the run, gathered per window
+                    kp, kl = keep
+                    kp[i, o0:o1].copy_(preds[:, : kp.shape[2]], non_blocking=True)
+                    kl[i, o0:o1].copy_(lps, non_blocking=True)
                 sl["dec_done"].record(s_dec)
-        s_last = s_decs[(i * len(batches) + len(batches) - 1) % n_dec]
-        with torch.cuda.stream(s_last):
-            if len(batches) > 1:
-                for s_ in s_decs:
-                    s_last.wait_stream(s_)
-            preds = res[0][0] if len(res) == 1 else torch.cat([r[0] for r in res])
-            lps = res[0][1] if len(res) == 1 else torch.cat([r[1] for r in res])
-            state["last_local"] = (preds, lps)  # this rank's captions of the step (before the all-gather)
-            if state.get("keep") is not None and i < state["keep"][0].shape[0]:  # every local caption of every timed step: compared
-                kp, kl = state["keep"]                                          # with the solo pass after the run, gathered per window
-                kp[i, : preds.shape[0]].copy_(preds[:, : kp.shape[2]], non_blocking=True)
-                kl[i, : lps.shape[0]].copy_(lps, non_blocking=True)
+        state["last_local"] = (lp_s, ll_s)   # this rank's captions of the step (before the all-gather); complete once every decode stream has drained
         state["i"] = i + 1
         state["last"] = out
-        state["last_stream"] = s_last
-        return preds, lps
+        state["last_stream"] = s_decs[(i * len(batches) + len(batches) - 1) % n_dec]
+        return lp_s, ll_s
 
     def gather_window(first, count):
         """N > 1: the ONE collective of a timed window -- ids + scores of all its steps, all ranks, in clip order (north_star:
@@ -669,9 +701,43 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    warm_used = max(args.warmup, 3 * n_slot)  # >= 3 per slot: the third identical decode call replays its hipGraph
+    def warm_steps(g_):   # >= 3 calls per slot: the third identical decode call replays its hipGraph
+        return max(args.warmup, 3 * n_slot) if g_ == 1 else (max(args.warmup, 3 * n_slotg * g_) + g_ - 1) // g_ * g_
+
+    # Which decode schedule runs the timed region is decided by MEASUREMENT: both candidates -- one search
+    # per G batches (the rule's G) and one search per batch -- run their warm-up and two untimed windows of --steps steps; the
+    # faster one (by its better window; over all ranks: the slowest rank's) is kept and both rates go into the JSON line.
+    # CN_DEC_GROUP set explicitly (or CN_SCHED_TRIAL=0) skips the trial.
+    schedule = None
+    if args.workload == "fixed" and G > 1 and os.environ.get("CN_DEC_GROUP") is None and os.environ.get("CN_SCHED_TRIAL", "1") != "0":
+        def trial(fn, warm):
+            state["i"] = 0
+            for _ in range(warm):
+                fn()
+            fence()
+            best_dt = float("inf")
+            for _ in range(2):
+                t0_ = time.perf_counter()
+                for _ in range(args.steps):
+                    fn()
+                torch.cuda.synchronize(dev)
+                best_dt = min(best_dt, time.perf_counter() - t0_)
+                fence()
+            return best_dt
+        t_grouped, t_single = trial(step_grouped, warm_steps(G)), trial(step, warm_steps(1))
+        if world > 1:
+            tt = torch.tensor([t_grouped, t_single], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_grouped, t_single = float(tt[0]), float(tt[1])
+        schedule = {"candidates": {f"G{G}x{n_decg}": round(total_clips * args.steps / t_grouped, 1),
+                                   f"G1x{n_dec}": round(total_clips * args.steps / t_single, 1)},
+                    "unit": "clips/s (better of two untimed windows)", "rule_G": G}
+        if t_single < t_grouped:
+            G = 1
+        schedule["chosen"] = f"G{G}x{n_decg if G > 1 else n_dec}"
+        state["i"] = 0
+    warm_used = warm_steps(G)
     if G > 1:
-        warm_used = (max(args.warmup, 3 * n_slot * G) + G - 1) // G * G
         step_single, step = step, step_grouped
     for _ in range(warm_used):
         step()
@@ -700,6 +766,15 @@ def main() -> None:
     stage_ms = {k: round(v[0], 4) for k, v in pre.items()}
     dominant = max(("pw1_gemm", "pw2_gemm", "dwconv_ln"), key=lambda k: pre.get(k, (0.0, 0))[0])
     solo_preds, solo_lps = out["best_preds"].clone(), out["best_lprobs"].clone()  # un-pipelined result of batch 0
+    solo_rot_p, solo_rot_l = [solo_preds], [solo_lps]       # un-pipelined results of every batch of the rotation
+    for k_ in range(1, NB):
+        eng.encode(waves[k_], out=(slots[0]["fe"], slots[0]["clip"]))
+        o_ = eng.decode(slots[0]["fe"], lens0, bos0, forbid, beam, min_pred, max_pred, clone=False, slot=0)
+        solo_rot_p.append(o_["best_preds"].clone())
+        solo_rot_l.append(o_["best_lprobs"].clone())
+    solo_rot_p, solo_rot_l = torch.stack(solo_rot_p), torch.stack(solo_rot_l)      # (NB, B, max_pred), (NB, B)
+    if NB > 1:   # (the pre-pass below and the parity legs work on batch 0: its frame embeddings back into slot 0)
+        eng.encode(w0, out=(slots[0]["fe"], slots[0]["clip"]))
     bm = int(out["sizes"][1].item())
     best = out["best_preds"][:, :bm]
     best_tokens = int((best != 0).sum().item())            # tokens of the returned captions (<eos> included)
@@ -754,7 +829,9 @@ def main() -> None:
     state["keep"] = None
     kp, kl = kp_all[:, :B0], kl_all[:, :B0]      # batch 0 (the only one of the fixed workload) of every timed step against the solo pass
     wp = min(kp.shape[2], lp_.shape[1])  # timed steps whose captions / scores of batch 0 differ from the solo pass
-    bad_steps = int(((kp[:, :, :wp] != solo_preds[None, :, :wp]).flatten(1).any(dim=1) | (kl != solo_lps[None]).flatten(1).any(dim=1)).sum().item())
+    rot = torch.arange(kp.shape[0], device=dev) % NB   # step i encoded batch i % NB of the rotation
+    bad_steps = int(((kp[:, :, :wp] != solo_rot_p[rot][:, :B0, :wp]).flatten(1).any(dim=1) | (kl != solo_rot_l[rot][:, :B0]).flatten(1).any(dim=1)).sum().item()) if kp.shape[0] else 0
+    solo_preds, solo_lps = solo_rot_p[(n_timed - 1) % NB], solo_rot_l[(n_timed - 1) % NB]   # the last timed step's batch
     # what the job returns: the (all-gathered) ids of the last timed step, every clip, in clip order.  Its hash lets a sharded run be
     # compared with the single-GPU run of the same clips (tests/test_gpu_bench_n2.py); on N > 1 every rank must hold the same table.
     import hashlib
@@ -860,8 +937,9 @@ def main() -> None:
             "dtype": {"bf16": "bf16", "fp8": "fp8 (e4m3 pointwise convolutions of stages 0-2) + bf16", "fp32": "f32", "exact": "f16x2", "mixed": "bf16 encoder + f16x2 decoder", "f16": "f16",
                       "mixed16": "f16 encoder + f16x2 decoder", "bf16+f16dec": "bf16 encoder + f16 decoder"}[args.precision], "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": B, "global_batch": total_clips, "beam_size": beam,
-                       "parallelism": f"dp{world}", "world_size_observed": world,
-                       "decode_group": G, "decode_streams": n_dec,
+                       "parallelism": f"dp{world}", "world_size_observed": world_observed, "allreduce_of_ones": ones_sum,
+                       "collective_backend": (None if world == 1 else dist.get_backend()),
+                       "decode_group": G, "decode_streams": n_decg if G > 1 else n_dec, "input_batches_rotated": NB,
                        **({"share_gpu_selftest": True} if share else {})},
             "audio_seconds_per_sec": round(audio_seconds_all * args.steps / dt, 1),
             "decode_tokens_per_sec": round(world * best_tokens / (decode_ms * 1e-3), 1),   # solo decode (pre-pass)
@@ -871,6 +949,7 @@ def main() -> None:
             "decode_grouped": ({"batches_per_search": G, "search_ms": round(decode_ms_grouped, 3), "ms_per_batch": round(decode_ms_grouped / G, 3),
                                 "launches_per_batch_step": round(graph_nodes_grouped / max_pred / G, 2)} if G > 1 else None),
             "roofline": roof,
+            "decode_schedule": schedule,
         }
         if args.workload == "fixed":
             n_steps = int(out["sizes"][0].item())

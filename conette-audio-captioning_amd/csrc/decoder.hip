@@ -1099,11 +1099,9 @@ struct DecGraph {
   hipGraphExec_t exec;
   hipGraph_t graph;
   hipEvent_t last;  // recorded behind every launch of `exec`: what an eviction waits for (never the whole device)
-  int seen;
+  int seen;         // 1: seen once (ran eagerly); 2: being captured by some thread (others run eagerly meanwhile)
+  int nodes;        // kernel nodes of `graph`
 };
-// The cache (lookup, LRU order, capture, eviction) is shared by every host thread that decodes on this context -- the
-// pipelines run two or three decode streams, usually from one thread, but nothing in the ABI says so: one lock around it.
-static std::mutex g_dec_graph_mu;
 static void dec_graph_release(DecGraph& g) {
   if (!g.exec) return;
   // the graph may still be executing on another stream: wait for ITS last launch.  (Not hipDeviceSynchronize: that is illegal
@@ -1117,42 +1115,51 @@ static void dec_graph_release(DecGraph& g) {
   g.exec = nullptr, g.graph = nullptr, g.last = nullptr;
 }
 #define CN_MAX_DEC_GRAPHS 64  // (bucket, pipeline slot) keys: conette_amd.engine sizes its buffer cache from the same number
+// The cache is shared by every host thread that decodes on this context (the pipelines run two or three decode streams,
+// usually from one thread, but nothing in the ABI says so).  Its lock is PER CONTEXT and covers only the table itself --
+// lookup, LRU order, insertion, the hand-over of an evicted entry: the ~300 eager launches of a first sighting, stream
+// capture + instantiation and the blocking wait for an evicted graph's last launch all run outside it, so threads that
+// drive other contexts (other GPUs) never meet, and an eviction stalls nobody but the caller that caused it.
 struct DecGraphCache {
-  DecGraph g[CN_MAX_DEC_GRAPHS];
-  int n;
-  int enabled;
-  int last_nodes;  // nodes of the most recently captured graph (conette_decode_graph_nodes)
+  std::mutex mu;
+  DecGraph g[CN_MAX_DEC_GRAPHS] = {};
+  int n = 0;
+  int enabled = 1;
+  int last_nodes = 0;  // nodes of the graph most recently launched or captured (conette_decode_graph_nodes)
 };
+static std::mutex g_dec_cache_create_mu;   // only the creation / destruction of a context's cache object
 static DecGraphCache* graph_cache(conette_ctx* ctx, bool create) {
-  if (ctx->dec_graphs == nullptr && create) {
-    DecGraphCache* c = new DecGraphCache();
-    memset(c, 0, sizeof(DecGraphCache));
-    c->enabled = 1;
-    ctx->dec_graphs = c;
-  }
+  std::lock_guard<std::mutex> lock(g_dec_cache_create_mu);
+  if (ctx->dec_graphs == nullptr && create) ctx->dec_graphs = new DecGraphCache();
   return (DecGraphCache*)ctx->dec_graphs;
 }
 void cn_decode_graphs_free(conette_ctx* ctx) {
   DecGraphCache* c = graph_cache(ctx, false);
   if (!c) return;
-  std::lock_guard<std::mutex> lock(g_dec_graph_mu);
-  for (int i = 0; i < c->n; ++i) dec_graph_release(c->g[i]);
+  {
+    std::lock_guard<std::mutex> lock(c->mu);
+    for (int i = 0; i < c->n; ++i) dec_graph_release(c->g[i]);
+    c->n = 0;
+  }
+  std::lock_guard<std::mutex> lock(g_dec_cache_create_mu);
   delete c;
   ctx->dec_graphs = nullptr;
 }
 extern "C" int conette_set_option(conette_ctx* ctx, int32_t option, int32_t value) {
   if (!ctx) return CN_ERR_ARG;
   if (option == CONETTE_OPT_DECODE_GRAPH) {
-    std::lock_guard<std::mutex> lock(g_dec_graph_mu);
     DecGraphCache* c = graph_cache(ctx, true);
-    if (c) c->enabled = value ? 1 : 0;
+    if (c) {
+      std::lock_guard<std::mutex> lock(c->mu);
+      c->enabled = value ? 1 : 0;
+    }
     return CN_OK;
   }
   if (option == CONETTE_OPT_DECODE_FUSION) {
     ctx->dec_unfused = value ? 0 : 1;
-    std::lock_guard<std::mutex> lock(g_dec_graph_mu);
     DecGraphCache* c = graph_cache(ctx, false);
     if (c) {  // cached graphs hold the other launch sequence
+      std::lock_guard<std::mutex> lock(c->mu);
       for (int i = 0; i < c->n; ++i) dec_graph_release(c->g[i]);
       c->n = 0;
     }
@@ -1209,12 +1216,11 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
                                  max_pred, best_preds, best_lprobs, mult_preds, mult_lprobs, out_sizes, step0_logits,
                                  trace_sel, trace_val, (char*)workspace, s));
   };
-  std::lock_guard<std::mutex> lock(g_dec_graph_mu);
   DecGraphCache* cache = graph_cache(ctx, true);
   const uint32_t dec_classes = (1u << CONETTE_PROF_DEC_PREPARE) | (1u << CONETTE_PROF_DEC_GEMM) |
                                (1u << CONETTE_PROF_DEC_ATTN) | (1u << CONETTE_PROF_DEC_MISC) |
                                (1u << CONETTE_PROF_SEARCH);
-  if (!cache || !cache->enabled || (ctx->prof_mask & dec_classes) != 0) return run();
+  if (!cache || (ctx->prof_mask & dec_classes) != 0) return run();
 
   DecKey key;
   memset(&key, 0, sizeof(key));
@@ -1222,42 +1228,64 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
   key.bl = best_lprobs, key.mp = mult_preds, key.ml = mult_lprobs, key.sz = out_sizes, key.s0 = step0_logits;
   key.ts = trace_sel, key.tv = trace_val, key.ws = workspace;
   key.B = batch, key.Ta = t_audio, key.beam = beam, key.min_pred = min_pred, key.maxp = max_pred;
-  DecGraph* e = nullptr;
-  for (int i = 0; i < cache->n; ++i)
-    if (cache->g[i].key == key) {  // least recently used first: a hit moves to the back
-      const DecGraph hit = cache->g[i];
-      memmove(&cache->g[i], &cache->g[i + 1], sizeof(DecGraph) * (cache->n - 1 - i));
-      cache->g[cache->n - 1] = hit;
-      e = &cache->g[cache->n - 1];
-      break;
+  auto find = [&]() -> DecGraph* {  // (under the lock) least recently used first: a hit moves to the back
+    for (int i = 0; i < cache->n; ++i)
+      if (cache->g[i].key == key) {
+        const DecGraph hit = cache->g[i];
+        memmove(&cache->g[i], &cache->g[i + 1], sizeof(DecGraph) * (cache->n - 1 - i));
+        cache->g[cache->n - 1] = hit;
+        return &cache->g[cache->n - 1];
+      }
+    return nullptr;
+  };
+  enum { EAGER, CAPTURE } todo = EAGER;
+  DecGraph evicted;
+  memset(&evicted, 0, sizeof(evicted));
+  {
+    std::lock_guard<std::mutex> lock(cache->mu);
+    if (!cache->enabled) {
+      todo = EAGER;
+    } else if (DecGraph* e = find()) {
+      if (e->exec) {  // replay (the launch and the event record stay under the lock: an eviction must see this launch's event)
+        CN_HIP(hipGraphLaunch(e->exec, s));
+        CN_HIP(hipEventRecord(e->last, s));
+        cache->last_nodes = e->nodes;
+        return CN_OK;
+      }
+      if (e->seen == 1) {  // second sighting: this call captures; the same key from another thread meanwhile runs eagerly
+        e->seen = 2;
+        todo = CAPTURE;
+      }
+    } else {  // first sighting: run eagerly (also performs the one-time kernel attribute setup)
+      if (cache->n == CN_MAX_DEC_GRAPHS) {
+        // Evict the least recently used entry.  Its graph may still be executing on another stream (two or three decode
+        // streams replay graphs side by side), and destroying an executable graph under a running launch is undefined: its
+        // own last launch is waited for (an event per graph) -- below, after the lock has been dropped.  This is the one
+        // place an entry point blocks, and it is off the steady state (more than CN_MAX_DEC_GRAPHS distinct (shape, buffer)
+        // keys alive at once); conette_set_option(DECODE_GRAPH, 0) avoids it.
+        evicted = cache->g[0];
+        memmove(&cache->g[0], &cache->g[1], sizeof(DecGraph) * (CN_MAX_DEC_GRAPHS - 1));
+        cache->n--;
+      }
+      DecGraph* fresh = &cache->g[cache->n++];
+      memset(fresh, 0, sizeof(*fresh));
+      fresh->key = key;
+      fresh->seen = 1;
     }
-  if (e && e->exec) {
-    CN_HIP(hipGraphLaunch(e->exec, s));
-    CN_HIP(hipEventRecord(e->last, s));
+  }
+  dec_graph_release(evicted);
+  if (todo == EAGER) return run();
+
+  // capture, instantiate, launch -- outside the lock; the entry is found again by its key when the graph exists
+  auto give_up = [&]() -> int {   // capture is not available here: every later call runs eagerly
+    std::lock_guard<std::mutex> lock(cache->mu);
+    cache->enabled = 0;
     return CN_OK;
-  }
-  if (!e) {  // first sighting: run eagerly (also performs the one-time kernel attribute setup)
-    if (cache->n == CN_MAX_DEC_GRAPHS) {
-      // Evict the least recently used entry.  Its graph may still be executing on another stream (two or three decode
-      // streams replay graphs side by side), and destroying an executable graph under a running launch is undefined: its
-      // own last launch is waited for (an event per graph).  This is the one place an entry point blocks, and it is off the
-      // steady state (more than CN_MAX_DEC_GRAPHS distinct (shape, buffer) keys alive at once);
-      // conette_set_option(DECODE_GRAPH, 0) avoids it.
-      dec_graph_release(cache->g[0]);
-      memmove(&cache->g[0], &cache->g[1], sizeof(DecGraph) * (CN_MAX_DEC_GRAPHS - 1));
-      cache->n--;
-    }
-    e = &cache->g[cache->n++];
-    memset(e, 0, sizeof(*e));
-    e->key = key;
-    e->seen = 1;
-    return run();
-  }
-  // second sighting: capture, instantiate, launch
+  };
   hipError_t ce = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
   if (ce != hipSuccess) {
     (void)hipGetLastError();
-    cache->enabled = 0;
+    give_up();
     return run();
   }
   const int rc = run();
@@ -1266,7 +1294,7 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
   if (rc != CN_OK || ce != hipSuccess || graph == nullptr) {
     (void)hipGetLastError();
     if (graph) (void)hipGraphDestroy(graph);
-    cache->enabled = 0;
+    give_up();
     return run();
   }
   hipGraphExec_t exec = nullptr;
@@ -1274,7 +1302,7 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
   if (ce != hipSuccess || exec == nullptr) {
     (void)hipGetLastError();
     (void)hipGraphDestroy(graph);
-    cache->enabled = 0;
+    give_up();
     return run();
   }
   hipEvent_t last = nullptr;
@@ -1282,25 +1310,37 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
     (void)hipGetLastError();
     (void)hipGraphExecDestroy(exec);
     (void)hipGraphDestroy(graph);
-    cache->enabled = 0;
+    give_up();
     return run();
   }
-  e->exec = exec;
-  e->graph = graph;
-  e->last = last;
+  size_t n_nodes = 0;
+  if (hipGraphGetNodes(graph, nullptr, &n_nodes) != hipSuccess) (void)hipGetLastError();
   {
-    size_t n_nodes = 0;
-    if (hipGraphGetNodes(graph, nullptr, &n_nodes) == hipSuccess) cache->last_nodes = (int)n_nodes;
-    else (void)hipGetLastError();
+    std::lock_guard<std::mutex> lock(cache->mu);
+    DecGraph* e = find();
+    if (e && !e->exec) {
+      e->exec = exec, e->graph = graph, e->last = last, e->nodes = (int)n_nodes;
+      cache->last_nodes = e->nodes;
+      CN_HIP(hipGraphLaunch(exec, s));
+      CN_HIP(hipEventRecord(last, s));
+      return CN_OK;
+    }
   }
+  // (the entry was evicted, or the cache reset, while this call captured: launch once and drop the graph)
   CN_HIP(hipGraphLaunch(exec, s));
   CN_HIP(hipEventRecord(last, s));
+  DecGraph tmp;
+  memset(&tmp, 0, sizeof(tmp));
+  tmp.exec = exec, tmp.graph = graph, tmp.last = last;
+  dec_graph_release(tmp);
   return CN_OK;
 }
 
 extern "C" int32_t conette_decode_graph_nodes(const conette_ctx* ctx) {
-  const DecGraphCache* c = ctx ? (const DecGraphCache*)ctx->dec_graphs : nullptr;
-  return c ? c->last_nodes : 0;
+  DecGraphCache* c = ctx ? (DecGraphCache*)ctx->dec_graphs : nullptr;
+  if (!c) return 0;
+  std::lock_guard<std::mutex> lock(c->mu);
+  return c->last_nodes;
 }
 
 // ---- teacher forcing as ONE causal pass (nn/decoding/forcing.py:12-71 is a single decoder forward over the caption) ----

@@ -26,17 +26,23 @@ extern "C" {
 
 #define CONETTE_ABI_VERSION 2 /* 2: conette_encode_taps carries its size; CONETTE_PREC_F16X2 / _FP8 / _F16; conette_decode_graph_nodes */
 
-/* precision of GEMM operands / intermediate activations (accumulation is always fp32,
- * the residual streams are always fp32) */
+/* precision of GEMM operands / intermediate activations.  Accumulation is always fp32 and the decoder's residual stream is
+ * always fp32; the ENCODER's residual stream is IEEE fp16 in the two 16-bit precisions (BF16, F16) since round 5 -- 11
+ * significant bits, |x| <= 65504 required: frame embeddings 4.43e-3 -> 4.48e-3 (BF16) and 5.4e-4 -> 8.5e-4 (F16) rel. rms off the
+ * fp32 reference for 10 C instead of 16 C bytes moved per position and block -- and fp32 in the other precisions */
 #define CONETTE_PREC_F32 0  /* v_mfma_f32_16x16x4_f32: exact-fp32 parity mode          */
 #define CONETTE_PREC_BF16 1 /* v_mfma_f32_16x16x32_bf16: throughput mode (BASELINE cfg) */
 #define CONETTE_PREC_F16X2 2 /* "exact": every GEMM operand an fp16 hi + lo pair (22 bits), products as three
                                 v_mfma_f32_16x16x32_f16 (hi.hi + hi.lo + lo.hi): fp32-MFMA accuracy at MFMA-f16 rate,
                                 exact-erf GELU; token ids equal the fp32 mode's / the reference's */
 
-#define CONETTE_PREC_FP8 3 /* BASELINE.json configs[4]: bf16 mode with the pointwise convolutions of ConvNeXt stages 0-2 on
-                              v_mfma_f32_32x32x16_fp8_fp8 (OCP e4m3 operands, per-tensor / per-output-channel scales,
-                              fp32 accumulation and residual stream); ~5 % of a block's update off the bf16 mode per block */
+#define CONETTE_PREC_FP8 3 /* EXPERIMENTAL, not a throughput mode and NOT the "fp8 MFMA pointwise GEMMs" half of BASELINE.json
+                              configs[4]: bf16 mode (fp32 residual stream) with the pointwise convolutions of ConvNeXt stages
+                              0-2 on the NON-scaled v_mfma_f32_32x32x16_fp8_fp8 (OCP e4m3 operands, per-tensor /
+                              per-output-channel scales).  That instruction has the bf16 form's cycle count, so the mode is
+                              slower than BF16 (which also moves fewer bytes since round 5) and lossy (~5 % of a block's update
+                              off the bf16 mode per block, ~1 in 5 captions kept).  Kept as the pinned starting point of a
+                              block-scaled (v_mfma_scale_f32_32x32x64_f8f6f4) port; see DESIGN.md section 9 */
 
 #define CONETTE_PREC_F16 4 /* the bf16 mode's kernels instantiated for IEEE fp16 operands (v_mfma_f32_*_f16: the same cycles,
                               the same bytes): 11 significant bits instead of 8, i.e. an eighth of the bf16 mode's operand
@@ -175,11 +181,11 @@ int conette_stream_destroy(void* stream);
                                          (forcing.py:12-71); 1: the KV-cached step kernels fed with the caption */
 int conette_set_option(conette_ctx* ctx, int32_t option, int32_t value);
 
-/* Kernel / copy nodes of the decode hipGraph captured most recently by conette_decode on this context (0: none yet):
- * the launch count of one whole search, for bench.py's decode roofline entry. */
+/* Kernel / copy nodes of the decode hipGraph that conette_decode launched (or captured) most recently on this context
+ * (0: none yet): the launch count of that whole search, for bench.py's decode roofline entry. */
 int32_t conette_decode_graph_nodes(const conette_ctx* ctx);
-/* Decode graphs a context keeps (least recently used evicted beyond it; an eviction drains the device once before the
- * graph is destroyed).  A caller that cycles through more (shape, buffer) keys than this replays nothing. */
+/* Decode graphs a context keeps (least recently used evicted beyond it; the evicting call waits for the evicted graph's own
+ * last launch, outside the context's cache lock).  A caller that cycles through more (shape, buffer) keys than this replays nothing. */
 #define CONETTE_MAX_DECODE_GRAPHS 64
 
 /* Per-kernel-class timing with HIP events recorded on the caller's stream around each launch
