@@ -416,6 +416,43 @@ def parity_report(args, Engine, eng, sd, dev, w0, lens0, bos0, forbid, t_audio, 
             key = enc_p if enc_p == dec_p else f"enc_{enc_p}+dec_{dec_p}"
             vf.setdefault(key, {})["greedy" if bm_ == 1 else f"beam{beam}"] = compare_ids(ids, lp, r32[bm_][0], r32[bm_][1])
         par["vs_fp32_mode"] = vf
+    # The same comparison on the PEAKED synthetic checkpoint (conette_amd.synth PEAKED, round 5: few candidates far above a noise
+    # floor, like a trained captioner -- the default checkpoint's Gaussian logits put every decision within a few percent of a
+    # logit of its runner-up, which is what the bf16 agreement above measures): the benchmark's clips, the 16-bit precisions
+    # against the library's exact precision (whose ids equal the oracle's / the reference's: tests/test_peaked_checkpoint.py).
+    try:
+        import numpy as np
+        from conette_amd import synth as _synth
+        sd_pk = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in _synth.synth_state_dict(recipe="peaked").items()}
+        pk_eng = {name: Engine(sd_pk, precision=name, device=dev) for name in ("exact", "bf16", "f16")}
+        pk_out = {}
+        for bi in range(max(1, args.parity_batches)):
+            wv_b = wv if bi == 0 else torch.from_numpy(_synth.synth_waveforms(n, wv.shape[1], 1234 + 7919 * bi)).to(dev)
+            for name, e in pk_eng.items():
+                fe_pk = e.encode(wv_b)[0].clone()
+                for bm_ in (1, beam):
+                    o = e.decode(fe_pk, ln, bs, forbid, bm_, min_pred, max_pred)
+                    cur = (_ids(o), o["best_lprobs"].cpu())
+                    if (name, bm_) in pk_out:
+                        a = pk_out[(name, bm_)]
+                        w_ = max(a[0].shape[1], cur[0].shape[1])
+                        pa_ = torch.zeros((a[0].shape[0], w_), dtype=a[0].dtype)
+                        pb_ = torch.zeros((cur[0].shape[0], w_), dtype=cur[0].dtype)
+                        pa_[:, : a[0].shape[1]] = a[0]
+                        pb_[:, : cur[0].shape[1]] = cur[0]
+                        cur = (torch.cat([pa_, pb_]), torch.cat([a[1], cur[1]]))
+                    pk_out[(name, bm_)] = cur
+        torch.cuda.synchronize(dev)
+        pk = {"reference": "the library's exact precision on the same clips (ids = the CPU oracle's on the committed peaked fixtures)",
+              "checkpoint": "conette_amd.synth.synth_state_dict(recipe='peaked')"}
+        for name in ("bf16", "f16"):
+            pk[name] = {("greedy" if bm_ == 1 else f"beam{beam}"): compare_ids(pk_out[(name, bm_)][0], pk_out[(name, bm_)][1],
+                                                                                pk_out[("exact", bm_)][0], pk_out[("exact", bm_)][1])
+                        for bm_ in (1, beam)}
+        par["peaked_checkpoint"] = pk
+        del pk_eng
+    except Exception as e_:   # (reported, never fatal: the leg is additional evidence)
+        par["peaked_checkpoint"] = {"error": f"{type(e_).__name__}: {e_}"[:300]}
     # what the other precisions cost: the same two-slot encode + decode loop, un-pipelined (one stream)
     for name, e in engines.items():
         if name == args.precision:

@@ -177,8 +177,11 @@ def _pos_embedding(maxlen: int = 5000, d: int = 256) -> np.ndarray:
 
 
 def synth_state_dict(n_words: int = N_WORDS_DEFAULT, seed: int = 0, eos_bias: float = 14.0,
-                     d_model: int = 256, n_layers: int = 6, d_ff: int = 2048) -> Dict[str, np.ndarray]:
-    """All tensors of the reference state dict (except the pickled ``_extra_state_``)."""
+                     d_model: int = 256, n_layers: int = 6, d_ff: int = 2048, recipe: str = "default") -> Dict[str, np.ndarray]:
+    """All tensors of the reference state dict (except the pickled ``_extra_state_``).
+
+    recipe = "peaked" (round 5): the same encoder, a decoder whose next-token distribution looks like a trained model's --
+    see ``_peaked_decoder``."""
     sd: Dict[str, np.ndarray] = {}
     vocab = 4 + n_words + len(TASK_NAMES)
     E = "preprocessor.encoder."
@@ -262,7 +265,67 @@ def synth_state_dict(n_words: int = N_WORDS_DEFAULT, seed: int = 0, eos_bias: fl
     for t in (0, 1, 3):
         sd[D + "classifier.bias"][t] = np.float32(-30.0)
     sd[D + "classifier.bias"][base:] = np.float32(-30.0)
+    if recipe == "peaked":
+        _peaked_decoder(sd, n_words, seed, d_model, n_layers)
+    elif recipe != "default":
+        raise ValueError(f"unknown recipe {recipe!r}")
     return sd
+
+
+# ---- recipe "peaked" -------------------------------------------------------------------------------------------------
+# The default recipe's logits are Gaussian over the vocabulary: the gap between neighbouring top candidates is ~ sigma / 4
+# whatever the scale, i.e. the same few percent of a logit that 16-bit operand rounding moves -- scaling the classifier scales
+# both (VERDICT r04 asked for "classifier / embedding scale up": that alone cannot help).  A trained captioner is peaked in
+# another way: FEW candidates far above a noise floor.  This recipe builds that by construction:
+#   * the token stream survives the six post-norm layers (attention values and the FFN's second matrix are small, embeddings
+#     twice as long as the positional encoding), so the final state is ~0.9 aligned with the current token's embedding;
+#   * every token u has a SUCCESSOR GROUP g(u) of two words; the classifier row of word v is
+#         s x (sum of the embeddings of the tokens whose successor group holds v)  +  s2 x (a random direction R_v),
+#     so the two successors of the current token sit ~20 above the ~N(0, s2^2) floor of the other 5 629 logits and are told
+#     apart by R_v . x -- which depends on position and audio;
+#   * a share of the tokens is "terminal": their embedding carries a component along a fixed direction q, and the <eos> row
+#     is s_e x q -- captions end after a terminal token (lengths 5-13 on the fixtures' clips).
+# Measured on the reference with the 8 clips of b8_10s (oracle/gen_golden.py): greedy calls with top-2 margin > 0.25: 93 %;
+# beam 3 calls with top-(k+1) margin > 0.25: 68 % (hypotheses of a beam search ARE near each other; default recipe: 14-17 %).
+PEAKED = dict(s=1.8, s2=7.0, s_e=4.5, tau=2.4, term_frac=0.3, gsize=2, emb_scale=2.0, ffn_scale=0.1, ca_v=0.025, sa_v_scale=0.2)
+
+
+def _peaked_decoder(sd: Dict[str, np.ndarray], n_words: int, seed: int, d: int, n_layers: int) -> None:
+    P = PEAKED
+    vocab = 4 + n_words + len(TASK_NAMES)
+    D = "model.decoder."
+    q = _uni("peaked:q", (d,), 1.0 / math.sqrt(d), 0.0, seed).astype(np.float64)
+    q = q / math.sqrt(float((q * q).sum()))
+    E0 = sd[D + "emb_layer.weight"].astype(np.float64) * P["emb_scale"]
+    term = _rng("peaked:term", seed).random(vocab) < P["term_frac"]
+    term[:4] = False
+    E = E0 + P["tau"] * term[:, None] * q[None, :]
+    E[0] = 0.0                                              # padding_idx row
+    sd[D + "emb_layer.weight"] = E.astype(np.float32)
+    gsize = int(P["gsize"])
+    n_groups = n_words // gsize
+    gam = (_rng("peaked:gamma", seed).random(vocab) * n_groups).astype(np.int64)   # successor group of every token
+    S = np.zeros((n_groups, d))
+    np.add.at(S, gam[1:], E0[1:])                           # per group: sum of its predecessors' (plain) embeddings
+    R = _uni("peaked:R", (vocab, d), 1.0 / math.sqrt(d), 0.0, seed).astype(np.float64)
+    Wc = np.zeros((vocab, d))
+    words = np.arange(4, 4 + n_groups * gsize)
+    Wc[words] = P["s"] * S[(words - 4) // gsize] + P["s2"] * R[words]
+    Wc[2] = P["s_e"] * q
+    sd[D + "classifier.weight"] = Wc.astype(np.float32)
+    b = sd[D + "classifier.bias"].copy()
+    b[2] = np.float32(0.0)
+    b[4 + n_groups * gsize: 4 + n_words] = np.float32(-30.0)
+    sd[D + "classifier.bias"] = b
+    for l in range(n_layers):
+        p = D + f"layers.{l}."
+        sd[p + "linear2.weight"] = (sd[p + "linear2.weight"] * np.float32(P["ffn_scale"])).astype(np.float32)
+        w = sd[p + "multihead_attn.in_proj_weight"].copy()
+        w[2 * d:] *= np.float32(P["ca_v"] / CA_V)
+        sd[p + "multihead_attn.in_proj_weight"] = w
+        w = sd[p + "self_attn.in_proj_weight"].copy()
+        w[2 * d:] *= np.float32(P["sa_v_scale"])
+        sd[p + "self_attn.in_proj_weight"] = w
 
 
 def synth_waveforms(batch: int, n_samples: int = 10 * SAMPLE_RATE, seed0: int = 1234,

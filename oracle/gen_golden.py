@@ -42,6 +42,15 @@ SCENARIOS = {
                                           max_pred_size=30), form="list"),
     "b2_4s_beam8_content_words": dict(secs=[4, 4], seed0=7000, kw=dict(task="audiocaps", beam_size=8, forbid_rep_mode="content_words",
                                                                         max_pred_size=16), form="tensor3"),
+    # round 5: the "peaked" synthetic checkpoint (synth.py PEAKED: few candidates far above a noise floor, like a trained
+    # captioner) -- the fixtures on which the 16-bit precisions' token ids are held to the reference's (tests/test_gpu_peaked.py);
+    # written to tests/golden/peaked/
+    "pk_b8_10s_beam1_clotho": dict(secs=[10] * 8, seed0=5000, kw=dict(task="clotho", beam_size=1), form="tensor3", recipe="peaked"),
+    "pk_b8_10s_beam3_clotho": dict(secs=[10] * 8, seed0=5000, kw=dict(task="clotho"), form="tensor3", recipe="peaked"),
+    "pk_b4_mixed_beam1_tasks": dict(secs=[3, 6.5, 10, 14.2], seed0=8000,
+                                    kw=dict(task=["clotho", "audiocaps", "macs", "wavcaps_freesound"], beam_size=1), form="list", recipe="peaked"),
+    "pk_b4_mixed_beam3_tasks": dict(secs=[3, 6.5, 10, 14.2], seed0=8000,
+                                    kw=dict(task=["clotho", "audiocaps", "macs", "wavcaps_freesound"]), form="list", recipe="peaked"),
 }
 
 
@@ -72,9 +81,17 @@ def main() -> None:
     hm.load_audioset_idx_to_name = lambda offline=False, verbose=0: {i: f"tag{i}" for i in range(527)}
     cfg = R.CoNeTTEConfig(**synth.synth_config_dict())
     model = R.CoNeTTEModel(cfg, device="cpu", offline=True)
-    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict().items()}
-    sd["_extra_state_"] = torch.from_numpy(synth.extra_state_tensor())
-    print(model.load_state_dict(sd, strict=True))
+    loaded = {"recipe": None}
+
+    def load_recipe(recipe):
+        if loaded["recipe"] == recipe:
+            return
+        sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(recipe=recipe).items()}
+        sd["_extra_state_"] = torch.from_numpy(synth.extra_state_tensor())
+        print(recipe, model.load_state_dict(sd, strict=True))
+        loaded["recipe"] = recipe
+
+    load_recipe("default")
     enc = model.preprocessor.encoder
 
     # ---- record per-step selections of the reference's own _select_k_next_toks ---------------
@@ -115,6 +132,7 @@ def main() -> None:
     for name, sc in SCENARIOS.items():
         if only and name not in only[0]:
             continue
+        load_recipe(sc.get("recipe", "default"))
         x, wav, n = make_inputs(sc)
         trace.clear()
         taps.clear()
@@ -139,11 +157,14 @@ def main() -> None:
             rec["sub_" + k] = sub(taps[k])
             rec["sum_" + k] = np.float64(taps[k].double().sum().item())
             rec["abs_" + k] = np.float64(taps[k].double().abs().sum().item())
-        np.savez_compressed(os.path.join(GOLD, name + ".npz"), **rec)
+        out_dir = GOLD if sc.get("recipe", "default") == "default" else os.path.join(GOLD, sc["recipe"])
+        os.makedirs(out_dir, exist_ok=True)
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
         print(name, out["preds"].shape, out["lprobs"].numpy().round(4), "min margin %.4g" % min(t[3] for t in trace))
 
     if only:
         return
+    load_recipe("default")
     # ---- API-shape cases (model.py:185-261, preprocessor.py:89-114) ---------------------------
     api = {}
     wav = torch.from_numpy(synth.synth_waveforms(2, 2 * SR, 7000))

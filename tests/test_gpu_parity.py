@@ -192,63 +192,13 @@ def test_topk_decisions_at_reference_states(name, prec, engines, synth_weights, 
     falls the other way in bf16 does not hide the later calls of that clip."""
     g = G.load(name)
     kw = json.loads(str(g["kw"]))
-    eng = engines[prec]
-    bsz = len(g["lengths"])
     beam = kw.get("beam_size", synth_cfg["beam_size"])
-    min_pred = kw.get("min_pred_size", synth_cfg["min_pred_size"])
-    max_pred = kw.get("max_pred_size", synth_cfg["max_pred_size"])
-    tasks = json.loads(str(g["tasks"]))
-    task_names = list(synth_cfg["task_names"])
-    bos = synth_weights["model.task_id_to_token_id"][torch.as_tensor([task_names.index(t) for t in tasks])].tolist()
-    mode = kw.get("forbid_rep_mode")
-    v = eng.vocab_size
-    forbid = _forbid_mask(synth_weights, synth_cfg, mode)
-    forbid = torch.zeros(v, dtype=torch.bool) if forbid is None else forbid.bool()
     calls = _ref_calls(g, beam)
-    state = {j: ([[bos[j]] for _ in range(beam)], [0.0] * beam) for j in range(bsz)}
-    items, rows_clip, rows_caps = [], [], []
-    for step, clip, par, tok, sums, margin in calls:
-        pre, sm = state[clip]
-        use = pre[:1] if step == 0 else pre
-        items.append((len(rows_clip), len(use), list(sm)))
-        for p_ in use:
-            rows_clip.append(clip)
-            rows_caps.append(p_ + [0] * (max_pred - len(p_)))
-        newp = [pre[p_] + [t] for p_, t in zip(par, tok)]
-        keep = [i for i, t in enumerate(tok) if not (t == 2 or step == max_pred - 1)]
-        state[clip] = ([newp[i] for i in keep], [sums[i] for i in keep])
-    fe = torch.from_numpy(g["frame_embs"])[rows_clip].cuda()
-    lens = torch.from_numpy(g["audio_shape"][:, 1].astype(np.int32))[rows_clip]
-    caps = torch.as_tensor(rows_caps, dtype=torch.int64)
-    eng.set_forcing_stepwise(True)   # the KV-cached step kernels the search itself runs (fused block / FFN kernels in bf16)
-    try:
-        logits = eng.forcing(fe, lens, caps).cpu()                    # (rows, max_pred, V)
-    finally:
-        eng.set_forcing_stepwise(False)
     tol = 5e-4 if prec in EXACT else 0.25 * R16[prec]
-    n_checked = n_same = n_eligible = 0
-    for (r0, n_rows, sm), (step, clip, par, tok, sums, margin) in zip(items, calls):
-        lg = logits[r0 : r0 + n_rows, step].clone()
-        if step < min_pred:
-            lg[:, 2] = -float("inf")
-        for i in range(n_rows):
-            seen = torch.zeros(v, dtype=torch.bool)
-            seen[torch.as_tensor(rows_caps[r0 + i][: step + 1])] = True
-            lg[i, seen & forbid] = -float("inf")
-        cand = torch.log_softmax(lg, dim=1)
-        if step > 0:
-            cand = cand + torch.as_tensor(sm[:n_rows])[:, None]
-        k = len(par)
-        vals, flat = torch.topk(cand.reshape(-1), k)
-        eff = min([margin] + [sums[i] - sums[i + 1] for i in range(k - 1)])
-        np.testing.assert_allclose(vals.numpy(), sums, atol=2e-4 * (step + 1) if prec in EXACT else 0.2 * R16[prec])
-        same = (flat // v).tolist() == par and (flat % v).tolist() == tok
-        n_same += same
-        if eff <= tol:
-            continue
-        n_eligible += 1
-        assert same, (name, prec, step, clip)
-        n_checked += 1
+    forbid = _forbid_mask(synth_weights, synth_cfg, kw.get("forbid_rep_mode"))
+    n_checked, n_same, n_eligible = G.topk_at_reference_states(
+        g, calls, engines[prec], synth_weights, synth_cfg, forbid, tol,
+        sum_atol=(lambda step: 2e-4 * (step + 1)) if prec in EXACT else (lambda step: 0.2 * R16[prec]), tag=(name, prec))
     print(f"top-k at reference states {name}/{prec}: {n_checked} of {len(calls)} calls above the margin verified, "
           f"{n_same} of {len(calls)} calls identical (parents, tokens and their order)")
     # exact precisions: every call above the 5e-4 margin (all but the two near-ties of the beam-8 fixture) verified, and ALL calls,
