@@ -14,6 +14,8 @@ def __getattr__(name):  # lazy: importing the package must not need a GPU or the
         return importlib.import_module(__name__ + ".model").CoNeTTEModel
     if name == "Engine":
         return importlib.import_module(__name__ + ".engine").Engine
+    if name == "BaselinePLM":   # the reference's second checkpoint family (pl_modules/baseline.py): no task tokens, no audio encoder
+        return importlib.import_module(__name__ + ".baseline").BaselinePLM
     raise AttributeError(name)
 
 

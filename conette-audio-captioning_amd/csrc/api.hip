@@ -296,7 +296,15 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
   for (int i = 0; i < n_tensors; ++i) B.index[names[i]] = i;
   const int d = cfg->d_model, V = cfg->vocab_size, dff = cfg->d_ff;
   const std::string E = "preprocessor.encoder.";
+  // A BaselinePLM-layout checkpoint (pl_modules/baseline.py:84-140: FrameIdentEncoder + projection + decoder) has no audio
+  // encoder: its input is precomputed frame embeddings.  A tensor list without any "preprocessor.encoder." entry creates a
+  // DECODER-ONLY context -- conette_decode / conette_greedy / conette_forcing work, conette_encode and
+  // conette_frontend_logmel return CN_ERR_ARG.
+  bool has_encoder = false;
+  for (int i = 0; i < n_tensors && !has_encoder; ++i) has_encoder = strncmp(names[i], E.c_str(), E.size()) == 0;
+  ctx->no_encoder = has_encoder ? 0 : 1;
 
+  if (has_encoder) {
   // ---- frontend tables ----
   {
     const float* cr = B.find(E + "spectrogram_extractor.stft.conv_real.weight", (int64_t)CN_N_BINS * CN_N_FFT);
@@ -485,6 +493,7 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
   ctx->norm_b = B.f32(E + "norm.bias", CN_FEAT);
   ctx->head_w = B.operand(E + "head_audioset.weight", (int64_t)CN_N_TAGS * CN_FEAT, 0, (int64_t)CN_N_TAGS * CN_FEAT);
   ctx->head_b = B.f32(E + "head_audioset.bias", CN_N_TAGS);
+  }  // has_encoder
 
   // ---- decoder ----
   ctx->proj_w = B.operand("model.projection.2.weight", (int64_t)d * CN_FEAT, 0, (int64_t)d * CN_FEAT);

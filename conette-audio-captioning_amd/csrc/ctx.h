@@ -78,6 +78,7 @@ struct conette_ctx {
   int fp8;    // CONETTE_PREC_FP8: bf16 everywhere except the pointwise convolutions of stages 0-2 (e4m3 operands)
   int sp16;   // CONETTE_PREC_F16X2: operands are sp16_t (fp16 hi/lo pairs, 4 bytes)
   int f16;    // CONETTE_PREC_F16: operands are half_t (the bf16 kernels instantiated for fp16), esize 2
+  int no_encoder;  // decoder-only context (a BaselinePLM-layout checkpoint: no "preprocessor.encoder." tensors at create)
   // frontend tables
   const float* window;     // [1024]
   const float2* tw512;     // [512]

@@ -912,6 +912,10 @@ extern "C" int conette_frontend_logmel(conette_ctx* ctx, const float* wave, int3
     cn_set_error("frontend_logmel: bad argument");
     return CN_ERR_ARG;
   }
+  if (ctx->no_encoder) {
+    cn_set_error("frontend_logmel: decoder-only context (created without preprocessor.encoder.* tensors)");
+    return CN_ERR_ARG;
+  }
   return cn_frontend(ctx, wave, batch, n_samples, out, (hipStream_t)stream);
 }
 
@@ -925,6 +929,11 @@ extern "C" int conette_encode(conette_ctx* ctx, const float* wave, int32_t batch
   }
   if (!ctx || !wave || !frame_embs || !workspace || batch <= 0) {
     cn_set_error("encode: bad argument");
+    return CN_ERR_ARG;
+  }
+  if (ctx->no_encoder) {
+    cn_set_error("encode: decoder-only context (created without preprocessor.encoder.* tensors: a BaselinePLM-layout checkpoint "
+                 "takes precomputed frame embeddings)");
     return CN_ERR_ARG;
   }
   if (taps && taps->struct_bytes < offsetof(conette_encode_taps, block)) {

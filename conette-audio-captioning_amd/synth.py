@@ -272,6 +272,27 @@ def synth_state_dict(n_words: int = N_WORDS_DEFAULT, seed: int = 0, eos_bias: fl
     return sd
 
 
+def synth_baseline_state_dict(n_words: int = N_WORDS_DEFAULT, seed: int = 0) -> Dict[str, Any]:
+    """A BaselinePLM-layout state dict (reference pl_modules/baseline.py:84-140: no audio encoder, no task tokens): the decoder
+    and projection of ``synth_state_dict`` at the vocabulary of a tokenizer WITHOUT task tokens (4 + n_words ids) under the keys
+    a Lightning checkpoint of that module holds -- ``projection.2.*``, ``decoder.*``, ``forbid_rep_mask`` (content_words: the
+    synthetic stop-words may repeat) and the tokenizer's ``tokenizers.0._extra_state`` dict."""
+    full = synth_state_dict(n_words, seed)
+    vocab = 4 + n_words
+    out: Dict[str, Any] = {}
+    for k, v in full.items():
+        if k.startswith("model.projection.") or k.startswith("model.decoder."):
+            kk = k[len("model."):]
+            if kk in ("decoder.emb_layer.weight", "decoder.classifier.weight", "decoder.classifier.bias"):
+                v = v[:vocab].copy()          # the task tokens' rows (appended behind the words) do not exist
+            out[kk] = v
+    frm = np.ones((vocab,), dtype=np.bool_)
+    frm[4: 4 + N_STOPWORDS] = False
+    out["forbid_rep_mask"] = frm
+    out["tokenizers.0._extra_state"] = synth_tokenizer_state(n_words, with_task_tokens=False)
+    return out
+
+
 # ---- recipe "peaked" -------------------------------------------------------------------------------------------------
 # The default recipe's logits are Gaussian over the vocabulary: the gap between neighbouring top candidates is ~ sigma / 4
 # whatever the scale, i.e. the same few percent of a logit that 16-bit operand rounding moves -- scaling the classifier scales

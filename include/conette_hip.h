@@ -86,7 +86,11 @@ int conette_abi_version(void);
  * reference key (e.g. "preprocessor.encoder.stages.0.0.pwconv1.weight"), `tensors[i]` a dev
  * pointer to the contiguous fp32 tensor (bool tensors as uint8, int64 as int64), `numel[i]`
  * its element count.  Replaces module construction + load_state_dict of
- * huggingface/model.py:41-107,126-163.  Synchronous (runs once). */
+ * huggingface/model.py:41-107,126-163.  Synchronous (runs once).
+ * A list WITHOUT any "preprocessor.encoder." tensor creates a decoder-only context -- the reference's BaselinePLM family
+ * (pl_modules/baseline.py:84-140: FrameIdentEncoder + projection + decoder over precomputed frame embeddings; the caller maps its
+ * keys "projection.*" / "decoder.*" / "forbid_rep_mask" under "model."): conette_decode / conette_greedy / conette_forcing work,
+ * conette_encode and conette_frontend_logmel return an error. */
 int conette_create(const conette_config* cfg, int32_t n_tensors, const char* const* names,
                    const void* const* tensors, const int64_t* numel, conette_ctx** out);
 void conette_destroy(conette_ctx* ctx);

@@ -275,14 +275,15 @@ def decoder_forward(w: Weights, memory: Tensor, mem_pad_mask: Optional[Tensor], 
 # ----------------------------------------------------------------------------------------
 @torch.no_grad()
 def teacher_forcing(w: Weights, audio: Tensor, audio_shape: Tensor, caps_in: Tensor, *, pad_id: int = 0,
-                    bos_id: int = 1, nhead: int = 8, n_layers: int = 6) -> Tensor:
+                    bos_id: int = 1, nhead: int = 8, n_layers: int = 6, require_task_token: bool = True) -> Tensor:
     """frame embeddings (B, T, 768) + input captions (B, t) -> logits (B, V, t).
 
     encode_audio (conette.py:452-470: projection + frame pad mask), then ONE causal decoder pass over caps_in with
     caps_in_pad_mask = tensor_to_pad_mask(caps_in, pad_value=pad_id) (forcing.py:44-49) and the square subsequent
     mask (:51-55); the result is permuted (caps, B, V) -> (B, V, caps) (:68-70).  conette.py:399-404 rejects captions
-    whose first token is still <bos> (the task token must have replaced it)."""
-    if bool(caps_in[:, 0].eq(bos_id).any()):
+    whose first token is still <bos> (the task token must have replaced it); BaselinePLM (baseline.py:346-361) has no task
+    tokens and no such check: ``require_task_token=False``."""
+    if require_task_token and bool(caps_in[:, 0].eq(bos_id).any()):
         raise ValueError("BOS was not replaced in input captions for decode_method='forcing'.")
     memory_bdt, mask = encode_audio(w, audio, audio_shape)
     caps_pad_mask = caps_in.eq(pad_id)
