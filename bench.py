@@ -842,13 +842,14 @@ def main() -> None:
     n_keep = n_timed if (world > 1 or os.environ.get("CN_BENCH_CHECK_ALL", "1") != "0") else 0  # (0: only the last step is compared)
     state["keep"] = (torch.zeros((n_keep, B, solo_preds.shape[1]), dtype=solo_preds.dtype, device=dev),
                      torch.zeros((n_keep, B), dtype=solo_lps.dtype, device=dev))
-    win_dt, own_dt = [], []
+    win_dt, own_dt, issue_dt = [], [], []
     gathered = None
     for w_i in range(n_rep):
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        issue_dt.append(time.perf_counter() - t0)   # the host has ENQUEUED the window's work (it runs ahead of the device)
         if world > 1:      # (this rank's own work ends where its last decode ends; the gather behind it waits for the others)
             for s_ in s_decs + s_encs:
                 s_.synchronize()
@@ -967,6 +968,7 @@ def main() -> None:
             "captions_sha256": captions_sha, "gather": ({"collectives_per_window": 2, "consistent_across_ranks": gather_consistent,
                                                         "what": "ids (K, B, max_pred) int32 + scores (K, B) fp32 of all K steps of a window, once per window"} if world > 1 else None),
             "timed_region_s": round(dt, 4), "repeat": n_rep,
+            "host_enqueue_ms_per_step": round(issue_dt[med] / args.steps * 1e3, 3),   # host time to enqueue a step (median window): below ms_per_step = the device, not the host, bounds the step
             "windows": {"clips_per_sec": [round(total_clips * args.steps / w, 2) for w in win_dt], "median_index": med,
                         "spread": round((max(win_dt) - min(win_dt)) / dt, 4), "timed_total_s": round(sum(win_dt), 4)},
             "rank_clips_per_sec": rank_rates,

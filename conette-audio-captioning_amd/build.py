@@ -32,6 +32,10 @@ if os.environ.get("CN_DB_XCDS"):   # A/B build: XCDs whose workgroups work in th
     FLAGS.append("-DDB_XCDS=" + os.environ["CN_DB_XCDS"])
 if os.environ.get("CN_G2_NOACT"):
     FLAGS.append("-DCN_G2_NOACT")
+if os.environ.get("CN_RS_PRIO"):    # A/B build: static wave priority in the role-split fused MLP (encoder.hip: 8 = B waves)
+    FLAGS.append("-DCN_RS_PRIO=" + os.environ["CN_RS_PRIO"])
+if os.environ.get("CN_FW_TH"):      # A/B build: output rows per block of the full-width depthwise kernel at C = 384 (encoder.hip: 4)
+    FLAGS.append("-DCN_FW_TH=" + os.environ["CN_FW_TH"])
 
 
 def hipcc() -> str:
@@ -51,6 +55,21 @@ FILE_FLAGS = {} if os.environ.get("CN_ALLOW_PK_HAZARD") else {"frontend.hip": ["
 SIDECAR = os.path.join(HERE, "libconette_hip.build.json")   # what LIB was built from: source hash + flags (travels with the .so)
 
 
+_TOOLCHAIN = None
+
+
+def toolchain_id() -> str:
+    """What identifies the compiler: the first lines of `hipcc --version` (HIP version, clang version + commit), cached."""
+    global _TOOLCHAIN
+    if _TOOLCHAIN is None:
+        try:
+            out = subprocess.run([hipcc(), "--version"], capture_output=True, text=True, timeout=60).stdout
+            _TOOLCHAIN = "\n".join(l.strip() for l in out.splitlines()[:3])
+        except Exception as e:   # no compiler here (a box that only runs the prebuilt library): the identity is "unknown"
+            _TOOLCHAIN = f"unknown ({type(e).__name__})"
+    return _TOOLCHAIN
+
+
 def source_hash() -> str:
     """sha256 over every file of csrc/ + the public header + the compiler flags (per file) -- the identity of a build.  A
     rebuild of the same sources gives another BINARY hash (checked in round 3), so staleness and 'which build do these PMC
@@ -62,6 +81,7 @@ def source_hash() -> str:
         h.update(os.path.basename(d).encode() + b"\0")
         h.update(open(d, "rb").read())
     h.update(repr((FLAGS, sorted(FILE_FLAGS.items()), os.environ.get("CN_FE_SRC", ""), os.environ.get("CN_FE_FLAGS", ""))).encode())
+    h.update(toolchain_id().encode())   # a compiler upgrade is another build: objects are not reused, PMC tables turn stale
     return h.hexdigest()
 
 
@@ -100,7 +120,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         stamp = obj + ".stamp"
 
         def digest(files):
-            h = hashlib.sha256(repr(cmd).encode())
+            h = hashlib.sha256((repr(cmd) + toolchain_id()).encode())
             for f in sorted(files):
                 h.update(f.encode() + b"\0" + open(f, "rb").read())
             return h.hexdigest()

@@ -514,6 +514,12 @@ __global__ __launch_bounds__(C* SPLIT > 384 ? 768 : 384) void cn_dwconv_ln_fw_ke
 #ifndef CN_FW_SPLIT
 #define CN_FW_SPLIT 2
 #endif
+#ifndef CN_RS_PRIO
+#define CN_RS_PRIO 8   // mlp_rs.h ABL bits 8 / 16: static wave priority for the B / the A role (0: none)
+#endif
+#ifndef CN_FW_TH
+#define CN_FW_TH 4   // output rows per block of the full-width kernel at C = 384 (A/B builds: 2 = half the LN tile, two blocks per CU)
+#endif
 template <typename T, typename XT, int C, int WW, int TH, int SPLIT = 1>
 static int launch_dwconv_fw(const XT* x, int B, int H, const CnBlockW& bw, T* y, hipStream_t s) {
   const int tiles_h = cn_cdiv(H, TH);
@@ -735,7 +741,7 @@ static int dwconv_dispatch(int C, const XT* x, int B, int H, int W, const CnBloc
     case 96: return launch_dwconv<T, XT, 96, 2, 8>(x, B, H, W, bw, y, s);
     case 192: return launch_dwconv<T, XT, 192, 1, 8>(x, B, H, W, bw, y, s);
     case 384:
-      if (W == 14) return launch_dwconv_fw<T, XT, 384, 14, 4, CN_FW_SPLIT>(x, B, H, bw, y, s);
+      if (W == 14) return launch_dwconv_fw<T, XT, 384, 14, CN_FW_TH, CN_FW_SPLIT>(x, B, H, bw, y, s);
       return launch_dwconv<T, XT, 384, 1, 4>(x, B, H, W, bw, y, s);
     case 768:
       if (W == 7) return launch_dwconv_fw<T, XT, 768, 7, 4>(x, B, H, bw, y, s);
@@ -863,7 +869,9 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
 #ifdef CN_NO_RS  // A/B builds only (tools/lab/ab.sh): round 2's chained kernel at stage 2
           else CN_TRY((cn_launch_mlp_rc2_ring<384, 4, 1, 3>(y, wsm, xc, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
 #else
-          else CN_TRY((cn_launch_mlp_rs<384, 4, 3>(y, wsm, xc, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
+          // (8 = the B waves -- GEMM2 + ring refill, the younger half of the block -- run at s_setprio 1: 143 against 148 us in the
+          // lab with the fp16 residual stream, profiles/r05_notes.md; the MI355X guide's "static priority for the younger half")
+          else CN_TRY((cn_launch_mlp_rs<384, 4, 3, CN_RS_PRIO>(y, wsm, xc, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
 #endif
           fused = true;
         }

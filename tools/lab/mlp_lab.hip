@@ -158,6 +158,18 @@ template <> std::vector<Variant> variants<384>() {
        [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3>(Y, WS, XF, M, nb, s); }, 4},
       {"x16 rs<384,np4,nst3>",
        [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3>(Y, WS, XH, M, nb, s); }, 4, 1},
+      {"x16 rs<384> prio B",
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 8>(Y, WS, XH, M, nb, s); }, 4, 1},
+      {"x16 rs<384> prio A",
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 16>(Y, WS, XH, M, nb, s); }, 4, 1},
+      {"ABL x16 rs<384> no DMA",
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 1>(Y, WS, XH, M, nb, s); }, 4, 1},
+      {"ABL x16 rs<384> no GELU",
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 2>(Y, WS, XH, M, nb, s); }, 4, 1},
+      {"ABL x16 rs<384> no tile I/O",
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 4>(Y, WS, XH, M, nb, s); }, 4, 1},
+      {"ABL x16 rs<384> none of the three",
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 7>(Y, WS, XH, M, nb, s); }, 4, 1},
       {"x16 rc2_ring<384,4,nck1,nst3>",
        [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_ring<384, 4, 1, 3>(Y, WS, XH, M, nb, s); }, 1, 1},
       {"rs<384> prio B",
