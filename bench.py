@@ -175,29 +175,30 @@ def pmc_mfma_busy(cls: str):
     return (round(num / den, 4), os.path.basename(path)) if den > 0 else (None, None)
 
 
-def algorithmic_work(cls: str, batch: int):
+def algorithmic_work(cls: str, batch: int, xbytes: float = 2.0):
     """(flops, bytes) of ALL launches of a kernel class for one batch of 10 s clips.
 
     Classes follow the library's profiling scopes: "pw1_gemm" = the fused MLP launches of stages 0-2
-    (both GEMMs) + the pw1 GEMMs of stage 3; "pw2_gemm" = the pw2 GEMMs of stage 3."""
+    (both GEMMs) + the pw1 GEMMs of stage 3; "pw2_gemm" = the pw2 GEMMs of stage 3.  xbytes: bytes per element of the
+    residual stream (2: the fp16 stream of the 16-bit precisions since round 5; 4: fp32)."""
     fl = by = 0.0
     for st, (c, d, p) in enumerate(zip(DIMS, DEPTHS, POS)):
         n = batch * p
         gemm = 2.0 * n * c * 4 * c
         wbytes = 2.0 * 4 * c * c
         if cls == "pw1_gemm":
-            if st in FUSED_STAGES:   # y (bf16) in, x (fp32) in + out, both weight matrices; hidden stays on chip
+            if st in FUSED_STAGES:   # y (16-bit) in, x in + out, both weight matrices; hidden stays on chip
                 fl += d * 2 * gemm
-                by += d * (2.0 * n * c + 8.0 * n * c + 2 * wbytes)
+                by += d * (2.0 * n * c + 2 * xbytes * n * c + 2 * wbytes)
             else:                    # (P x C) . (C x 4C) + bias + GELU -> bf16 hidden
                 fl += d * gemm
                 by += d * (2.0 * n * c + 2.0 * n * 4 * c + wbytes)
-        elif cls == "pw2_gemm" and st not in FUSED_STAGES:  # (P x 4C) . (4C x C), LayerScale, fp32 residual in/out
+        elif cls == "pw2_gemm" and st not in FUSED_STAGES:  # (P x 4C) . (4C x C), LayerScale, residual in/out
             fl += d * gemm
-            by += d * (2.0 * n * 4 * c + 8.0 * n * c + wbytes)
-        elif cls == "dwconv_ln":     # 49 MAC per element on the VALU; fp32 in, bf16 out
+            by += d * (2.0 * n * 4 * c + 2 * xbytes * n * c + wbytes)
+        elif cls == "dwconv_ln":     # 49 MAC per element on the VALU; residual stream in, 16-bit y out
             fl += d * 2.0 * 49 * n * c
-            by += d * (4.0 * n * c + 2.0 * n * c)
+            by += d * (xbytes * n * c + 2.0 * n * c)
     return fl, by
 
 
@@ -930,7 +931,7 @@ def main() -> None:
     roof = {"kernel": dominant, "avg_launch_us": round(avg_launch_s * 1e6, 2), "launches_per_step": launches_per_step,
             "traffic": None}
     if args.workload == "fixed":
-        fl, by = algorithmic_work(dominant, B)
+        fl, by = algorithmic_work(dominant, B, 2.0 if args.precision in ("bf16", "f16", "bf16+f16dec", "mixed", "mixed16") else 4.0)
         if dominant in ("pw1_gemm", "pw2_gemm"):
             achieved = fl / launches_per_step / avg_launch_s / 1e12
             roof.update({"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
