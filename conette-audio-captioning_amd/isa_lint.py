@@ -1,6 +1,6 @@
 """ISA lint of the built library: no kernel may contain the instruction form that MI355X executes wrongly beside bf16 MFMAs.
 
-Measured on gfx950 (tools/lab/pk_mfma_probe.hip, pk_mfma_sweep.hip; profiles/r03_notes.md section 8): a packed-fp32 arithmetic
+Measured on gfx950 (tools/lab/pk_mfma_probe.hip; the sweeps over MFMA shapes and op_sel forms are summarised in profiles/r03_notes.md section 8): a packed-fp32 arithmetic
 instruction -- v_pk_mul_f32, v_pk_add_f32, v_pk_fma_f32 -- whose op_sel routes the HIGH half of src1 into the low result
 (`op_sel:[0,1...]`, any op_sel_hi) returns wrong values in lanes 48-63 in ~2 % of its executions while ANOTHER wave on the same SIMD is
 executing v_mfma_f32_16x16x32_bf16 (not beside the f16 / fp8 / 32x32x16 / f32 MFMAs, plain VALU, LDS or memory traffic; every
