@@ -6,7 +6,8 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-// KIND: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_exp_f32, 3 v_rcp_f32, 4 v_min_f32, 5 v_cvt_pk_bf16_f32, 6 v_pk_mul_f32, 7 mix (gelu-like)
+// KIND: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_exp_f32, 3 v_rcp_f32, 4 v_min_f32, 5 v_cvt_pk_bf16_f32, 6 v_pk_mul_f32, 7 mix (gelu-like),
+// 8 v_dot2_f32_f16, 9 v_fma_mix_f32 (f16 src0), 10 v_perm_b32, 11 v_pk_fma_f16, 12 v_dot2c_f32_f16 (round 5: the depthwise conv's candidates)
 template <int KIND>
 __global__ void k(unsigned long long* out, float seed, int iters) {
   float a[8];
@@ -32,6 +33,11 @@ __global__ void k(unsigned long long* out, float seed, int iters) {
         if (KIND == 4) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
         if (KIND == 5) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
         if (KIND == 6) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(p[(i + 1) & 7]));
+        if (KIND == 8) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(c), "v"(d));
+        if (KIND == 9) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(a[i]) : "v"(c), "v"(d));
+        if (KIND == 10) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(d));
+        if (KIND == 11) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(d));
+        if (KIND == 12) asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(d));
         if (KIND == 7) {  // 2 trans : 5 regular, as in the sigmoid GELU
           if ((i & 7) == 2) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
           else if ((i & 7) == 5) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
@@ -51,9 +57,10 @@ __global__ void k(unsigned long long* out, float seed, int iters) {
 int main() {
   unsigned long long* out;
   CK(hipMalloc(&out, 16));
-  const char* names[] = {"v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "v_min_f32", "v_cvt_pk_bf16_f32", "v_pk_mul_f32", "mix 6 fma : 1 exp : 1 rcp"};
-  void (*ks[])(unsigned long long*, float, int) = {k<0>, k<1>, k<2>, k<3>, k<4>, k<5>, k<6>, k<7>};
-  for (int kind = 0; kind < 8; ++kind)
+  const char* names[] = {"v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "v_min_f32", "v_cvt_pk_bf16_f32", "v_pk_mul_f32", "mix 6 fma : 1 exp : 1 rcp",
+                         "v_dot2_f32_f16", "v_fma_mix_f32", "v_perm_b32", "v_pk_fma_f16", "v_dot2c_f32_f16"};
+  void (*ks[])(unsigned long long*, float, int) = {k<0>, k<1>, k<2>, k<3>, k<4>, k<5>, k<6>, k<7>, k<8>, k<9>, k<10>, k<11>, k<12>};
+  for (int kind = 0; kind < 13; ++kind)
     for (int wps : {1, 2, 4}) {
       const int iters = 4096;
       hipEvent_t e0, e1;
