@@ -130,6 +130,14 @@ template <> std::vector<Variant> variants<96>() {
        [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 8, 1>(Y, WS, XH, M, nb, s); }, 1, 1},
       {"x16 rc2_resident<96,8,nck2>",
        [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 8, 2>(Y, WS, XH, M, nb, s); }, 2, 1},
+      {"ABL x16 rc2_resident<96,12> no residual loads",
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 12, 1, 1>(Y, WS, XH, M, nb, s); }, 1, 1},
+      {"ABL x16 rc2_resident<96,12> no stores",
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 12, 1, 2>(Y, WS, XH, M, nb, s); }, 1, 1},
+      {"ABL x16 rc2_resident<96,12> neither",
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 12, 1, 3>(Y, WS, XH, M, nb, s); }, 1, 1},
+      {"ABL x16 rc2_resident<96,12> no global traffic at all",
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rc2_resident<96, 12, 1, 11>(Y, WS, XH, M, nb, s); }, 1, 1},
       {"rs<96,np8,nst8>",
        [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<96, 8, 8>(Y, WS, XF, M, nb, s); }, 4},
   };
