@@ -11,6 +11,7 @@
 #include <algorithm>
 #include "mlp_rc2.h"
 #include "mlp_rs.h"
+#include "mlp_rs16.h"
 #include "mlp_f8.h"
 #include "mlp_sp.h"
 #include "down_fused.h"
@@ -471,7 +472,9 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
           if (w1 && w2 && bw.b1 && bw.b2 && bw.scale && cn_pack_mlp_f8(w1, bw.b1, w2, bw.b2, bw.scale, C, ms, 0) == CN_OK) bw.mlp_f8 = ms;
         }
         if (ctx->esize == 2 && C <= 384) {
-          const size_t bytes = (size_t)(C / 8) * (C / 8 + 1) * 1024 + (size_t)(C / 32) * 1024;  // Rc2Geom<C, 1>::TOTAL_BYTES (the role-split stream's tail, C fp32, is smaller)
+          // Rc2Geom<C, 1>::TOTAL_BYTES; the role-split streams of C = 384 are [C/8][C/8 + 1] KB (mlp_rs.h) or [C/8][C/8 + 2] KB
+          // (mlp_rs16.h) + C fp32
+          const size_t bytes = std::max((size_t)(C / 8) * (C / 8 + 1) * 1024 + (size_t)(C / 32) * 1024, (size_t)(C / 8) * (C / 8 + 2) * 1024 + (size_t)C * 4);
           void* ms = B.alloc(bytes);
           const float* w1 = B.find(p + "pwconv1.weight", (int64_t)4 * C * C);
           const float* w2 = B.find(p + "pwconv2.weight", (int64_t)4 * C * C);
@@ -479,7 +482,11 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
             const int units = ((C / 8) * (C / 8 + 1) + C / 32) * 64;  // one thread per 16-byte fragment piece, the bias fragments included
             // C = 384 runs the role-split kernel (mlp_rs.h): same fragments, entry e = [W1 of chunk e | W2 of chunk e - 2]
 #ifndef CN_NO_RS
-            if (C == 384) CN_H16_CALL(ctx, hipLaunchKernelGGL(pk_mlp_rs<HT>, dim3((units + 255) / 256), dim3(256), 0, 0, w1, bw.b1, w2, bw.b2, bw.scale, C, (HT*)ms));
+            // (with the 16-bit residual stream of the bf16 / f16 precisions: mlp_rs16.h, the same pipeline on 16x16x32 MFMAs)
+            if (C == 384 && CN_RS16 && !ctx->fp8) {
+              const int u16 = (C / 8) * (C / 8 + 2) * 64;
+              CN_H16_CALL(ctx, hipLaunchKernelGGL(pk_mlp_rs16<HT>, dim3((u16 + 255) / 256), dim3(256), 0, 0, w1, bw.b1, w2, bw.b2, bw.scale, C, (HT*)ms));
+            } else if (C == 384) CN_H16_CALL(ctx, hipLaunchKernelGGL(pk_mlp_rs<HT>, dim3((units + 255) / 256), dim3(256), 0, 0, w1, bw.b1, w2, bw.b2, bw.scale, C, (HT*)ms));
             else
 #endif
             CN_H16_CALL(ctx, hipLaunchKernelGGL(pk_mlp_rc2<HT>, dim3((units + 255) / 256), dim3(256), 0, 0, w1, bw.b1, w2, bw.b2, bw.scale, C, CN_RC2_NCK(C), (HT*)ms));

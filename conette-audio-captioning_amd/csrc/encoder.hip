@@ -13,6 +13,7 @@
 #include "gemm2.h"
 #include "mlp_rc2.h"
 #include "mlp_rs.h"
+#include "mlp_rs16.h"
 #include "mlp_f8.h"
 #include "mlp_sp.h"
 #include "down_fused.h"
@@ -871,6 +872,9 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
 #else
           // (8 = the B waves -- GEMM2 + ring refill, the younger half of the block -- run at s_setprio 1: 143 against 148 us in the
           // lab with the fp16 residual stream, profiles/r05_notes.md; the MI355X guide's "static priority for the younger half")
+          // 16-bit residual stream: the same pipeline on 16x16x32 MFMAs (mlp_rs16.h; 125 against 132 us, profiles/r05_notes.md section 8);
+          // the stream was packed for the kernel that runs (api.hip)
+          else if constexpr (sizeof(XT) == 2 && CN_RS16) CN_TRY((cn_launch_mlp_rs16<384, 4, 3, CN_RS_PRIO>(y, wsm, xc, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
           else CN_TRY((cn_launch_mlp_rs<384, 4, 3, CN_RS_PRIO>(y, wsm, xc, (int)P, ctx->n_cu - ctx->enc_reserved_cus, s)));
 #endif
           fused = true;

@@ -13,6 +13,7 @@
 #include "mlp_rc2.h"
 #include "mlp_f8.h"
 #include "mlp_rs.h"
+#include "mlp_rs16.h"
 
 void cn_set_error(const char* fmt, ...) {
   va_list ap;
@@ -168,6 +169,12 @@ template <> std::vector<Variant> variants<384>() {
        [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3>(Y, WS, XH, M, nb, s); }, 4, 1},
       {"x16 rs<384> prio B",
        [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 8>(Y, WS, XH, M, nb, s); }, 4, 1},
+      {"x16 rs16<384,np4,nst3>",
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs16<384, 4, 3>(Y, WS, XH, M, nb, s); }, 5, 1},
+      {"x16 rs16<384> prio B",
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs16<384, 4, 3, 8>(Y, WS, XH, M, nb, s); }, 5, 1},
+      {"ABL x16 rs16<384> none of the three",
+       [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs16<384, 4, 3, 7>(Y, WS, XH, M, nb, s); }, 5, 1},
       {"x16 rs<384> prio A",
        [](const bf16_t* Y, const bf16_t* WS, void* X, int M, int nb, hipStream_t s) { return cn_launch_mlp_rs<384, 4, 3, 16>(Y, WS, XH, M, nb, s); }, 4, 1},
       {"ABL x16 rs<384> no DMA",
@@ -221,8 +228,9 @@ template <int C> static int run(int batch, int iters) {
   for (size_t i = 0; i < hXh.size(); ++i) hXh[i] = (half_t)(i < hX.size() ? hX[i] : 0.f);
   float *X = dalloc<float>(hX.size() + 64 * C), *Xref = dalloc<float>((size_t)Mc * C), *Xref2 = dalloc<float>((size_t)Mc * C);
   bf16_t* H = dalloc<bf16_t>((size_t)Mc * 4 * C);
-  bf16_t* WS2[5] = {nullptr, dalloc<bf16_t>(Rc2Geom<C, 1>::TOTAL_BYTES / 2), dalloc<bf16_t>(Rc2Geom<C, 2>::TOTAL_BYTES / 2),
-                    dalloc<bf16_t>(Rc2Geom<C, 1>::TOTAL_BYTES / 2), dalloc<bf16_t>(Rc2Geom<C, 1>::TOTAL_BYTES / 2)};  // [3]: NCK = 1, skewed entries; [4]: role-split entries
+  bf16_t* WS2[6] = {nullptr, dalloc<bf16_t>(Rc2Geom<C, 1>::TOTAL_BYTES / 2), dalloc<bf16_t>(Rc2Geom<C, 2>::TOTAL_BYTES / 2),
+                    dalloc<bf16_t>(Rc2Geom<C, 1>::TOTAL_BYTES / 2), dalloc<bf16_t>(Rc2Geom<C, 1>::TOTAL_BYTES / 2),
+                    dalloc<bf16_t>(Rs16Geom<C>::TOTAL_BYTES / 2)};  // [5]: role-split entries for the 16x16x32 kernel; [3]: NCK = 1, skewed entries; [4]: role-split entries
   CK(hipMemcpy(W1, hW1.data(), hW1.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(W2, hW2.data(), hW2.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(b1, hb1.data(), 4 * C * 4, hipMemcpyHostToDevice));
@@ -236,6 +244,8 @@ template <int C> static int run(int batch, int iters) {
     }
     const int u3 = ((C / 8) * (C / 8 + 1) + C / 32) * 64;
     hipLaunchKernelGGL(pk_mlp_rs, dim3((u3 + 255) / 256), dim3(256), 0, 0, W1, b1, W2, b2, sc, C, WS2[4]);
+    const int u5 = Rs16Geom<C>::NCH * Rs16Geom<C>::FR * 64;
+    hipLaunchKernelGGL(pk_mlp_rs16, dim3((u5 + 255) / 256), dim3(256), 0, 0, W1, b1, W2, b2, sc, C, WS2[5]);
   }
   // reference on the first Mc rows
   CK(hipMemcpy(Xref, hX.data(), (size_t)Mc * C * 4, hipMemcpyHostToDevice));
