@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import subprocess
 import sys
@@ -659,13 +660,22 @@ def main() -> None:
         s_dec = s_decs[g % n_decg]
         if state.get("prof") is not None:   # the dominant class is event-timed on every prof_every-th step of the timed region
             eng.profile_enable(state["prof"] if i % prof_every == 0 else ())
+        probe = state.get("gap_probe")
         with torch.cuda.stream(s_enc):
+            if probe is not None:
+                pe = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                pe[0].record(s_enc)
             if g >= n_slotg:
                 # the group slot's frame buffer is free again.  EVERY encode of the group waits: with two encoder streams
                 # (CN_ENC_STREAMS=2) the m >= 1 encodes run on the stream that did not wait at m == 0
                 s_enc.wait_event(gs["dec_done"])
+            if probe is not None:
+                pe[1].record(s_enc)
             eng.encode(waves[i % NB], out=(gs["fe"][m * B:(m + 1) * B], gs["clip"]), slot=i & 1)
             gs["enc_done"][m].record(s_enc)
+            if probe is not None:
+                pe[2].record(s_enc)
+                probe.append((m, pe))
         if m == G - 1:
             with torch.cuda.stream(s_dec):
                 for e_ in gs["enc_done"]:
@@ -842,7 +852,12 @@ def main() -> None:
     # (every window is bracketed by barrier + synchronize on both sides; the reported value is the MEDIAN window's)
     # The dominant class's launches are bracketed by HIP events on the encode stream in every prof_every-th timed step (1 = every step):
     # an event pair per launch is 36 extra packets per step on that stream, ~2 % of the step when every step carries them.
-    prof_every = max(1, int(os.environ.get("CN_PROF_EVERY", "4")))
+    # The stride is kept coprime with the decode group: step i is encode i % G of its group, the encodes of a group overlap the previous
+    # group's search to different degrees (gap probe, profiles/r05_notes.md section 8: 5.35 / 5.25 / 4.81 / 4.49 ms at G = 4), and a
+    # stride of G would time the same one every time.
+    prof_every = max(1, int(os.environ.get("CN_PROF_EVERY", "5")))
+    while prof_every > 1 and math.gcd(prof_every, G) > 1:
+        prof_every += 1
     state["prof"] = (dominant,)
     state["i"] = 0
     n_rep = max(1, args.repeat)
@@ -852,6 +867,8 @@ def main() -> None:
                      torch.zeros((n_keep, B), dtype=solo_lps.dtype, device=dev))
     win_dt, own_dt, issue_dt = [], [], []
     gathered = None
+    if os.environ.get("CN_GAP_PROBE") and G > 1:   # lab: where the encode stream idles (stderr; events around every encode)
+        state["gap_probe"] = []
     for w_i in range(n_rep):
         fence()
         t0 = time.perf_counter()
@@ -869,6 +886,14 @@ def main() -> None:
             own_dt.append(time.perf_counter() - t0)   # this rank's own work
         fence()
         win_dt.append(time.perf_counter() - t0)
+    if state.get("gap_probe"):
+        pr = state.pop("gap_probe")
+        for m_ in range(G):
+            rows_ = [(pr[j - 1][1][2].elapsed_time(pr[j][1][0]), pr[j][1][0].elapsed_time(pr[j][1][1]), pr[j][1][1].elapsed_time(pr[j][1][2]))
+                     for j in range(1, len(pr)) if pr[j][0] == m_]
+            a_ = np.array(rows_)
+            print(f"[bench] gap probe m={m_}: after previous encode {a_[:, 0].mean() * 1e3:.0f} us (max {a_[:, 0].max() * 1e3:.0f}), "
+                f"waiting for the slot {a_[:, 1].mean() * 1e3:.0f} us (max {a_[:, 1].max() * 1e3:.0f}), encode {a_[:, 2].mean():.3f} ms", file=sys.stderr, flush=True)
     # the pipelined steps (encode of batch i next to the decodes of batches i-1, i-2) must reproduce the solo pass bit for bit
     lp_, ll_ = state["last_local"][0][:B0], state["last_local"][1][:B0]
     kp_all, kl_all = state["keep"]

@@ -36,6 +36,8 @@ if os.environ.get("CN_RS_PRIO"):    # A/B build: static wave priority in the rol
     FLAGS.append("-DCN_RS_PRIO=" + os.environ["CN_RS_PRIO"])
 if os.environ.get("CN_RS16"):       # A/B build: 0 = stage 2 of the bf16 / f16 precisions on the 32x32x16 role-split kernel (mlp_rs.h)
     FLAGS.append("-DCN_RS16=" + os.environ["CN_RS16"])
+if os.environ.get("CN_STEM_MFMA"):  # A/B build: 0 = the VALU stem kernel
+    FLAGS.append("-DCN_STEM_MFMA=" + os.environ["CN_STEM_MFMA"])
 if os.environ.get("CN_FW_TH"):      # A/B build: output rows per block of the full-width depthwise kernel at C = 384 (encoder.hip: 4)
     FLAGS.append("-DCN_FW_TH=" + os.environ["CN_FW_TH"])
 

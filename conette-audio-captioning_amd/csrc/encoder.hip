@@ -115,6 +115,99 @@ __global__ __launch_bounds__(256) void cn_stem_kernel(const float* __restrict__ 
   }
 }
 
+// Stem on the fp32 matrix cores (round 5).  The VALU kernel above reads its 16 x 96 weights from LDS once per position (6 KB, 69 us
+// of LDS time per launch at B = 64: it is LDS bound); here the product runs transposed as O^T = W^T (96 x 16) . patches^T (16 x 32
+// positions) on v_mfma_f32_32x32x2_f32 -- exact fp32 products and sums -- with W^T as 24 A-operand registers per lane, loaded once
+// per wave: no weights in LDS at all.  Lane (j = l & 31, h = l >> 5) is position tile * 32 + j; k-step s of the product takes
+// patch row s >> 1, columns 2 h + (s & 1): one 8-byte load per patch row and lane.  The rows of W^T are permuted (cn_rc2_chan) so that
+// accumulator register r of channel tile t is channel 32 t + 16 (r >> 3) + 8 h + (r & 7): a lane owns 48 channels of ITS position in
+// runs of eight, the LayerNorm statistics are a lane sum plus one exchange between the halves, the stores are 16 bytes.
+template <typename XT>
+__global__ __launch_bounds__(256) void cn_stem_mfma_kernel(const float* __restrict__ in, int F, int H0, long n_pos,
+                                                           const float* __restrict__ w /*[16][96]*/, const float* __restrict__ bias,
+                                                           const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                           XT* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float s_p[3 * 96];  // bias, LN weight, LN bias
+  for (int i = threadIdx.x; i < 3 * 96; i += 256) s_p[i] = i < 96 ? bias[i] : i < 192 ? ln_w[i - 96] : ln_b[i - 192];
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  float a[3][8];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) a[t][s] = w[(4 * (s >> 1) + 2 * h + (s & 1)) * 96 + 32 * t + cn_rc2_chan(j)];
+  __syncthreads();
+  const long n_tiles = (n_pos + 31) >> 5;
+  const long n_waves = (long)gridDim.x * 4;
+  for (long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < n_tiles; tile += n_waves) {
+    const long pos = tile * 32 + j;
+    const long p = pos < n_pos ? pos : n_pos - 1;
+    const int wq = (int)(p % 56);
+    const long tt = p / 56;
+    const int hh = (int)(tt % H0);
+    const int b = (int)(tt / H0);
+    f32x2 xv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 4 * hh - 4 + i;
+      xv[i] = f32x2{0.f, 0.f};
+      if (r >= 0 && r < F) xv[i] = *(const f32x2*)(in + ((size_t)b * F + r) * CN_N_MELS + 4 * wq + 2 * h);
+    }
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const f32x4 b0 = *(const f32x4*)(s_p + 32 * t + 16 * u + 8 * h), b1 = *(const f32x4*)(s_p + 32 * t + 16 * u + 8 * h + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][8 * u + e] = b0[e], acc[t][8 * u + 4 + e] = b1[e];
+      }
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s], xv[s >> 1][s & 1], acc[t], 0, 0, 0);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += acc[t][r];
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / 96.0f);
+    float v2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc[t][r] -= mean;
+        v2 = fmaf(acc[t][r], acc[t][r], v2);
+      }
+    v2 += __shfl_xor(v2, 32);
+    const float rstd = 1.0f / sqrtf(v2 * (1.0f / 96.0f) + 1e-6f);
+    if (pos < n_pos) {
+      XT* o = out + (size_t)pos * 96 + 8 * h;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int ch = 32 * t + 16 * u + 8 * h;
+          float v[8];
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const f32x4 lw = *(const f32x4*)(s_p + 96 + ch + 4 * q), lb = *(const f32x4*)(s_p + 192 + ch + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * q + e] = acc[t][8 * u + 4 * q + e] * rstd * lw[e] + lb[e];
+          }
+          if constexpr (sizeof(XT) == 2) {
+            *(cn_h8<XT>*)(o + 32 * t + 16 * u) = cn_h8<XT>{cn_from_f32<XT>(v[0]), cn_from_f32<XT>(v[1]), cn_from_f32<XT>(v[2]), cn_from_f32<XT>(v[3]),
+                                                          cn_from_f32<XT>(v[4]), cn_from_f32<XT>(v[5]), cn_from_f32<XT>(v[6]), cn_from_f32<XT>(v[7])};
+          } else {
+            *(f32x4*)(o + 32 * t + 16 * u) = f32x4{v[0], v[1], v[2], v[3]};
+            *(f32x4*)(o + 32 * t + 16 * u + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          }
+        }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // depthwise 7x7 (pad 3) + LayerNorm over C (eps 1e-6): x XT (B,H,W,C) -> y T (B,H,W,C)
 // (XT = half_t: 2-byte loads feed v_fma_mix_f32 directly -- the fp16 input is an operand of the fp32 fma, no conversion
@@ -512,6 +605,9 @@ __global__ __launch_bounds__(C* SPLIT > 384 ? 768 : 384) void cn_dwconv_ln_fw_ke
   }
 }
 
+#ifndef CN_STEM_MFMA
+#define CN_STEM_MFMA 1   // 0 (A/B builds): the VALU stem kernel of rounds 1-4
+#endif
 #ifndef CN_FW_SPLIT
 #define CN_FW_SPLIT 2
 #endif
@@ -785,8 +881,17 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
   {
     const long n_pos = (long)B * g.H[0] * g.W[0];
     CnProfScope ps(ctx, CONETTE_PROF_STEM, s);
+#if CN_STEM_MFMA
+    {
+      const long n_tiles = (n_pos + 31) / 32;
+      const unsigned grid = (unsigned)std::min<long>((n_tiles + 3) / 4, 8L * ctx->n_cu);
+      hipLaunchKernelGGL((cn_stem_mfma_kernel<XT>), dim3(grid), dim3(256), 0, s, ws.logmel, g.F, g.H[0], n_pos, ctx->stem_w, ctx->stem_b,
+                         ctx->stem_ln_w, ctx->stem_ln_b, wsx);
+    }
+#else
     hipLaunchKernelGGL((cn_stem_kernel<1, XT>), dim3((unsigned)((n_pos + 63) / 64)), dim3(256), 0, s, ws.logmel, g.F, g.H[0],
                        n_pos, ctx->stem_w, ctx->stem_b, ctx->stem_ln_w, ctx->stem_ln_b, wsx);
+#endif
     CN_LAUNCH_CHECK();
     if (taps) CN_TRY(tap_copy(taps->stem, wsx, (size_t)n_pos * 96, s));
   }
