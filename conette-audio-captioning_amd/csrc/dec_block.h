@@ -46,6 +46,12 @@
 #ifndef DB_ROWS
 #define DB_ROWS 4   // rows (= row waves) per block, 16-bit operands: many small blocks spread the K/V and weight streams over more CUs
 #endif
+#ifndef DB_WIDE_ROWS
+#define DB_WIDE_ROWS 8   // rows per block of a wide search (R >= DB_WIDE_R rows), 16-bit operands
+#endif
+#ifndef DB_WIDE_R
+#define DB_WIDE_R 512
+#endif
 #ifndef DB_XCDS
 #define DB_XCDS 8   // XCDs whose workgroups work in the block kernel (8 = all: the product)
 #endif
@@ -144,8 +150,10 @@ __device__ __forceinline__ void db_kv_attend(DbKV<NB, HT> (&buf)[DEPTH], const f
 // same 16-byte column of the block's rows from neighbouring lanes, and at a 1 KB pitch those all hit one bank quad (rocprof
 // r03_h / r04_a: 48 % of this kernel's LDS cycles were bank conflicts)
 #define DB_RP 260
-template <typename HT> struct DbL {   // LDS map (dynamic, bytes) of the block kernel for operand type HT
-  static constexpr int ROWS = DbOp<HT>::ROWS, NT = DbOp<HT>::NPH;
+// NR = rows per block: DbOp<HT>::ROWS unless the launch picks another instantiation (decoder.hip: 8 for the 16-bit operand types at
+// R >= 512 rows -- the grouped search of bench.py -- where halving the weight re-streaming pays: profiles/r05_notes.md section 8)
+template <typename HT, int NR = DbOp<HT>::ROWS> struct DbL {   // LDS map (dynamic, bytes) of the block kernel for operand type HT
+  static constexpr int ROWS = NR, NT = DbOp<HT>::NPH;
   static constexpr int RPW = ROWS / 4;                  // rows per row wave (four row waves)
   static_assert(ROWS % 4 == 0 && ROWS <= 12, "rows per block: a multiple of the four row waves, within one 16-row MFMA tile (+ the zero row)");
   static constexpr int THREADS = 512;                  // 4 GEMM waves + 4 row waves
@@ -156,14 +164,14 @@ template <typename HT> struct DbL {   // LDS map (dynamic, bytes) of the block k
   static constexpr int OFF_P = OFF_V + 3 * ROWS * DB_RP * 4;  // parameters: bin 768 | bo | bq | bo2 | g1 | b1 | g2 | b2
   static constexpr int BYTES = OFF_P + 2560 * 4;
 };
-template <typename HT>
+template <typename HT, int NR = DbOp<HT>::ROWS>
 __device__ __forceinline__ void db_store_row(char* sA, int wave, int lane, const f32x4& o, float inv) {
   typedef G2Geom<256> G;
   char* p = sA + wave * G::RBY + (((lane >> 1) ^ (wave & G::SWM)) * 16) + (lane & 1) * 8;
   if constexpr (DbOp<HT>::NPH == 2) {
     const unsigned b0 = cn_sp16_bits(o[0] * inv), b1 = cn_sp16_bits(o[1] * inv), b2 = cn_sp16_bits(o[2] * inv), b3 = cn_sp16_bits(o[3] * inv);
     *(uint2*)p = uint2{__builtin_amdgcn_perm(b1, b0, 0x05040100u), __builtin_amdgcn_perm(b3, b2, 0x05040100u)};
-    *(uint2*)(p + DbL<HT>::TILE) = uint2{__builtin_amdgcn_perm(b1, b0, 0x07060302u), __builtin_amdgcn_perm(b3, b2, 0x07060302u)};
+    *(uint2*)(p + DbL<HT, NR>::TILE) = uint2{__builtin_amdgcn_perm(b1, b0, 0x07060302u), __builtin_amdgcn_perm(b3, b2, 0x07060302u)};
   } else {
     cn_store4((HT*)p, o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
   }
@@ -229,7 +237,7 @@ __device__ __forceinline__ void db_frag_load(F8& dst, const DbStream& st, int m,
 // while the last pass drains); the GEMM waves issue no other vector memory instruction.
 // P = pass of the stream: 16-bit operands have one pass per matrix (P = matrix); sp16 has two -- P = 2 m: the lo halves of
 // W_m against the hi activation tile (starts the sum), P = 2 m + 1: the hi halves against the lo and the hi tile.
-template <int P, typename HT>
+template <int P, typename HT, int NR = DbOp<HT>::ROWS>
 __device__ __forceinline__ void db_gemm_regs(const DbStream& wlane, cn_h8<typename DbOp<HT>::frag_t> (&fw)[4][8], const char* sA,
                                              int lane, f32x4 (&acc)[4]) {
   typedef G2Geom<256> G;
@@ -237,21 +245,21 @@ __device__ __forceinline__ void db_gemm_regs(const DbStream& wlane, cn_h8<typena
   constexpr int NPH = DbOp<HT>::NPH, LASTP = 6 * NPH - 1;
   constexpr bool kHiPass = NPH == 2 && (P & 1) == 1;
   const int lr = lane & 15, lq = lane >> 4;
-  const int arow = lr < DbOp<HT>::ROWS ? lr : DbOp<HT>::ROWS;  // padding rows of the M tile all read the zero row
-  const int asw = lr < DbOp<HT>::ROWS ? (lr & G::SWM) : 0;
+  const int arow = lr < NR ? lr : NR;  // padding rows of the M tile all read the zero row
+  const int asw = lr < NR ? (lr & G::SWM) : 0;
   if (!kHiPass) {
 #pragma unroll
     for (int a = 0; a < 4; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   cn_h8<FT> fa = *(const cn_h8<FT>*)(sA + arow * G::RBY + ((lq ^ asw) * 16));
   cn_h8<FT> fl = fa;
-  if (kHiPass) fl = *(const cn_h8<FT>*)(sA + DbL<HT>::TILE + arow * G::RBY + ((lq ^ asw) * 16));
+  if (kHiPass) fl = *(const cn_h8<FT>*)(sA + DbL<HT, NR>::TILE + arow * G::RBY + ((lq ^ asw) * 16));
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
     const cn_h8<FT> fc = fa, fcl = fl;
     if (ks < 7) {
       fa = *(const cn_h8<FT>*)(sA + arow * G::RBY + (((lq + 4 * (ks + 1)) ^ asw) * 16));
-      if (kHiPass) fl = *(const cn_h8<FT>*)(sA + DbL<HT>::TILE + arow * G::RBY + (((lq + 4 * (ks + 1)) ^ asw) * 16));
+      if (kHiPass) fl = *(const cn_h8<FT>*)(sA + DbL<HT, NR>::TILE + arow * G::RBY + (((lq + 4 * (ks + 1)) ^ asw) * 16));
     }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -276,14 +284,14 @@ __device__ __forceinline__ void db_gemm_regs(const DbStream& wlane, cn_h8<typena
   }
 }
 // matrix M of the layer (0 q, 1 k, 2 v, 3 self out-proj, 4 cross q-proj, 5 cross out-proj) in the operand type's passes
-template <int M, typename HT>
+template <int M, typename HT, int NR = DbOp<HT>::ROWS>
 __device__ __forceinline__ void db_gemm_mat(const DbStream& wlane, cn_h8<typename DbOp<HT>::frag_t> (&fw)[4][8], const char* sA,
                                             int lane, f32x4 (&acc)[4]) {
   if constexpr (DbOp<HT>::NPH == 2) {
-    db_gemm_regs<2 * M, HT>(wlane, fw, sA, lane, acc);
-    db_gemm_regs<2 * M + 1, HT>(wlane, fw, sA, lane, acc);
+    db_gemm_regs<2 * M, HT, NR>(wlane, fw, sA, lane, acc);
+    db_gemm_regs<2 * M + 1, HT, NR>(wlane, fw, sA, lane, acc);
   } else {
-    db_gemm_regs<M, HT>(wlane, fw, sA, lane, acc);
+    db_gemm_regs<M, HT, NR>(wlane, fw, sA, lane, acc);
   }
 }
 
@@ -316,8 +324,8 @@ __device__ unsigned long long g_db_prof[16];
 #define DB_NB_CROSS 8      // cross-attention frames per batch
 #define DB_DEPTH_CROSS 2   // requested right after the self-attention; the rest roll while the first are consumed
 
-template <typename HT>
-__global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
+template <typename HT, int NR = DbOp<HT>::ROWS>
+__global__ __launch_bounds__((DbL<HT, NR>::THREADS), 1) void cn_dec_block_kernel(
     DbPrologue pro, DbWeights wt,
     HT* __restrict__ kc, HT* __restrict__ vc,    // self K/V cache of this layer [step][R][256]
     const int* __restrict__ anc, int step, int R, int beam, int maxp,
@@ -331,12 +339,12 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
   typedef typename DbOp<HT>::frag_t FT;
   constexpr int NT = DbOp<HT>::NPH;  // activation tiles (sp16: hi and lo halves)
   constexpr bool kXL = DbOp<HT>::kExactLn;
-  char* sA = smem + DbL<HT>::OFF_A;
-  float* sX = (float*)(smem + DbL<HT>::OFF_X);
-  float* sV = (float*)(smem + DbL<HT>::OFF_V);
+  char* sA = smem + DbL<HT, NR>::OFF_A;
+  float* sX = (float*)(smem + DbL<HT, NR>::OFF_X);
+  float* sV = (float*)(smem + DbL<HT, NR>::OFF_V);
   float* sY = sV;                      // pre-LayerNorm rows (after q | k | v are dead)
-  float* sQ = sV + DbOp<HT>::ROWS * DB_RP;      // scaled cross-attention queries
-  float* sP = (float*)(smem + DbL<HT>::OFF_P);
+  float* sQ = sV + NR * DB_RP;      // scaled cross-attention queries
+  float* sP = (float*)(smem + DbL<HT, NR>::OFF_P);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // DB_XCDS < 8 (A/B build knob): only the workgroups dealt to the first DB_XCDS XCDs work (the grid is 8 / DB_XCDS times
@@ -345,9 +353,9 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
   if (DB_XCDS < 8) {
     if ((bx & 7) >= DB_XCDS) return;
     bx = (bx >> 3) * DB_XCDS + (bx & 7);
-    if (bx * DbOp<HT>::ROWS >= R) return;
+    if (bx * NR >= R) return;
   }
-  const int r0 = bx * DbOp<HT>::ROWS;
+  const int r0 = bx * NR;
 
   if (wave < 4) {
     // ======================= GEMM waves ========================================================
@@ -361,36 +369,36 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
     f32x4 acc[4];
     DB_SYNC();  // b1: x rows (sA) and parameters (sP) are in LDS
     {           // q | k | v
-      db_gemm_mat<0, HT>(wlane, fw, sA, lane, acc);
-      if (lr < DbOp<HT>::ROWS)
+      db_gemm_mat<0, HT, NR>(wlane, fw, sA, lane, acc);
+      if (lr < NR)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int n = 64 * wave + 16 * a + 4 * lq;
           const f32x4 bb = *(const f32x4*)(sP + n);
-          *(f32x4*)(sV + (0 * DbOp<HT>::ROWS + lr) * DB_RP + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
+          *(f32x4*)(sV + (0 * NR + lr) * DB_RP + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
         }
-      db_gemm_mat<1, HT>(wlane, fw, sA, lane, acc);
-      if (lr < DbOp<HT>::ROWS)
+      db_gemm_mat<1, HT, NR>(wlane, fw, sA, lane, acc);
+      if (lr < NR)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int n = 64 * wave + 16 * a + 4 * lq;
           const f32x4 bb = *(const f32x4*)(sP + 256 + n);
-          *(f32x4*)(sV + (1 * DbOp<HT>::ROWS + lr) * DB_RP + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
+          *(f32x4*)(sV + (1 * NR + lr) * DB_RP + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
         }
-      db_gemm_mat<2, HT>(wlane, fw, sA, lane, acc);
-      if (lr < DbOp<HT>::ROWS)
+      db_gemm_mat<2, HT, NR>(wlane, fw, sA, lane, acc);
+      if (lr < NR)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int n = 64 * wave + 16 * a + 4 * lq;
           const f32x4 bb = *(const f32x4*)(sP + 512 + n);
-          *(f32x4*)(sV + (2 * DbOp<HT>::ROWS + lr) * DB_RP + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
+          *(f32x4*)(sV + (2 * NR + lr) * DB_RP + n) = f32x4{acc[a][0] + bb[0], acc[a][1] + bb[1], acc[a][2] + bb[2], acc[a][3] + bb[3]};
         }
     }
     DB_SYNC();  // b2: q | k | v ready
     DB_SYNC();  // b3: self-attention output in sA
     {
-      db_gemm_mat<3, HT>(wlane, fw, sA, lane, acc);
-      if (lr < DbOp<HT>::ROWS)
+      db_gemm_mat<3, HT, NR>(wlane, fw, sA, lane, acc);
+      if (lr < NR)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int n = 64 * wave + 16 * a + 4 * lq;
@@ -401,8 +409,8 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
     DB_SYNC();  // b4: pre-LN1 rows ready
     DB_SYNC();  // b5: x1 in sX / sA
     {
-      db_gemm_mat<4, HT>(wlane, fw, sA, lane, acc);
-      if (lr < DbOp<HT>::ROWS)
+      db_gemm_mat<4, HT, NR>(wlane, fw, sA, lane, acc);
+      if (lr < NR)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int n = 64 * wave + 16 * a + 4 * lq;
@@ -413,8 +421,8 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
     DB_SYNC();  // b6: cross queries ready
     DB_SYNC();  // b7: cross-attention output in sA
     {
-      db_gemm_mat<5, HT>(wlane, fw, sA, lane, acc);
-      if (lr < DbOp<HT>::ROWS)
+      db_gemm_mat<5, HT, NR>(wlane, fw, sA, lane, acc);
+      if (lr < NR)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int n = 64 * wave + 16 * a + 4 * lq;
@@ -430,11 +438,11 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
   // Four row waves; wave rw works for the rows rw + 4 h of the block, h < RPW (16-bit operands: RPW = 1, one row per wave;
   // exact precision: RPW = 2, eight rows per block -- twelve waves would cap the kernel at 168 registers, the hi / lo GEMM
   // waves need 212).  Row h = 0 is the one whose K/V batches are requested ahead of the phases that consume them.
-  constexpr int ROWS = DbOp<HT>::ROWS, RPW = DbL<HT>::RPW;
+  constexpr int ROWS = NR, RPW = DbL<HT, NR>::RPW;
   const int rw = wave - 4;
   const int rt = tid - 256;
   unsigned long long t_prev = dbg ? wall_clock64() : 0ull;
-  if (rt < 32 * NT) ((uint4*)(sA + (rt >> 5) * DbL<HT>::TILE + ROWS * 512))[rt & 31] = uint4{0, 0, 0, 0};  // the zero row(s)
+  if (rt < 32 * NT) ((uint4*)(sA + (rt >> 5) * DbL<HT, NR>::TILE + ROWS * 512))[rt & 31] = uint4{0, 0, 0, 0};  // the zero row(s)
   // parameters -> LDS, 10 pieces of 1 KB by LDS-DMA (landed before this wave's younger P0 loads, i.e. before b1)
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -481,7 +489,7 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
       xr = db_row_ln<kXL>(v, pro.g3, pro.b3, lane);
     }
     *(f32x4*)(sX + rr[h] * DB_RP + 4 * lane) = xr;
-    db_store_row<HT>(sA, rr[h], lane, xr, 1.0f);
+    db_store_row<HT, NR>(sA, rr[h], lane, xr, 1.0f);
   }
   // self-attention K/V of the ancestors (row h = 0): requested now, consumed after the q | k | v GEMMs
   auto skp = [&](int h) { return [&, h](int s) { return kc + ((size_t)s * R + rb[h] + __builtin_amdgcn_readlane(my_anc[h], s)) * 256 + 4 * lane; }; };
@@ -537,7 +545,7 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
 #pragma unroll
       for (int i = 0; i < 4; ++i) o[i] = o[i] * corr + p * vn[i];
     }
-    db_store_row<HT>(sA, rr[h], lane, o, 1.0f / l);
+    db_store_row<HT, NR>(sA, rr[h], lane, o, 1.0f / l);
   }
   DB_STAMP(2)
   DB_SYNC();  // b3
@@ -550,7 +558,7 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
     const f32x4 y = *(const f32x4*)(sY + rr[h] * DB_RP + 4 * lane);
     const f32x4 x1 = db_row_ln<kXL>(y, sP + DB_P_G1, sP + DB_P_B1, lane);
     *(f32x4*)(sX + rr[h] * DB_RP + 4 * lane) = x1;
-    db_store_row<HT>(sA, rr[h], lane, x1, 1.0f);
+    db_store_row<HT, NR>(sA, rr[h], lane, x1, 1.0f);
   }
   DB_STAMP(4)
   DB_SYNC();  // b5
@@ -565,7 +573,7 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     if (h > 0) db_kv_prefetch(xkv, n_fr[h], xkp(h), xvp(h));
     db_kv_attend(xkv, q, n_fr[h], xkp(h), xvp(h), m, l, o);
-    db_store_row<HT>(sA, rr[h], lane, o, 1.0f / l);
+    db_store_row<HT, NR>(sA, rr[h], lane, o, 1.0f / l);
   }
   DB_STAMP(6)
   DB_SYNC();  // b7
@@ -586,6 +594,6 @@ __global__ __launch_bounds__(DbL<HT>::THREADS, 1) void cn_dec_block_kernel(
   if (dbg && lane == 0 && rw == 0) atomicAdd(&g_db_prof[9], 1ull);
 }
 
-template <typename HT> static inline int cn_dec_block_setup() {
-  return cn_configure_lds((const void*)cn_dec_block_kernel<HT>, DbL<HT>::BYTES);
+template <typename HT, int NR = DbOp<HT>::ROWS> static inline int cn_dec_block_setup() {
+  return cn_configure_lds((const void*)cn_dec_block_kernel<HT, NR>, DbL<HT, NR>::BYTES);
 }

@@ -906,11 +906,21 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
           DbWeights wt;
           wt.stream = lw.blk_w;
           wt.params = lw.blk_p;
-          CN_TRY(cn_dec_block_setup<T>());
-          hipLaunchKernelGGL(cn_dec_block_kernel<T>, dim3(DB_XCDS < 8 ? 8 * cn_cdiv(cn_cdiv(R, DbOp<T>::ROWS), DB_XCDS) : cn_cdiv(R, DbOp<T>::ROWS)), dim3(DbL<T>::THREADS), DbL<T>::BYTES, s, pro, wt, kc, vc,
-                             w.anc, step, R, beam, maxp, (const T*)kvc, kv_ld, l * 2 * d, frame_lens, Ta, w.x, xt,
-                             scale, kvalid, db_debug, gate);
-          CN_LAUNCH_CHECK();
+          // rows per block: DbOp<T>::ROWS (4: many small blocks spread a short search over the chip); a wide search -- R >= DB_WIDE_R
+          // rows, the grouped search of four 64-clip batches -- runs 8 rows per block (two per row wave): half the blocks, half the
+          // weight re-streaming from L2, +1.1 % end to end beside the encoder (profiles/r05_notes.md section 8).  Row-local arithmetic:
+          // the same bits either way.
+          auto launch_block = [&](auto nr_tag) -> int {
+            constexpr int NR = decltype(nr_tag)::value;
+            CN_TRY((cn_dec_block_setup<T, NR>()));
+            hipLaunchKernelGGL((cn_dec_block_kernel<T, NR>), dim3(DB_XCDS < 8 ? 8 * cn_cdiv(cn_cdiv(R, NR), DB_XCDS) : cn_cdiv(R, NR)), dim3((DbL<T, NR>::THREADS)), (DbL<T, NR>::BYTES), s, pro, wt, kc, vc,
+                               w.anc, step, R, beam, maxp, (const T*)kvc, kv_ld, l * 2 * d, frame_lens, Ta, w.x, xt,
+                               scale, kvalid, db_debug, gate);
+            CN_LAUNCH_CHECK();
+            return CN_OK;
+          };
+          if (CnIsH16<T>::value && DB_WIDE_ROWS != DbOp<T>::ROWS && R >= DB_WIDE_R) CN_TRY(launch_block(std::integral_constant<int, DB_WIDE_ROWS>{}));
+          else CN_TRY(launch_block(std::integral_constant<int, DbOp<T>::ROWS>{}));
         }
         if (ffn_fused) {
           CnProfScope ps(ctx, CONETTE_PROF_DEC_GEMM, s);
