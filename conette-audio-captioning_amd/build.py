@@ -30,6 +30,8 @@ if os.environ.get("CN_DB_ROWS_SP"):   # A/B build: rows per decoder block kernel
     FLAGS.append("-DDB_ROWS_SP=" + os.environ["CN_DB_ROWS_SP"])
 if os.environ.get("CN_DB_WIDE_ROWS"):   # A/B build: rows per block of a wide search (dec_block.h: 8; 4 = off)
     FLAGS.append("-DDB_WIDE_ROWS=" + os.environ["CN_DB_WIDE_ROWS"])
+if os.environ.get("CN_DB_WIDE_ROWS_SP"):   # A/B build: the same for the exact precision (dec_block.h: 8; 4 = off)
+    FLAGS.append("-DDB_WIDE_ROWS_SP=" + os.environ["CN_DB_WIDE_ROWS_SP"])
 if os.environ.get("CN_DB_WIDE_R"):      # A/B build: rows from which a search counts as wide (dec_block.h: 512)
     FLAGS.append("-DDB_WIDE_R=" + os.environ["CN_DB_WIDE_R"])
 if os.environ.get("CN_DB_XCDS"):   # A/B build: XCDs whose workgroups work in the decoder block kernel (dec_block.h: 8 = all)

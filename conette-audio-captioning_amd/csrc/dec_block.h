@@ -49,6 +49,9 @@
 #ifndef DB_WIDE_ROWS
 #define DB_WIDE_ROWS 8   // rows per block of a wide search (R >= DB_WIDE_R rows), 16-bit operands
 #endif
+#ifndef DB_WIDE_ROWS_SP
+#define DB_WIDE_ROWS_SP 8  // ... exact precision (mixed16 beside the encoder: +1.2-2.3 %, exact +0.3 %)
+#endif
 #ifndef DB_WIDE_R
 #define DB_WIDE_R 512
 #endif

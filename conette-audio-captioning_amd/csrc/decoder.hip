@@ -919,7 +919,8 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
             CN_LAUNCH_CHECK();
             return CN_OK;
           };
-          if (CnIsH16<T>::value && DB_WIDE_ROWS != DbOp<T>::ROWS && R >= DB_WIDE_R) CN_TRY(launch_block(std::integral_constant<int, DB_WIDE_ROWS>{}));
+          constexpr int kWide = CnIsH16<T>::value ? DB_WIDE_ROWS : DB_WIDE_ROWS_SP;
+          if (kWide != DbOp<T>::ROWS && R >= DB_WIDE_R) CN_TRY(launch_block(std::integral_constant<int, kWide>{}));
           else CN_TRY(launch_block(std::integral_constant<int, DbOp<T>::ROWS>{}));
         }
         if (ffn_fused) {
