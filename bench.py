@@ -72,7 +72,7 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: CPU self-test of the launcher / sharding / gather path (no GPU work, no timing)")
     ap.add_argument("--master-port", type=int, default=0)
-    ap.add_argument("--also", default="bf16:g1,bf16+f16dec,f16,mixed16,exact",
+    ap.add_argument("--also", default="bf16:e2,bf16:g1,bf16+f16dec,f16,mixed16,exact",
                     help="N = 1, fixed workload, bf16 only: after the run, the SAME pipelined benchmark at these precisions (one child "
                          "process each, 3 windows, no CPU / parity legs), reported under `also_pipelined` ('' = skip); `PREC:g1` = that "
                          "precision with one beam search per batch (CN_DEC_GROUP=1) instead of the grouped decode")
@@ -325,6 +325,8 @@ def also_pipelined(args, batch):
         env = dict(os.environ)
         if opt == "g1":
             env["CN_DEC_GROUP"] = "1"
+        if opt == "e2":                        # "bf16:e2" = the encodes of consecutive batches on TWO streams (see s_encs in main)
+            env["CN_ENC_STREAMS"] = "2"
         cmd = [sys.executable, os.path.abspath(__file__), "--precision", prec, "--steps", str(args.steps), "--warmup", str(args.warmup),
                "--repeat", "3", "--batch", str(batch), "--beam", str(args.beam), "--cpu-clips", "0", "--parity-clips", "0", "--also", ""]
         try:
@@ -332,6 +334,7 @@ def also_pipelined(args, batch):
             d = json.loads(r.stdout.strip().splitlines()[-1])
             out[name] = {"clips_per_sec": d["value"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
                          "decode_group": d["config"].get("decode_group"), "decode_streams": d["config"].get("decode_streams"),
+                         "encode_streams": d["config"].get("encode_streams"),
                          "windows_clips_per_sec": d["windows"]["clips_per_sec"], "pipeline_consistent": d["pipeline_consistent"]}
         except Exception as e:  # a failed child does not void the line: it is reported as such
             out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -592,8 +595,13 @@ def main() -> None:
     # hipGraph) overlaps the encode of batch i+1 (big MFMA / VALU kernels; their persistent kernels leave
     # CN_ENC_RESERVE compute units to the decode stream).
     prio = int(os.environ.get("CN_DEC_PRIO", "-1"))  # decode stream priority (negative = higher)
-    n_enc = int(os.environ.get("CN_ENC_STREAMS", "1"))   # 2: encodes of consecutive batches on alternating streams (the blocks
-    # of one batch start on the CUs the previous batch has left; measured 3 % slower than one stream, kept as a knob)
+    # CN_ENC_STREAMS=2: the encodes of consecutive batches on alternating streams -- the blocks of one batch start on the compute
+    # units the previous batch's tail has left.  Round 3: 3 % slower than one stream; round 5 (fp16 stream, 8-row decode blocks):
+    # +4.7 % (13.3 k against 12.75 k clips/s, same box) -- but two encodes in flight time-slice the compute units, so a launch's
+    # wall time (HIP events or rocprof alike) is no longer ITS time: 248 us per launch of the dominant class against 148, a
+    # "roofline.frac" of 0.20 that measures queueing.  The line's `value` and `roofline` therefore come from ONE encode stream (a
+    # launch owns the chip, its duration is the kernel's); the two-stream rate is reported beside it as `also_pipelined["bf16:e2"]`.
+    n_enc = int(os.environ.get("CN_ENC_STREAMS", "1"))
     s_encs = [torch.cuda.Stream(dev, priority=int(os.environ.get("CN_ENC_PRIO", "0"))) for _ in range(max(1, min(n_enc, 2)))]
     # Grouped decode (fixed workload): the beam search of G consecutive batches runs as ONE chain over G x B clips, launched when
     # the G-th of them has been encoded.  A search is a latency chain whose kernels re-fetch every layer's weights once per
@@ -1014,7 +1022,7 @@ def main() -> None:
             "config": {"workload": wl, "batch_per_gpu": B, "global_batch": total_clips, "beam_size": beam,
                        "parallelism": f"dp{world}", "world_size_observed": world_observed, "allreduce_of_ones": ones_sum,
                        "collective_backend": (None if world == 1 else dist.get_backend()),
-                       "decode_group": G, "decode_streams": n_decg if G > 1 else n_dec, "input_batches_rotated": NB,
+                       "decode_group": G, "decode_streams": n_decg if G > 1 else n_dec, "encode_streams": len(s_encs), "input_batches_rotated": NB,
                        **({"share_gpu_selftest": True} if share else {})},
             "audio_seconds_per_sec": round(audio_seconds_all * args.steps / dt, 1),
             "decode_tokens_per_sec": round(world * best_tokens / (decode_ms * 1e-3), 1),   # solo decode (pre-pass)
