@@ -43,7 +43,7 @@ DEC_GROUP_DEFAULT = 16                       # CN_DEC_GROUP: batches whose beam 
 FUSED_STAGES = (0, 1, 2)                     # pw1 + GELU + pw2 run as ONE kernel (mlp_rc2.h), timed under "pw1_gemm"
 # kernel-name fragments of each profiling class in the committed PMC tables (profiles/*_pmc_*.csv)
 PMC_KERNELS = {
-    "pw1_gemm": ("cn_mlp_rc2_", "cn_mlp_rs_", "EpiBiasActIDF16bLi4"),
+    "pw1_gemm": ("cn_mlp_rc2_", "cn_mlp_rs_", "cn_mlp_rs16_", "EpiBiasActIDF16bLi4"),
     "pw2_gemm": ("EpiResid",),
     "dwconv_ln": ("cn_dwconv_ln",),
 }
