@@ -83,7 +83,7 @@ def choose_decode_group(steps: int, batch: int, beam: int, cap: int = 16) -> int
     """Batches whose beam searches run as one chain (bench.py step_grouped): the largest divisor of ``steps`` -- a timed window must
     end on a group boundary -- with G x batch <= 256 clips, G <= cap and G x batch x beam below the 4 096 rows at which the
     GEMM tile shapes change."""
-    g_max = max(1, min(cap, 256 // max(1, batch), 4095 // max(1, batch * beam)))
+    g_max = max(1, min(cap, int(os.environ.get("CN_DEC_GROUP_CLIPS", "256")) // max(1, batch), 4095 // max(1, batch * beam)))
     return max(g for g in range(1, g_max + 1) if steps % g == 0)
 
 
