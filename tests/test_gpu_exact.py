@@ -154,3 +154,18 @@ def test_exact_decode_at_4096_rows(fused, engines, synth_weights):
         v = big[k].view(n // 64, 64, *big[k].shape[1:])
         assert torch.equal(v, small[k][None].expand_as(v)), k
     torch.testing.assert_close(big["best_lprobs"].view(n // 64, 64), small["best_lprobs"][None].expand(n // 64, 64), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("prec", ["exact", "bf16"])
+def test_wide_search_blocks_return_the_narrow_search_bits(prec, engines, synth_weights):
+    """Round 5: a search of >= 512 rows runs the decoder block kernel with 8 rows per block (two per row wave), a shorter one
+    with 4 (dec_block.h DB_WIDE_ROWS / DB_WIDE_R, chosen at launch).  The arithmetic is row-local: 32 clips x beam 3 = 96 rows
+    (narrow) tiled eight times = 768 rows (wide) must return the same ids AND the same score bits eight times."""
+    eng = engines[prec]
+    fe, lens, bos, fm = _decode_inputs(synth_weights, 32, seed=11)
+    narrow = eng.decode(fe, lens, bos, fm, 3, 3, 20)
+    wide = eng.decode(fe.repeat(8, 1, 1).contiguous(), lens.repeat(8), bos.repeat(8), fm, 3, 3, 20)
+    torch.cuda.synchronize()
+    for k in ("best_preds", "mult_preds", "best_lprobs", "mult_lprobs"):
+        v = wide[k].view(8, 32, *wide[k].shape[1:])
+        assert torch.equal(v, narrow[k][None].expand_as(v)), k
