@@ -44,6 +44,9 @@ if os.environ.get("CN_RS16"):       # A/B build: 0 = stage 2 of the bf16 / f16 p
     FLAGS.append("-DCN_RS16=" + os.environ["CN_RS16"])
 if os.environ.get("CN_STEM_MFMA"):  # A/B build: 0 = the VALU stem kernel
     FLAGS.append("-DCN_STEM_MFMA=" + os.environ["CN_STEM_MFMA"])
+for _k in ("CN_DW96_S", "CN_DW96_TH", "CN_DW192_S", "CN_DW192_TH"):   # A/B builds: tile of the depthwise kernel of stages 0 / 1 (encoder.hip)
+    if os.environ.get(_k):
+        FLAGS.append(f"-D{_k}=" + os.environ[_k])
 if os.environ.get("CN_FW_TH"):      # A/B build: output rows per block of the full-width depthwise kernel at C = 384 (encoder.hip: 4)
     FLAGS.append("-DCN_FW_TH=" + os.environ["CN_FW_TH"])
 

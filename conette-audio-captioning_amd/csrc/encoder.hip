@@ -605,6 +605,19 @@ __global__ __launch_bounds__(C* SPLIT > 384 ? 768 : 384) void cn_dwconv_ln_fw_ke
   }
 }
 
+// tile of the depthwise kernel of stages 0 / 1: 4 S columns x TH rows per block of C x S threads (A/B builds: CN_DW96_S ...)
+#ifndef CN_DW96_S
+#define CN_DW96_S 2
+#endif
+#ifndef CN_DW96_TH
+#define CN_DW96_TH 8
+#endif
+#ifndef CN_DW192_S
+#define CN_DW192_S 1
+#endif
+#ifndef CN_DW192_TH
+#define CN_DW192_TH 8
+#endif
 #ifndef CN_STEM_MFMA
 #define CN_STEM_MFMA 1   // 0 (A/B builds): the VALU stem kernel of rounds 1-4
 #endif
@@ -835,8 +848,8 @@ extern "C" size_t conette_encode_workspace_bytes(const conette_ctx* ctx, int32_t
 template <typename T, typename XT>
 static int dwconv_dispatch(int C, const XT* x, int B, int H, int W, const CnBlockW& bw, T* y, hipStream_t s) {
   switch (C) {
-    case 96: return launch_dwconv<T, XT, 96, 2, 8>(x, B, H, W, bw, y, s);
-    case 192: return launch_dwconv<T, XT, 192, 1, 8>(x, B, H, W, bw, y, s);
+    case 96: return launch_dwconv<T, XT, 96, CN_DW96_S, CN_DW96_TH>(x, B, H, W, bw, y, s);
+    case 192: return launch_dwconv<T, XT, 192, CN_DW192_S, CN_DW192_TH>(x, B, H, W, bw, y, s);
     case 384:
       if (W == 14) return launch_dwconv_fw<T, XT, 384, 14, CN_FW_TH, CN_FW_SPLIT>(x, B, H, bw, y, s);
       return launch_dwconv<T, XT, 384, 1, 4>(x, B, H, W, bw, y, s);
