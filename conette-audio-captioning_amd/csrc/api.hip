@@ -105,6 +105,17 @@ __global__ void pk_taps_last(const float* __restrict__ src, float* __restrict__ 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < C * taps) dst[(i % taps) * C + i / taps] = src[i];
 }
+// depthwise (C, 1, 7, 7) -> [42][C] fp16 pairs of consecutive kernel rows (encoder.hip, CN_DW_DOT2): slot a * 7 + j = (k[2a][j], k[2a+1][j]),
+// slot 21 + a * 7 + j = (k[2a+1][j], k[2a+2][j]), a < 3; the low half is the first of the pair
+__global__ void pk_dw_pairs(const float* __restrict__ src, unsigned* __restrict__ dst, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * 42) return;
+  const int c = i % C, slot = i / C;
+  const int odd = slot >= 21, a = (slot % 21) / 7, j = slot % 7;
+  const int kh = 2 * a + odd;
+  const half_t lo = (half_t)src[c * 49 + kh * 7 + j], hi = (half_t)src[c * 49 + (kh + 1) * 7 + j];
+  dst[i] = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+}
 // (N, C, 2, 2) -> [N][(kh*2+kw)*C + c]
 template <typename T>
 __global__ void pk_down(const float* __restrict__ src, T* __restrict__ dst, int N, int C) {
@@ -448,6 +459,12 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
         float* dst = (float*)B.alloc((size_t)C * 49 * 4);
         if (w) hipLaunchKernelGGL(pk_taps_last, dim3((C * 49 + 255) / 256), dim3(256), 0, 0, w, dst, C, 49);
         bw.dw_w = dst;
+        bw.dw_wp = nullptr;
+        if (ctx->esize == 2 && !ctx->fp8) {   // the precisions whose encoder stream is fp16 (encoder.hip: XT = half_t)
+          unsigned* wp = (unsigned*)B.alloc((size_t)C * 42 * 4);
+          if (w) hipLaunchKernelGGL(pk_dw_pairs, dim3((C * 42 + 255) / 256), dim3(256), 0, 0, w, wp, C);
+          bw.dw_wp = wp;
+        }
         bw.dw_b = B.f32(p + "dwconv.bias", C);
         bw.ln_w = B.f32(p + "norm.weight", C);
         bw.ln_b = B.f32(p + "norm.bias", C);

@@ -24,6 +24,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef _Float16 half_t;
 template <typename H> using cn_h8 = H __attribute__((ext_vector_type(8)));
 template <typename H> using cn_h4 = H __attribute__((ext_vector_type(4)));
+typedef _Float16 cn_h2 __attribute__((ext_vector_type(2)));   // one register of two fp16 values (v_dot2_f32_f16 operands)
 template <typename T> struct CnIsH16 { static constexpr bool value = false; };
 template <> struct CnIsH16<bf16_t> { static constexpr bool value = true; };
 template <> struct CnIsH16<half_t> { static constexpr bool value = true; };

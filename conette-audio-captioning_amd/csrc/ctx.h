@@ -17,6 +17,7 @@ static const int CN_DIMS[4] = {96, 192, 384, 768};
 
 struct CnBlockW {
   const float* dw_w;  // [49][C]
+  const unsigned* dw_wp;  // fp16 stream only: [42][C] fp16 pairs of consecutive kernel rows, (k[2a][j], k[2a+1][j]) at a * 7 + j, (k[2a+1][j], k[2a+2][j]) at 21 + a * 7 + j
   const float* dw_b;
   const float* ln_w;
   const float* ln_b;

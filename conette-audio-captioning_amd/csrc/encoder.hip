@@ -18,6 +18,11 @@
 #include "mlp_sp.h"
 #include "down_fused.h"
 
+// fp16 stream: depthwise conv on row pairs through v_dot2_f32_f16 (0: A/B builds, one v_fma_mix_f32 per tap as in the first half of round 5)
+#ifndef CN_DW_DOT2
+#define CN_DW_DOT2 1
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // stem: Conv2d(1 -> 96, k 4x4, s 4x4, pad (4, 0)) + LayerNorm(channels_first, eps 1e-6)
 // in: logmel (B, F, 224) fp32; out: (B, H0, 56, 96) fp32.  4 lanes per output position (24 channels each, weights
@@ -243,6 +248,7 @@ template <int C, int S, int TH> struct DwTile {
 template <typename T, typename XT, int C, int S, int TH>
 __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(const XT* __restrict__ x, int H, int W, int tiles_h,
                                                             int tiles_w, const float* __restrict__ dw_w /*[49][C]*/,
+                                                            const unsigned* __restrict__ dw_wp /*[42][C] fp16 row pairs (fp16 stream)*/,
                                                             const float* __restrict__ dw_b,
                                                             const float* __restrict__ ln_w,
                                                             const float* __restrict__ ln_b, T* __restrict__ y,
@@ -272,23 +278,93 @@ __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(c
   }
 #pragma unroll 1
   for (int c = c0; c < C; c += CT) {
-  float k[49];
-#pragma unroll
-  for (int i = 0; i < 49; ++i) k[i] = dw_w[i * C + c];
-  DW_STAMP(0)
   float acc[TH][4];
   const float bias = dw_b[c];
 #pragma unroll
   for (int a = 0; a < TH; ++a)
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[a][e] = bias;
-
   const XT* xb = x + (size_t)b * H * W * C + c;
   // 80 % of the tiles are interior: no clamping / masking, and every load of an input row is
   // `row base + compile-time offset` (q * C floats fits the 13-bit immediate), which removes the
   // per-load 64-bit address arithmetic that dominated the VALU instruction count (rocprof:
   // 4250 VALU wave-instructions per 32-output patch against 1568 FMAs).
   const bool interior = (h0 >= 3) && (h0 + TH + 3 <= H) && (w0 >= 3) && (w0 + 4 + 3 <= W);
+  if constexpr (sizeof(XT) == 2 && CN_DW_DOT2) {
+    // ---- fp16 stream, round 5: input rows in PAIRS.  p[q] = (x[r][q], x[r + 1][q]) for even r is one register, the weights come as
+    // fp16 pairs of consecutive kernel rows -- ke[a][j] = (k[2a][j], k[2a + 1][j]), ko[a][j] = (k[2a + 1][j], k[2a + 2][j]): whichever
+    // parity r - oh has, the row pair meets a weight pair -- and `v_dot2_f32_f16` (exact fp16 products, fp32 sum) adds TWO taps per
+    // instruction: 28 instructions per output (21 dot2 + 7 single taps through v_fma_mix_f32: k[0][j] / k[6][j] are halves of ke[0][j] /
+    // ko[2][j]) against 49, + one v_perm per loaded pair.  The VALU-issue floor of the layer drops by 40 %; the only change in the
+    // arithmetic is the depthwise weight as an fp16 operand (2^-12 relative, listed in oracle/bf16_ref.py) and the order of an
+    // output's 49 terms.
+    static_assert(TH % 2 == 0, "row pairs");
+    cn_h2 ke[3][7], ko[3][7];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        ke[a][j] = __builtin_bit_cast(cn_h2, dw_wp[(a * 7 + j) * C + c]);
+        ko[a][j] = __builtin_bit_cast(cn_h2, dw_wp[(21 + a * 7 + j) * C + c]);
+      }
+    DW_STAMP(0)
+    auto fma_pair = [&](int r, const cn_h2 (&p)[10]) {   // rows r (even) and r + 1 of the halo
+#pragma unroll
+      for (int oh = 0; oh < TH; ++oh) {
+        const int i = r - oh;   // kernel row of halo row r for output row oh
+        if (i < -1 || i > 6) continue;
+#pragma unroll
+        for (int q = 0; q < 10; ++q)
+#pragma unroll
+          for (int ow = 0; ow < 4; ++ow) {
+            const int j = q - ow;
+            if (j < 0 || j > 6) continue;
+            if (i == -1) acc[oh][ow] = fmaf((float)p[q][1], (float)ke[0][j][0], acc[oh][ow]);
+            else if (i == 6) acc[oh][ow] = fmaf((float)p[q][0], (float)ko[2][j][1], acc[oh][ow]);
+            else if ((i & 1) == 0) acc[oh][ow] = __builtin_amdgcn_fdot2(p[q], ke[i >> 1][j], acc[oh][ow], false);
+            else acc[oh][ow] = __builtin_amdgcn_fdot2(p[q], ko[i >> 1][j], acc[oh][ow], false);
+          }
+      }
+    };
+    constexpr int NPR = (TH + 6) / 2;
+    if (interior) {
+      const XT* base = xb + ((size_t)(h0 - 3) * W + (w0 - 3)) * C;
+      auto load_pair = [&](int r, cn_h2 (&p)[10]) {
+        const XT* x0 = base + (size_t)r * W * C;
+        const XT* x1 = x0 + (size_t)W * C;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) p[q] = cn_h2{x0[q * C], x1[q * C]};
+      };
+      cn_h2 pa[10], pb[10];
+      load_pair(0, pa);
+#pragma unroll
+      for (int u = 0; u < NPR; u += 2) {   // two-pair software pipeline: the loads of pair u + 1 are in flight under the products of pair u
+        if (u + 1 < NPR) load_pair(2 * (u + 1), pb);
+        fma_pair(2 * u, pa);
+        if (u + 2 < NPR) load_pair(2 * (u + 2), pa);
+        if (u + 1 < NPR) fma_pair(2 * (u + 1), pb);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NPR; ++u) {
+        const int hh0 = h0 - 3 + 2 * u, hh1 = hh0 + 1;
+        const bool ok0 = (hh0 >= 0) && (hh0 < H), ok1 = (hh1 >= 0) && (hh1 < H);
+        const XT* x0 = xb + (size_t)min(max(hh0, 0), H - 1) * W * C;
+        const XT* x1 = xb + (size_t)min(max(hh1, 0), H - 1) * W * C;
+        XT v0[10], v1[10];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) v0[q] = x0[wcl[q]], v1[q] = x1[wcl[q]];
+        cn_h2 p[10];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) p[q] = cn_h2{(ok0 && wok[q]) ? v0[q] : (XT)0.f, (ok1 && wok[q]) ? v1[q] : (XT)0.f};
+        fma_pair(2 * u, p);
+      }
+    }
+  } else {
+  float k[49];
+#pragma unroll
+  for (int i = 0; i < 49; ++i) k[i] = dw_w[i * C + c];
+  DW_STAMP(0)
   auto fma_row = [&](int r, const XT (&v)[10]) {
 #pragma unroll
     for (int oh = 0; oh < TH; ++oh) {
@@ -339,6 +415,7 @@ __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(c
       fma_row(r, v);
     }
   }
+  }  // fp32 stream / CN_DW_DOT2 = 0
 #pragma unroll
   for (int oh = 0; oh < TH; ++oh)
 #pragma unroll
@@ -448,7 +525,7 @@ static int launch_dwconv(const XT* x, int B, int H, int W, const CnBlockW& bw, T
   const size_t smem = ((size_t)NPOS_ * DwTile<C, S, TH>::PITCH + NPOS_ * (NT_ / NPOS_) + 2 * NPOS_) * sizeof(float);
   CN_TRY(cn_configure_lds((const void*)cn_dwconv_ln_kernel<T, XT, C, S, TH>, (int)smem));
   hipLaunchKernelGGL((cn_dwconv_ln_kernel<T, XT, C, S, TH>), dim3((unsigned)(B * tiles_h * tiles_w)),
-                     dim3((C > 384 ? 384 : C) * S), smem, s, x, H, W, tiles_h, tiles_w, bw.dw_w, bw.dw_b, bw.ln_w, bw.ln_b, y,
+                     dim3((C > 384 ? 384 : C) * S), smem, s, x, H, W, tiles_h, tiles_w, bw.dw_w, bw.dw_wp, bw.dw_b, bw.ln_w, bw.ln_b, y,
 #ifdef CN_G2_PROF
                      getenv("CN_DW_DEBUG") ? atoi(getenv("CN_DW_DEBUG")) : 0);
 #else
@@ -475,9 +552,82 @@ static int launch_dwconv(const XT* x, int B, int H, int W, const CnBlockW& bw, T
 // an output are still added in the same (kh, kw) order, so the result does not depend on SPLIT.
 template <int C, int WW, int TH, int OW0, int NOW, typename XT>
 __device__ __forceinline__ void cn_fw_conv(const XT* __restrict__ xb /* + c */, int H, int h0,
-                                           const float* __restrict__ dw_w, float bias, int c, float* __restrict__ s_v,
-                                           int PITCH) {
+                                           const float* __restrict__ dw_w, const unsigned* __restrict__ dw_wp, float bias, int c,
+                                           float* __restrict__ s_v, int PITCH) {
   constexpr int Q0 = OW0 - 3 < 0 ? 0 : OW0 - 3, Q1 = OW0 + NOW + 3 > WW ? WW : OW0 + NOW + 3, NQ = Q1 - Q0;
+  if constexpr (sizeof(XT) == 2 && CN_DW_DOT2) {
+    // fp16 stream: input rows in pairs, two taps per v_dot2_f32_f16 (see cn_dwconv_ln_kernel)
+    static_assert(TH % 2 == 0, "row pairs");
+    cn_h2 ke[3][7], ko[3][7];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        ke[a][j] = __builtin_bit_cast(cn_h2, dw_wp[(a * 7 + j) * C + c]);
+        ko[a][j] = __builtin_bit_cast(cn_h2, dw_wp[(21 + a * 7 + j) * C + c]);
+      }
+    float acc[TH][NOW];
+#pragma unroll
+    for (int a = 0; a < TH; ++a)
+#pragma unroll
+      for (int e = 0; e < NOW; ++e) acc[a][e] = bias;
+    auto load_pair = [&](int r, cn_h2 (&p)[NQ]) {   // halo rows r (even) and r + 1; rows above / below the map are zeros (block-uniform)
+      const int hh0 = h0 - 3 + r, hh1 = hh0 + 1;
+      XT v0[NQ], v1[NQ];
+      if (hh0 >= 0 && hh0 < H) {
+        const XT* xr = xb + (size_t)hh0 * WW * C;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v0[q] = xr[(Q0 + q) * C];
+      } else {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v0[q] = (XT)0.f;
+      }
+      if (hh1 >= 0 && hh1 < H) {
+        const XT* xr = xb + (size_t)hh1 * WW * C;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v1[q] = xr[(Q0 + q) * C];
+      } else {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v1[q] = (XT)0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) p[q] = cn_h2{v0[q], v1[q]};
+    };
+    auto fma_pair = [&](int r, const cn_h2 (&p)[NQ]) {
+#pragma unroll
+      for (int oh = 0; oh < TH; ++oh) {
+        const int i = r - oh;
+        if (i < -1 || i > 6) continue;
+#pragma unroll
+        for (int ow = 0; ow < NOW; ++ow)
+#pragma unroll
+          for (int j = 0; j < 7; ++j) {
+            const int q = OW0 + ow + j - 3;
+            if (q < 0 || q >= WW) continue;  // zero padding left / right of the map: the tap does not exist
+            const cn_h2 pv = p[q - Q0];
+            if (i == -1) acc[oh][ow] = fmaf((float)pv[1], (float)ke[0][j][0], acc[oh][ow]);
+            else if (i == 6) acc[oh][ow] = fmaf((float)pv[0], (float)ko[2][j][1], acc[oh][ow]);
+            else if ((i & 1) == 0) acc[oh][ow] = __builtin_amdgcn_fdot2(pv, ke[i >> 1][j], acc[oh][ow], false);
+            else acc[oh][ow] = __builtin_amdgcn_fdot2(pv, ko[i >> 1][j], acc[oh][ow], false);
+          }
+      }
+    };
+    constexpr int NPR = (TH + 6) / 2;
+    cn_h2 pa[NQ], pb[NQ];
+    load_pair(0, pa);
+#pragma unroll
+    for (int u = 0; u < NPR; u += 2) {
+      if (u + 1 < NPR) load_pair(2 * (u + 1), pb);
+      fma_pair(2 * u, pa);
+      if (u + 2 < NPR) load_pair(2 * (u + 2), pa);
+      if (u + 1 < NPR) fma_pair(2 * (u + 1), pb);
+    }
+#pragma unroll
+    for (int oh = 0; oh < TH; ++oh)
+#pragma unroll
+      for (int ow = 0; ow < NOW; ++ow) s_v[(oh * WW + OW0 + ow) * PITCH + c] = acc[oh][ow];
+    return;
+  }
   float k[49];
 #pragma unroll
   for (int i = 0; i < 49; ++i) k[i] = dw_w[i * C + c];
@@ -529,7 +679,7 @@ __device__ __forceinline__ void cn_fw_conv(const XT* __restrict__ xb /* + c */, 
 
 template <typename T, typename XT, int C, int WW, int TH, int SPLIT>
 __global__ __launch_bounds__(C* SPLIT > 384 ? 768 : 384) void cn_dwconv_ln_fw_kernel(const XT* __restrict__ x, int H, int tiles_h,
-                                                              const float* __restrict__ dw_w /*[49][C]*/,
+                                                              const float* __restrict__ dw_w /*[49][C]*/, const unsigned* __restrict__ dw_wp,
                                                               const float* __restrict__ dw_b,
                                                               const float* __restrict__ ln_w,
                                                               const float* __restrict__ ln_b, T* __restrict__ y) {
@@ -548,13 +698,13 @@ __global__ __launch_bounds__(C* SPLIT > 384 ? 768 : 384) void cn_dwconv_ln_fw_ke
 
   if constexpr (SPLIT == 1) {
 #pragma unroll 1
-    for (int c = tid; c < C; c += CT) cn_fw_conv<C, WW, TH, 0, WW, XT>(xb0 + c, H, h0, dw_w, dw_b[c], c, s_v, PITCH);
+    for (int c = tid; c < C; c += CT) cn_fw_conv<C, WW, TH, 0, WW, XT>(xb0 + c, H, h0, dw_w, dw_wp, dw_b[c], c, s_v, PITCH);
   } else {
     const int c = tid < C ? tid : tid - C;  // waves 0-5: left half, waves 6-11: right half (wave-uniform)
     if (tid < C)
-      cn_fw_conv<C, WW, TH, 0, WW / 2, XT>(xb0 + c, H, h0, dw_w, dw_b[c], c, s_v, PITCH);
+      cn_fw_conv<C, WW, TH, 0, WW / 2, XT>(xb0 + c, H, h0, dw_w, dw_wp, dw_b[c], c, s_v, PITCH);
     else
-      cn_fw_conv<C, WW, TH, WW / 2, WW / 2, XT>(xb0 + c, H, h0, dw_w, dw_b[c], c, s_v, PITCH);
+      cn_fw_conv<C, WW, TH, WW / 2, WW / 2, XT>(xb0 + c, H, h0, dw_w, dw_wp, dw_b[c], c, s_v, PITCH);
   }
   __syncthreads();
   // LayerNorm statistics: wave per position, C / 64 values per lane, two positions per iteration
@@ -636,7 +786,7 @@ static int launch_dwconv_fw(const XT* x, int B, int H, const CnBlockW& bw, T* y,
   const size_t smem = ((size_t)TH * WW * (C + 4) + 2 * TH * WW) * sizeof(float);
   CN_TRY(cn_configure_lds((const void*)cn_dwconv_ln_fw_kernel<T, XT, C, WW, TH, SPLIT>, (int)smem));
   hipLaunchKernelGGL((cn_dwconv_ln_fw_kernel<T, XT, C, WW, TH, SPLIT>), dim3((unsigned)(B * tiles_h)), dim3(C * SPLIT > 384 ? 768 : 384), smem, s, x, H,
-                     tiles_h, bw.dw_w, bw.dw_b, bw.ln_w, bw.ln_b, y);
+                     tiles_h, bw.dw_w, bw.dw_wp, bw.dw_b, bw.ln_w, bw.ln_b, y);
   CN_LAUNCH_CHECK();
   return CN_OK;
 }

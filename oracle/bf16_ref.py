@@ -14,7 +14,8 @@ Rounding points (conette-audio-captioning_amd/csrc):
   decoder: see ``decoder_forward_bf16``.
   residual stream (round 5): inside ``operands(...)`` every tensor the 16-bit precisions' kernels STORE to the stream -- the
       stem's output, every block's x', every downsample layer's output -- is rounded to IEEE fp16 (``res16``; csrc/common.h XT);
-      the depthwise convolution reads those fp16 values as exact operands of its fp32 fma (v_fma_mix_f32), so nothing else changes.
+      the depthwise convolution reads those fp16 values as exact operands and -- since the second half of round 5, when it adds two taps
+      per v_dot2_f32_f16 -- its 7 x 7 weights as fp16 operands too (``res16`` of dwconv.weight: 2^-12 relative); products exact, sums fp32.
 The GPU evaluates GELU through approximations that are exact to <= 5.5e-5 absolute (bf16) / 8.6e-7 (fp16) in the fused MLP
 (common.h cn_gelu_e1) and 1.5e-7 elsewhere (A&S 7.1.26, common.h); the oracle uses the exact erf form, so a handful of hidden
 values per million round to the neighbouring bf16.
@@ -67,7 +68,7 @@ def operands(kind: str):
 def convnext_block_bf16(w: Weights, prefix: str, x: Tensor, folded: bool) -> Tensor:
     """nn/encoders/convnext.py:61-74 with bf16 GEMM operands.  x: (B, C, H, W) fp32 values of the residual stream."""
     c = x.shape[1]
-    y = F.conv2d(x, w[prefix + "dwconv.weight"], w[prefix + "dwconv.bias"], padding=3, groups=c)
+    y = F.conv2d(x, res16(w[prefix + "dwconv.weight"]), w[prefix + "dwconv.bias"], padding=3, groups=c)
     y = y.permute(0, 2, 3, 1)
     y = bf16(F.layer_norm(y, (c,), w[prefix + "norm.weight"], w[prefix + "norm.bias"], 1e-6))
     h = F.linear(y, bf16(w[prefix + "pwconv1.weight"])) + w[prefix + "pwconv1.bias"]

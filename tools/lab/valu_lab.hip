@@ -38,6 +38,11 @@ __global__ void k(unsigned long long* out, float seed, int iters) {
         if (KIND == 10) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(d));
         if (KIND == 11) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(d));
         if (KIND == 12) asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(d));
+        if (KIND == 13) {  // 3 dot2 : 1 fma_mix -- the row-paired depthwise conv (7 taps of a column in 4 instructions)
+          if ((i & 3) == 3) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]" : "+v"(a[i]) : "v"(c), "v"(d));
+          else asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(c), "v"(d));
+        }
+        if (KIND == 14) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,1,0]" : "+v"(a[i]) : "v"(c), "v"(d));  // both sources f16
         if (KIND == 7) {  // 2 trans : 5 regular, as in the sigmoid GELU
           if ((i & 7) == 2) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
           else if ((i & 7) == 5) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
@@ -58,10 +63,10 @@ int main() {
   unsigned long long* out;
   CK(hipMalloc(&out, 16));
   const char* names[] = {"v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "v_min_f32", "v_cvt_pk_bf16_f32", "v_pk_mul_f32", "mix 6 fma : 1 exp : 1 rcp",
-                         "v_dot2_f32_f16", "v_fma_mix_f32", "v_perm_b32", "v_pk_fma_f16", "v_dot2c_f32_f16"};
-  void (*ks[])(unsigned long long*, float, int) = {k<0>, k<1>, k<2>, k<3>, k<4>, k<5>, k<6>, k<7>, k<8>, k<9>, k<10>, k<11>, k<12>};
-  for (int kind = 0; kind < 13; ++kind)
-    for (int wps : {1, 2, 4}) {
+                         "v_dot2_f32_f16", "v_fma_mix_f32", "v_perm_b32", "v_pk_fma_f16", "v_dot2c_f32_f16", "3 dot2 : 1 fma_mix", "v_fma_mix_f32 (f16 x f16)"};
+  void (*ks[])(unsigned long long*, float, int) = {k<0>, k<1>, k<2>, k<3>, k<4>, k<5>, k<6>, k<7>, k<8>, k<9>, k<10>, k<11>, k<12>, k<13>, k<14>};
+  for (int kind = 0; kind < 15; ++kind)
+    for (int wps : {1, 2, 4, 5}) {
       const int iters = 4096;
       hipEvent_t e0, e1;
       hipEventCreate(&e0);
