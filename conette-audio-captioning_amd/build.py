@@ -49,6 +49,8 @@ for _k in ("CN_DW96_S", "CN_DW96_TH", "CN_DW192_S", "CN_DW192_TH"):   # A/B buil
         FLAGS.append(f"-D{_k}=" + os.environ[_k])
 if os.environ.get("CN_DW_DOT2"):    # A/B build: 0 = the depthwise conv of the fp16 stream with one v_fma_mix_f32 per tap (encoder.hip)
     FLAGS.append("-DCN_DW_DOT2=" + os.environ["CN_DW_DOT2"])
+if os.environ.get("CN_FW_SPLIT"):   # A/B build: threads per channel of the full-width depthwise kernel at C = 384 (encoder.hip: 2)
+    FLAGS.append("-DCN_FW_SPLIT=" + os.environ["CN_FW_SPLIT"])
 if os.environ.get("CN_FW_TH"):      # A/B build: output rows per block of the full-width depthwise kernel at C = 384 (encoder.hip: 4)
     FLAGS.append("-DCN_FW_TH=" + os.environ["CN_FW_TH"])
 
