@@ -29,8 +29,7 @@ extern "C" {
 /* precision of GEMM operands / intermediate activations.  Accumulation is always fp32 and the decoder's residual stream is
  * always fp32; the ENCODER's residual stream is IEEE fp16 in the two 16-bit precisions (BF16, F16) since round 5 -- 11
  * significant bits, |x| <= 65504 required: frame embeddings 4.43e-3 -> 4.48e-3 (BF16) and 5.4e-4 -> 8.5e-4 (F16) rel. rms off the
- * fp32 reference for 10 C instead of 16 C bytes moved per position and block -- and fp32 in the other precisions.  In the same two
- * precisions the depthwise 7 x 7 weights are fp16 operands as well (two taps per v_dot2_f32_f16: 4.49e-3 / 8.8e-4) */
+ * fp32 reference for 10 C instead of 16 C bytes moved per position and block -- and fp32 in the other precisions */
 #define CONETTE_PREC_F32 0  /* v_mfma_f32_16x16x4_f32: exact-fp32 parity mode          */
 #define CONETTE_PREC_BF16 1 /* v_mfma_f32_16x16x32_bf16: throughput mode (BASELINE cfg) */
 #define CONETTE_PREC_F16X2 2 /* "exact": every GEMM operand an fp16 hi + lo pair (22 bits), products as three
