@@ -72,7 +72,7 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: CPU self-test of the launcher / sharding / gather path (no GPU work, no timing)")
     ap.add_argument("--master-port", type=int, default=0)
-    ap.add_argument("--also", default="bf16:e2,bf16:g1,bf16+f16dec,f16,mixed16,exact",
+    ap.add_argument("--also", default="bf16:e2,bf16:g1,bf16+f16dec,f16,mixed16,exact,certified,certified@peaked",
                     help="N = 1, fixed workload, bf16 only: after the run, the SAME pipelined benchmark at these precisions (one child "
                          "process each, 3 windows, no CPU / parity legs), reported under `also_pipelined` ('' = skip); `PREC:g1` = that "
                          "precision with one beam search per batch (CN_DEC_GROUP=1) instead of the grouped decode")
@@ -321,6 +321,21 @@ def also_pipelined(args, batch):
     import subprocess
     out = {}
     for name in [n for n in args.also.split(",") if n]:
+        if name.startswith("certified"):       # "certified[:base][@peaked]": the id-certified pipeline (bench_certified.py, round 6)
+            spec, _, ckpt = name.partition("@")
+            cmd = [sys.executable, os.path.join(ROOT, "bench_certified.py"), "--base", spec.partition(":")[2] or "f16", "--checkpoint",
+                   ckpt or "default", "--steps", str(max(4, args.steps // 4 * 4)), "--repeat", "3", "--batch", str(batch), "--beam", str(args.beam)]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+                d = json.loads(r.stdout.strip().splitlines()[-1])
+                out[name] = {k: d[k] for k in ("value", "ms_per_step", "precision", "checkpoint", "recompute_fraction",
+                                               "rerun_fraction_with_padding", "tolerance", "pipeline_consistent", "pipeline_steps_checked",
+                                               "ids_identical_to_exact")}
+                out[name]["clips_per_sec"] = out[name].pop("value")
+                out[name]["windows_clips_per_sec"] = d["windows"]["clips_per_sec"]
+            except Exception as e:
+                out[name] = {"error": f"{type(e).__name__}: {e}"[:300], "stderr": (r.stderr[-300:] if "r" in dir() else None)}
+            continue
         prec, _, opt = name.partition(":")     # "bf16:g1" = the bf16 pipeline with ONE beam search per batch (round 3's schedule)
         env = dict(os.environ)
         if opt == "g1":
@@ -387,6 +402,22 @@ def parity_report(args, Engine, eng, sd, dev, w0, lens0, bos0, forbid, t_audio, 
                 err = (g - ofe)
                 vo[name]["frame_embs_rel_rms"] = round(float(err.pow(2).mean().sqrt() / ofe.pow(2).mean().sqrt()), 7)
                 vo[name]["frame_embs_max_abs"] = round(float(err.abs().max()), 6)
+        # the certified precision (round 6): the fp16 pipeline + device-side margins, uncertified clips re-run through the exact
+        # context -- its ids must be the oracle's on EVERY clip (tests/test_gpu_certified.py asserts it; here it is reported)
+        try:
+            ce = Engine(sd, precision="certified", device=dev)
+            cfe = ce.encode(wv)[0].clone()
+            cd = {"base": ce.base_precision}
+            for bm_ in (1, beam):
+                o = ce.generate_certified(wv, cfe, ln, bs, forbid, bm_, min_pred, max_pred)
+                key = "greedy" if bm_ == 1 else f"beam{beam}"
+                cd[key] = compare_ids(_ids(o), o["best_lprobs"].cpu(), ora["greedy" if bm_ == 1 else "beam"],
+                                      None if bm_ == 1 else ora["beam_lp"], ora["greedy_margin" if bm_ == 1 else "beam_margin"])
+                cd[key]["recomputed_clips"] = [int(o["recomputed"].sum()), n]
+            vo["certified"] = cd
+            del ce
+        except Exception as e_:
+            vo["certified"] = {"error": f"{type(e_).__name__}: {e_}"[:300]}
         par["vs_oracle"] = vo
     if "fp32" in engines:  # the library's fp32 mode as the reference (its ids equal the oracle's above), on --parity-batches batches
         from conette_amd import synth as _synth
@@ -429,14 +460,19 @@ def parity_report(args, Engine, eng, sd, dev, w0, lens0, bos0, forbid, t_audio, 
         import numpy as np
         from conette_amd import synth as _synth
         sd_pk = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in _synth.synth_state_dict(recipe="peaked").items()}
-        pk_eng = {name: Engine(sd_pk, precision=name, device=dev) for name in ("exact", "bf16", "f16")}
+        pk_eng = {name: Engine(sd_pk, precision=name, device=dev) for name in ("exact", "bf16", "f16", "certified")}
+        pk_re = {}
         pk_out = {}
         for bi in range(max(1, args.parity_batches)):
             wv_b = wv if bi == 0 else torch.from_numpy(_synth.synth_waveforms(n, wv.shape[1], 1234 + 7919 * bi)).to(dev)
             for name, e in pk_eng.items():
                 fe_pk = e.encode(wv_b)[0].clone()
                 for bm_ in (1, beam):
-                    o = e.decode(fe_pk, ln, bs, forbid, bm_, min_pred, max_pred)
+                    if name == "certified":
+                        o = e.generate_certified(wv_b, fe_pk, ln, bs, forbid, bm_, min_pred, max_pred)
+                        pk_re[bm_] = pk_re.get(bm_, 0) + int(o["recomputed"].sum())
+                    else:
+                        o = e.decode(fe_pk, ln, bs, forbid, bm_, min_pred, max_pred)
                     cur = (_ids(o), o["best_lprobs"].cpu())
                     if (name, bm_) in pk_out:
                         a = pk_out[(name, bm_)]
@@ -450,10 +486,12 @@ def parity_report(args, Engine, eng, sd, dev, w0, lens0, bos0, forbid, t_audio, 
         torch.cuda.synchronize(dev)
         pk = {"reference": "the library's exact precision on the same clips (ids = the CPU oracle's on the committed peaked fixtures)",
               "checkpoint": "conette_amd.synth.synth_state_dict(recipe='peaked')"}
-        for name in ("bf16", "f16"):
+        for name in ("bf16", "f16", "certified"):
             pk[name] = {("greedy" if bm_ == 1 else f"beam{beam}"): compare_ids(pk_out[(name, bm_)][0], pk_out[(name, bm_)][1],
                                                                                 pk_out[("exact", bm_)][0], pk_out[("exact", bm_)][1])
                         for bm_ in (1, beam)}
+        for bm_ in (1, beam):
+            pk["certified"]["greedy" if bm_ == 1 else f"beam{beam}"]["recomputed_clips"] = [pk_re.get(bm_, 0), pk_out[("exact", bm_)][0].shape[0]]
         par["peaked_checkpoint"] = pk
         del pk_eng
     except Exception as e_:   # (reported, never fatal: the leg is additional evidence)

@@ -32,10 +32,12 @@ class BaselinePLM:
     """Inference surface of the reference's ``BaselinePLM`` over a decoder-only HIP context."""
 
     def __init__(self, state_dict: Mapping[str, Any], *, tokenizer_state: Optional[Mapping[str, Any]] = None,
-                 beam_size: int = 2, min_pred_size: int = 3, max_pred_size: Optional[int] = None, d_model: int = 256,
+                 beam_size: int = 10, min_pred_size: int = 3, max_pred_size: Optional[int] = None, d_model: int = 256,
                  nhead: int = 8, num_decoder_layers: int = 6, dim_feedforward: int = 2048, proj_name: str = "lin768",
                  acti_name: str = "gelu", precision: str = "bf16", device: Union[str, torch.device, None] = "cuda") -> None:
-        # (constructor defaults: baseline.py:42-52 -- beam_size 2, min_pred_size 3, max_pred_size from the tokenizer)
+        # (constructor defaults of the reference's BaselinePLM.__init__, pl_modules/baseline.py:36-52: proj_name "lin768",
+        # min_pred_size 3, max_pred_size None -> the tokenizer's longest sentence (:88-99), beam_size 10, nhead 8, d_model 256,
+        # num_decoder_layers 6, dim_feedforward 2048, acti_name "gelu"; tests/test_baseline_plm.py holds them against that list)
         if proj_name != "lin768" or acti_name != "gelu":
             raise ValueError(f"Unsupported hyper-parameters for the MI355X path: proj_name={proj_name!r}, acti_name={acti_name!r} "
                              "(expected 'lin768' and 'gelu'; lin2048 belongs to the PANN encoders, out of scope)")
@@ -148,7 +150,10 @@ class BaselinePLM:
             return self.engine.greedy(fe, lens, bos, forbid, min_pred, max_pred)["logits"].permute(0, 2, 1)
         if decode_method == "generate":
             beam = int(kwargs.get("beam_size", hp["beam_size"]))
-            res = self.engine.decode(fe, lens, bos, forbid, beam, min_pred, max_pred)
+            if self.engine.certified:   # given embeddings: uncertified clips re-run through the exact DECODER
+                res = self.engine.generate_certified(None, fe, lens, bos, forbid, beam, min_pred, max_pred)
+            else:
+                res = self.engine.decode(fe, lens, bos, forbid, beam, min_pred, max_pred)
             pred_size, best_maxlen = (int(v) for v in res["sizes"].tolist())
             return (res["best_preds"][:, :best_maxlen].to(torch.long).contiguous(), res["best_lprobs"],
                     res["mult_preds"][:, :, :pred_size].to(torch.long).contiguous(), res["mult_lprobs"])

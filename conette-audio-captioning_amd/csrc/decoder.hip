@@ -18,7 +18,7 @@
 #include "gemm2.h"
 #include "dec_ffn.h"
 
-#define CN_MAX_BEAM 8
+#define CN_MAX_BEAM 16  // beams 1..8: the register-resident step kernel; 9..16 (BaselinePLM's default is 10, baseline.py:47): the generic one
 #define CN_MAX_PRED 64
 #define FF2_SPLITS 8
 static int ff2_splits_default() { return 4; }  // split-K slabs of the unfused FFN2 GEMM at small R
@@ -33,7 +33,7 @@ __global__ void cn_cvt_kernel(const float* __restrict__ in, T* __restrict__ out,
 __global__ void cn_init_state_kernel(int B, int beam, int maxp, const int* __restrict__ bos, int* n_active, int* slot,
                                      float* sum_lp, int* prefix, int* anc, int* cur_tok, int* out_preds,
                                      float* out_avg, int* out_len, int* sizes, int pad_id, int* trace_sel,
-                                     float* trace_val, int* live) {
+                                     float* trace_val, int* live, float* margins) {
   const int R = B * beam;
   const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
   for (int i = gid; i < CN_MAX_PRED + 2; i += gsz) live[i] = 0;
@@ -55,6 +55,8 @@ __global__ void cn_init_state_kernel(int B, int beam, int maxp, const int* __res
     for (int i = gid; i < maxp * R * 2; i += gsz) trace_sel[i] = -1;
   if (trace_val)
     for (int i = gid; i < maxp * R; i += gsz) trace_val[i] = 0.f;
+  if (margins)  // a step a clip does not take (it has finished) decides nothing: +inf
+    for (int i = gid; i < B * (maxp + 1); i += gsz) margins[i] = INFINITY;
 }
 
 // x = E[tok] * sqrt(d) + PE[step]   (aac_tfmer.py:100-106); d == 256, one wave per row
@@ -285,17 +287,28 @@ __device__ __forceinline__ ValIdx vi_wave(ValIdx x) {
   return x;
 }
 
+// The effective margin of one top-k call (round 6, precision "certified"): how far the call is from ANY other outcome -- the gap
+// between the last pick and the first rejected candidate, and the gaps between consecutive picks (their order decides which
+// hypothesis lands in which slot: beam.py:165-169).  A 16-bit search whose every call (and whose final best-beam choice) has a
+// margin above twice the precision's worst candidate error has taken the decisions an exact search takes.
+__device__ __forceinline__ float cn_step_margin(const float* selv, int k, float runner_up) {
+  float m = selv[k - 1] - runner_up;
+  for (int c = 0; c + 1 < k; ++c) m = fminf(m, selv[c] - selv[c + 1]);
+  return m;   // NaN (-inf - -inf: fewer finite candidates than picks) reads as "not certified" on the host
+}
+
 __global__ __launch_bounds__(256) void cn_search_step_kernel(float* __restrict__ logits, int ldv, int V, int beam,
                                                              int maxp, int step, int min_pred, int eos_id,
                                                              const uint8_t* __restrict__ forbid, int* n_active,
                                                              int* slot, float* sum_lp, int* prefix, int* anc,
                                                              int* cur_tok, int* out_preds, float* out_avg,
-                                                             int* out_len, int* trace_sel, float* trace_val, int* live) {
+                                                             int* out_len, int* trace_sel, float* trace_val, int* live,
+                                                             float* margins) {
   __shared__ float s_red[8];
   __shared__ ValIdx s_vi[4];
   __shared__ float s_mx[CN_MAX_BEAM], s_lg[CN_MAX_BEAM], s_base[CN_MAX_BEAM];
-  __shared__ float s_selv[CN_MAX_BEAM];
-  __shared__ int s_self[CN_MAX_BEAM];
+  __shared__ float s_selv[CN_MAX_BEAM + 1];
+  __shared__ int s_self[CN_MAX_BEAM + 1];
   __shared__ int s_prefix[CN_MAX_BEAM][CN_MAX_PRED + 1];
   __shared__ int s_anc[CN_MAX_BEAM][CN_MAX_PRED];
   __shared__ int s_slot[CN_MAX_BEAM];
@@ -346,8 +359,9 @@ __global__ __launch_bounds__(256) void cn_search_step_kernel(float* __restrict__
     }
     __syncthreads();
   }
-  // top-k over the nrows * V candidates, k rounds of block arg-max (ties -> lowest flat index)
-  for (int c = 0; c < k; ++c) {
+  // top-k over the nrows * V candidates, k rounds of block arg-max (ties -> lowest flat index); with a margin output one
+  // more round finds the first rejected candidate
+  for (int c = 0; c < k + (margins != nullptr ? 1 : 0); ++c) {
     ValIdx best{-INFINITY, 0x7fffffff};
     for (int p = 0; p < nrows; ++p) {
       const float* lg = logits + (size_t)(rb + p) * ldv;
@@ -390,6 +404,7 @@ __global__ __launch_bounds__(256) void cn_search_step_kernel(float* __restrict__
     }
     n_active[b] = cnt;
     if (cnt > 0) atomicAdd(&live[step + 1], cnt);  // rows that search on: gates the next step's kernels
+    if (margins) margins[(size_t)b * (maxp + 1) + step] = cn_step_margin(s_selv, k, s_selv[k]);
   }
   __syncthreads();
   for (int c = 0; c < k; ++c) {
@@ -437,8 +452,9 @@ __global__ __launch_bounds__(S3_T) void cn_search_step3_kernel(const float* __re
                                                                int* slot, float* sum_lp, int* prefix, int* anc,
                                                                int* cur_tok, int* out_preds, float* out_avg,
                                                                int* out_len, int* trace_sel, float* trace_val, int dbg,
-                                                               int* live) {
+                                                               int* live, float* margins) {
   __shared__ float s_redm[NR][16], s_reds[NR][16];
+  __shared__ float s_ru[16];
   __shared__ ValIdx s_cand[16][CN_MAX_BEAM];
   __shared__ float s_base[CN_MAX_BEAM];
   __shared__ float s_selv[CN_MAX_BEAM];
@@ -610,6 +626,33 @@ __global__ __launch_bounds__(S3_T) void cn_search_step3_kernel(const float* __re
   }
   __syncthreads();
   S3_STAMP(6)
+  if (margins != nullptr) {  // the first rejected candidate: the best of everything the k picks left (same expression, same bits)
+    float ru = -INFINITY;
+#pragma unroll
+    for (int p = 0; p < NR; ++p)
+      if (p < nrows) {
+        const float base = s_base[p];
+#pragma unroll
+        for (int sl = 0; sl < VPT; ++sl) {
+          const int v = sl * S3_T + tid;
+          float cand = (val[p][sl] - rmx[p]) - rlg[p];
+          if (step != 0) cand = base + cand;
+          const int flat = p * V + v;
+          bool taken = v >= V;
+          for (int c = 0; c < k; ++c) taken |= (s_self[c] == flat);
+          if (!taken) ru = fmaxf(ru, cand);
+        }
+      }
+    ru = cn_wave_max_dpp(ru);
+    if (lane == 0) s_ru[wv] = ru;
+    __syncthreads();
+    if (tid == 0) {
+      ru = s_ru[0];
+#pragma unroll
+      for (int w = 1; w < 16; ++w) ru = fmaxf(ru, s_ru[w]);
+      margins[(size_t)b * (maxp + 1) + step] = cn_step_margin(s_selv, k, ru);
+    }
+  }
   // bookkeeping (beam.py:164-203)
   if (tid < k) {
     const size_t ti = ((size_t)step * gridDim.x + b) * beam + tid;
@@ -660,7 +703,7 @@ __global__ __launch_bounds__(S3_T) void cn_search_step3_kernel(const float* __re
 __global__ void cn_finalize_kernel(int B, int beam, int maxp, int eos_id, const int* __restrict__ out_preds,
                                    const float* __restrict__ out_avg, const int* __restrict__ out_len,
                                    int* __restrict__ best_preds, float* __restrict__ best_lp,
-                                   int* __restrict__ eos_idx, int* sizes) {
+                                   int* __restrict__ eos_idx, int* sizes, float* __restrict__ margins) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   int best = 0, mlen = 0;
@@ -674,6 +717,12 @@ __global__ void cn_finalize_kernel(int B, int beam, int maxp, int eos_id, const 
   }
   atomicMax(&sizes[0], mlen);
   best_lp[b] = bv;
+  if (margins) {  // how far the best hypothesis is from the second best (beam.py:214-217 takes the first maximum)
+    float second = -INFINITY;
+    for (int s = 0; s < beam; ++s)
+      if (s != best) second = fmaxf(second, out_avg[b * beam + s]);
+    margins[(size_t)b * (maxp + 1) + maxp] = bv - second;
+  }
   int e = -1;
   for (int j = 0; j < maxp; ++j) {
     const int t = out_preds[((size_t)b * beam + best) * maxp + j];
@@ -816,7 +865,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
                        float* best_lprobs, int32_t* mult_preds, float* mult_lprobs, int32_t* out_sizes,
                        float* step0_logits, int32_t* trace_sel, float* trace_val, char* wsp, hipStream_t s,
                        const int32_t* force_caps = nullptr, float* force_logits = nullptr,
-                       float* greedy_logits = nullptr) {
+                       float* greedy_logits = nullptr, float* margins = nullptr) {
   const conette_config& cfg = ctx->cfg;
   const int d = cfg.d_model, NL = cfg.n_layers, R = B * beam, V = cfg.vocab_size, dff = cfg.d_ff;
   DecWs w = dec_ws(ctx, B, Ta, beam, maxp, wsp);
@@ -846,7 +895,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
   }
   hipLaunchKernelGGL(cn_init_state_kernel, dim3(64), dim3(256), 0, s, B, beam, maxp, bos_ids, w.n_active, w.slot,
                      w.sum_lp, w.prefix, w.anc, w.cur_tok, mult_preds, mult_lprobs, w.out_len, out_sizes, cfg.pad_id,
-                     trace_sel, trace_val, w.live);
+                     trace_sel, trace_val, w.live, margins);
   CN_LAUNCH_CHECK();
   if (forcing) {
     hipLaunchKernelGGL(cn_force_init_kernel, dim3(cn_cdiv(B, 64)), dim3(64), 0, s, force_caps, B, maxp, cfg.pad_id,
@@ -1067,11 +1116,11 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
       CN_LAUNCH_CHECK();
     }
     CnProfScope ps_search(ctx, CONETTE_PROF_SEARCH, s);
-    if (V <= S3_T * S3_VPT) {  // register-resident step (one block of 1024 threads per clip)
+    if (V <= S3_T * S3_VPT && beam <= 8) {  // register-resident step (one block of 1024 threads per clip)
 #define S3_LAUNCH(NR_, VPT_)                                                                                          \
   hipLaunchKernelGGL((cn_search_step3_kernel<NR_, VPT_>), dim3(B), dim3(S3_T), 0, s, w.logits, w.ldv, V, beam, maxp,  \
                      step, min_pred, cfg.eos_id, forbid, w.n_active, w.slot, w.sum_lp, w.prefix, w.anc, w.cur_tok,    \
-                     mult_preds, mult_lprobs, w.out_len, trace_sel, trace_val, db_debug, w.live)
+                     mult_preds, mult_lprobs, w.out_len, trace_sel, trace_val, db_debug, w.live, margins)
       const int vpt = cn_cdiv(V, S3_T);
       if (beam <= 4) {
         if (vpt <= 2) S3_LAUNCH(4, 2);
@@ -1083,16 +1132,16 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
         else S3_LAUNCH(8, 8);
       }
 #undef S3_LAUNCH
-    } else {  // vocabularies beyond 8192 entries: the generic step (masking in place, top-k over global memory)
+    } else {  // vocabularies beyond 8192 entries, beams beyond 8: the generic step (masking in place, top-k over global memory)
       hipLaunchKernelGGL(cn_search_step_kernel, dim3(B), dim3(256), 0, s, w.logits, w.ldv, V, beam, maxp, step,
                          min_pred, cfg.eos_id, forbid, w.n_active, w.slot, w.sum_lp, w.prefix, w.anc, w.cur_tok,
-                         mult_preds, mult_lprobs, w.out_len, trace_sel, trace_val, w.live);
+                         mult_preds, mult_lprobs, w.out_len, trace_sel, trace_val, w.live, margins);
     }
     CN_LAUNCH_CHECK();
   }
   if (forcing) return CN_OK;
   hipLaunchKernelGGL(cn_finalize_kernel, dim3(cn_cdiv(B, 64)), dim3(64), 0, s, B, beam, maxp, cfg.eos_id, mult_preds,
-                     mult_lprobs, w.out_len, best_preds, best_lprobs, w.eos_idx, out_sizes);
+                     mult_lprobs, w.out_len, best_preds, best_lprobs, w.eos_idx, out_sizes, margins);
   CN_LAUNCH_CHECK();
   hipLaunchKernelGGL(cn_finalize2_kernel, dim3(1), dim3(256), 0, s, B, w.eos_idx, out_sizes);
   CN_LAUNCH_CHECK();
@@ -1101,7 +1150,7 @@ static int decode_impl(conette_ctx* ctx, const float* frame_embs, const int32_t*
 
 // ---- hipGraph replay of the (static) decode launch sequence ---------------------------------------
 struct DecKey {
-  const void *fe, *lens, *bos, *forbid, *bp, *bl, *mp, *ml, *sz, *s0, *ts, *tv, *ws;
+  const void *fe, *lens, *bos, *forbid, *bp, *bl, *mp, *ml, *sz, *s0, *ts, *tv, *mg, *ws;
   int B, Ta, beam, min_pred, maxp;
   bool operator==(const DecKey& o) const { return memcmp(this, &o, sizeof(DecKey)) == 0; }
 };
@@ -1196,8 +1245,8 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
                               const int32_t* bos_ids, const uint8_t* forbid_mask, int32_t batch, int32_t t_audio,
                               int32_t beam, int32_t min_pred, int32_t max_pred, int32_t* best_preds,
                               float* best_lprobs, int32_t* mult_preds, float* mult_lprobs, int32_t* out_sizes,
-                              float* step0_logits, int32_t* trace_sel, float* trace_val, void* workspace,
-                              size_t workspace_bytes, void* stream) {
+                              float* step0_logits, int32_t* trace_sel, float* trace_val, float* margins,
+                              void* workspace, size_t workspace_bytes, void* stream) {
   if (!ctx || !frame_embs || !frame_lens || !bos_ids || !best_preds || !best_lprobs || !mult_preds || !mult_lprobs ||
       !out_sizes || !workspace || batch <= 0 || t_audio <= 0) {
     cn_set_error("decode: bad argument");
@@ -1225,7 +1274,7 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
   auto run = [&]() -> int {
     CN_BY_PRECISION(ctx, decode_impl<OT>(ctx, frame_embs, frame_lens, bos_ids, forbid_mask, batch, t_audio, beam, min_pred,
                                  max_pred, best_preds, best_lprobs, mult_preds, mult_lprobs, out_sizes, step0_logits,
-                                 trace_sel, trace_val, (char*)workspace, s));
+                                 trace_sel, trace_val, (char*)workspace, s, nullptr, nullptr, nullptr, margins));
   };
   DecGraphCache* cache = graph_cache(ctx, true);
   const uint32_t dec_classes = (1u << CONETTE_PROF_DEC_PREPARE) | (1u << CONETTE_PROF_DEC_GEMM) |
@@ -1237,7 +1286,7 @@ extern "C" int conette_decode(conette_ctx* ctx, const float* frame_embs, const i
   memset(&key, 0, sizeof(key));
   key.fe = frame_embs, key.lens = frame_lens, key.bos = bos_ids, key.forbid = forbid_mask, key.bp = best_preds;
   key.bl = best_lprobs, key.mp = mult_preds, key.ml = mult_lprobs, key.sz = out_sizes, key.s0 = step0_logits;
-  key.ts = trace_sel, key.tv = trace_val, key.ws = workspace;
+  key.ts = trace_sel, key.tv = trace_val, key.mg = margins, key.ws = workspace;
   key.B = batch, key.Ta = t_audio, key.beam = beam, key.min_pred = min_pred, key.maxp = max_pred;
   auto find = [&]() -> DecGraph* {  // (under the lock) least recently used first: a hit moves to the back
     for (int i = 0; i < cache->n; ++i)

@@ -867,17 +867,24 @@ __global__ __launch_bounds__(256) void cn_ln_patchify_kernel(const XT* __restric
 }
 
 // frame_embs[b][t][c] = mean over the W freq positions (convnext.py:306); also an operand-type copy
+// + the overflow check of the fp16 residual stream (round 6): a value beyond 65504 anywhere in the stream is inf there, NaN after
+// the next LayerNorm, and reaches this kernel through the residual adds, the 7 x 7 windows and the downsampling -- one test per
+// output value here, one atomic per (clip, frame) row that holds any (conette_encode_nonfinite reads the counter)
 template <typename T, typename XT>
 __global__ __launch_bounds__(256) void cn_frame_mean_kernel(const XT* __restrict__ x, int W, int C,
-                                                            float* __restrict__ fe, T* __restrict__ fe_t) {
+                                                            float* __restrict__ fe, T* __restrict__ fe_t,
+                                                            int* __restrict__ nonfinite) {
   const size_t bt = blockIdx.x;
+  bool bad = false;
   for (int c = threadIdx.x; c < C; c += 256) {
     float s = 0.f;
     for (int w = 0; w < W; ++w) s += cn_ld1(x + (bt * W + w) * C + c);
     const float m = s / (float)W;
+    bad |= !(__builtin_fabsf(m) <= 3.0e38f);
     fe[bt * C + c] = m;
     if (fe_t) fe_t[bt * C + c] = cn_from_f32<T>(m);
   }
+  if (__syncthreads_or(bad ? 1 : 0) && threadIdx.x == 0) atomicAdd(nonfinite, 1);
 }
 
 // clip head input: max_t + mean_t -> nn.LayerNorm(768, eps 1e-6) (convnext.py:324-330)
@@ -1175,7 +1182,7 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
   const int Tn = g.H[3];
   CnProfScope ps_heads(ctx, CONETTE_PROF_HEADS, s);
   hipLaunchKernelGGL((cn_frame_mean_kernel<T, XT>), dim3((unsigned)(B * Tn)), dim3(256), 0, s, xc, g.W[3], CN_FEAT,
-                     frame_embs, (T*)nullptr);
+                     frame_embs, (T*)nullptr, ctx->nonfinite);
   CN_LAUNCH_CHECK();
   if (clip_probs) {
     hipLaunchKernelGGL((cn_clip_pool_ln_kernel<T>), dim3((unsigned)B), dim3(256), 0, s, frame_embs, Tn, ctx->norm_w,
@@ -1184,6 +1191,20 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
     EpiBiasAct<float> eh{ctx->head_b, clip_probs, CN_N_TAGS, ACT_SIGMOID};
     CN_TRY(cn_mm((const T*)ws.clip_t, CN_FEAT, (const T*)ctx->head_w, CN_FEAT, B, CN_N_TAGS, CN_FEAT, eh, s));
   }
+  return CN_OK;
+}
+
+extern "C" int conette_encode_nonfinite(conette_ctx* ctx, void* stream, int32_t* count) {
+  if (!ctx || !count) {
+    cn_set_error("encode_nonfinite: bad argument");
+    return CN_ERR_ARG;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  int32_t host = 0;
+  CN_HIP(hipMemcpyAsync(&host, ctx->nonfinite, sizeof(host), hipMemcpyDeviceToHost, s));
+  CN_HIP(hipStreamSynchronize(s));
+  if (host != 0) CN_HIP(hipMemsetAsync(ctx->nonfinite, 0, sizeof(host), s));
+  *count = host;
   return CN_OK;
 }
 

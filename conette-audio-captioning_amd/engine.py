@@ -30,8 +30,25 @@ EXPORTS = (
     "conette_frontend_logmel", "conette_encode", "conette_decode", "conette_resample", "conette_resample_len",
     "conette_set_option", "conette_profile_enable", "conette_profile_read", "conette_stream_create_masked",
     "conette_stream_destroy", "conette_forcing_workspace_bytes", "conette_forcing",
-    "conette_greedy_workspace_bytes", "conette_greedy", "conette_decode_graph_nodes",
+    "conette_greedy_workspace_bytes", "conette_greedy", "conette_decode_graph_nodes", "conette_encode_nonfinite",
 )
+# ---- precision "certified": when is a 16-bit search's decision as good as an exact one's? ------------------------------------
+# Per base precision and kind of search, (a, b, c): the top-k call of step i is certified when its effective margin is at
+# least a + b * (i + 1), the final best-beam choice when its margin is at least c.  Calibration (tools/calibrate_margins.py ->
+# profiles/r06_margin_calibration.txt; 512 clips x 2 synthetic checkpoints x beam 1 / 3, ~10^5 decisions per base precision):
+# when a 16-bit search leaves the exact search's trajectory, the margin it saw at that call was at most
+#     f16 0.018 (greedy) / 0.030 (beam 3),  mixed16 0.008 / 0.021,  bf16+f16dec 0.070 / 0.120,  bf16 0.140 / 0.246
+# -- flat over the 20 steps (the running sums' error is common to the candidates of a parent and cancels in a gap; hence
+# b = 0), larger between rows of different parents (beam > 1) than inside one row (greedy); final choice: at most 0.0014 /
+# none / 0.005 / 0.019 on the averaged scores.  The tolerances below are ~1.7x those maxima.  What they cost is the share
+# of clips whose closest decision is nearer than that: `recompute_fraction` of the bench line.
+CERT_TOL = {
+    "f16": {"greedy": (0.03, 0.0, 0.0), "beam": (0.05, 0.0, 0.004)},
+    "mixed16": {"greedy": (0.015, 0.0, 0.0), "beam": (0.035, 0.0, 0.003)},
+    "bf16+f16dec": {"greedy": (0.12, 0.0, 0.0), "beam": (0.20, 0.0, 0.012)},
+    "bf16": {"greedy": (0.24, 0.0, 0.0), "beam": (0.40, 0.0, 0.04)},
+}
+CERT_DEFAULT_BASE = "f16"
 OPT_DECODE_GRAPH = 1
 OPT_DECODE_FUSION = 2
 OPT_ENCODE_RESERVED_CUS = 3
@@ -87,7 +104,10 @@ def load_library() -> C.CDLL:
     lib.conette_decode.restype = C.c_int
     lib.conette_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                   C.c_void_p]
+    lib.conette_encode_nonfinite.restype = C.c_int
+    lib.conette_encode_nonfinite.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
     lib.conette_forcing_workspace_bytes.restype = C.c_size_t
     lib.conette_forcing_workspace_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
     lib.conette_forcing.restype = C.c_int
@@ -115,7 +135,7 @@ def load_library() -> C.CDLL:
     lib.conette_resample.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.conette_resample_len.restype = C.c_int32
     lib.conette_resample_len.argtypes = [C.c_int32, C.c_int32, C.c_int32]
-    if lib.conette_abi_version() != 2:
+    if lib.conette_abi_version() != 3:
         raise RuntimeError("libconette_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -194,16 +214,27 @@ class Engine:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         table = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "exact": PREC_F16X2, "f16x2": PREC_F16X2, "fp8": PREC_FP8,
                  "f16": PREC_F16, "fp16": PREC_F16}
-        if precision == "mixed":     # bf16 encoder + exact (fp16 hi/lo pairs) decoder
+        # "certified" (round 6): a 16-bit base precision for every clip + the device-side margins of its search (conette_decode's
+        # `margins`); clips whose margins do not certify their ids are re-run through an exact context.  "certified" alone picks
+        # CERT_DEFAULT_BASE; "certified:<base>" names it.
+        self.certified = precision == "certified" or precision.startswith("certified:")
+        base = precision
+        if self.certified:
+            base = precision.split(":", 1)[1] if ":" in precision else CERT_DEFAULT_BASE
+            if base not in CERT_TOL:
+                raise ValueError(f"certified: unknown base precision {base!r} (expected one of {tuple(CERT_TOL)})")
+        self.base_precision = base
+        if base == "mixed":     # bf16 encoder + exact (fp16 hi/lo pairs) decoder
             self.precision, self.precision_dec = PREC_BF16, PREC_F16X2
-        elif precision == "mixed16":  # fp16 encoder + exact decoder
+        elif base == "mixed16":  # fp16 encoder + exact decoder
             self.precision, self.precision_dec = PREC_F16, PREC_F16X2
-        elif precision == "bf16+f16dec":  # bf16 encoder (the throughput mode's) + fp16 decoder: the decoder's operands flip the most captions
+        elif base == "bf16+f16dec":  # bf16 encoder (the throughput mode's) + fp16 decoder: the decoder's operands flip the most captions
             self.precision, self.precision_dec = PREC_BF16, PREC_F16
         else:
-            self.precision = self.precision_dec = table[precision]
-        self.precision_name = precision if precision in ("mixed", "mixed16", "bf16+f16dec") else {
+            self.precision = self.precision_dec = table[base]
+        self.precision_name = precision if (self.certified or base in ("mixed", "mixed16", "bf16+f16dec")) else {
             PREC_BF16: "bf16", PREC_F32: "fp32", PREC_F16X2: "exact", PREC_FP8: "fp8", PREC_F16: "f16"}[self.precision]
+        self.eos_id, self.pad_id = int(eos_id), int(pad_id)
         vocab = int(state_dict["model.decoder.classifier.weight"].shape[0])
         self.vocab_size = vocab
         self.d_model, self.nhead, self.n_layers, self.d_ff = d_model, nhead, n_layers, d_ff
@@ -237,19 +268,26 @@ class Engine:
             # "mixed": frame_embs (B, T, 768) fp32 is the interface between the two halves of the path, so the encoder and the
             # decoder may run at different precisions -- here the bf16 encoder (the throughput mode's) feeds an exact decoder
             self._ctx_dec = create(self.precision_dec) if self.precision_dec != self.precision else self._ctx
+            # "certified": the exact context that re-runs the clips the margins do not certify (encoder + decoder; shared with
+            # the base's decoder when that is exact already)
+            self._ctx_x = None
+            if self.certified:
+                self._ctx_x = self._ctx_dec if self.precision_dec == PREC_F16X2 else create(PREC_F16X2)
+        self.cert_stats = {"clips": 0, "recomputed": 0}
         self._ws: Dict[str, torch.Tensor] = {}
         self._dec_bufs: Dict[Any, Dict[str, Any]] = {}
         del keep
 
     def __del__(self) -> None:
-        ctx, ctx_dec = getattr(self, "_ctx", None), getattr(self, "_ctx_dec", None)
-        for c in ([ctx] if ctx_dec is ctx else [ctx, ctx_dec]):
-            if c:
+        seen = []
+        for c in (getattr(self, "_ctx", None), getattr(self, "_ctx_dec", None), getattr(self, "_ctx_x", None)):
+            if c and all(c is not d for d in seen):
+                seen.append(c)
                 try:
                     self.lib.conette_destroy(c)
                 except Exception:
                     pass
-        self._ctx = self._ctx_dec = None
+        self._ctx = self._ctx_dec = self._ctx_x = None
 
     def _workspace(self, key: str, nbytes: int) -> torch.Tensor:
         ws = self._ws.get(key)
@@ -268,10 +306,16 @@ class Engine:
 
     # ---- a2-a7 -----------------------------------------------------------------------------
     def encode(self, wave: torch.Tensor, taps=False, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-               slot: int = 0):
+               slot: int = 0, exact: bool = False):
         """wave (B, L) fp32 on device -> frame_embs (B, T, 768), clip_probs (B, 527) [, taps dict].
         ``taps="blocks"`` additionally returns the output of every ConvNeXt block ("block0" .. "block17").
-        ``slot`` selects the scratch workspace: encodes running concurrently on different streams need different slots."""
+        ``slot`` selects the scratch workspace: encodes running concurrently on different streams need different slots.
+        ``exact`` (certified engines only): run on the exact context that re-computes uncertified clips."""
+        ctx = self._ctx
+        if exact:
+            if self._ctx_x is None:
+                raise RuntimeError("encode(exact=True) needs a certified engine")
+            ctx = self._ctx_x
         wave = wave.to(self.device, torch.float32).contiguous()
         b, l = wave.shape
         f, hs, ws_ = encoder_geometry(l)
@@ -281,8 +325,8 @@ class Engine:
             clip = torch.empty((b, N_TAGS), dtype=torch.float32, device=self.device)
         else:
             frame_embs, clip = out
-        need = self.lib.conette_encode_workspace_bytes(self._ctx, b, l)
-        wsb = self._workspace("enc" if slot == 0 else f"enc{slot}", need)
+        need = self.lib.conette_encode_workspace_bytes(ctx, b, l)
+        wsb = self._workspace(("xenc" if exact else "enc") + ("" if slot == 0 else str(slot)), need)
         tap_struct, tap_out = None, None
         if taps:
             dims = (96, 192, 384, 768)
@@ -308,7 +352,7 @@ class Engine:
                         tap_out[f"block{blk}"] = e(b, hs[i], ws_[i], dims[i])
                         tap_struct.block[blk] = tap_out[f"block{blk}"].data_ptr()
                         blk += 1
-        st = self.lib.conette_encode(self._ctx, _ptr(wave), b, l, _ptr(frame_embs), _ptr(clip),
+        st = self.lib.conette_encode(ctx, _ptr(wave), b, l, _ptr(frame_embs), _ptr(clip),
                                      C.byref(tap_struct) if tap_struct is not None else None, _ptr(wsb),
                                      wsb.numel(), _stream())
         _check(st, "conette_encode")
@@ -318,10 +362,10 @@ class Engine:
 
     # ---- a9-a14 ----------------------------------------------------------------------------
     def _decode_buffers(self, b: int, t: int, beam: int, max_pred: int, s0: bool, trace: bool,
-                        slot: int = 0) -> Dict[str, Any]:
+                        slot: int = 0, margins: bool = False, exact: bool = False) -> Dict[str, Any]:
         """Persistent I/O buffers per shape (and pipeline slot): identical pointers let the library
         replay its hipGraph."""
-        key = (b, t, beam, max_pred, s0, trace, slot)
+        key = (b, t, beam, max_pred, s0, trace, slot, margins, exact)
         buf = self._dec_bufs.pop(key, None)
         if buf is not None:
             self._dec_bufs[key] = buf           # least recently used first: a hit moves to the back
@@ -338,6 +382,7 @@ class Engine:
                 "step0": e((b * beam, ldv), torch.float32) if s0 else None,
                 "trace_sel": e((max_pred, b, beam, 2), torch.int32) if trace else None,
                 "trace_val": e((max_pred, b, beam), torch.float32) if trace else None,
+                "margins": e((b, max_pred + 1), torch.float32) if margins else None,
             }
             if len(self._dec_bufs) >= MAX_DECODE_GRAPHS:
                 # the evicted buffers may still be written by a decode running on another stream: drain before they are freed
@@ -349,12 +394,19 @@ class Engine:
     def decode(self, frame_embs: torch.Tensor, frame_lens: torch.Tensor, bos_ids: torch.Tensor,
                forbid_mask: Optional[torch.Tensor], beam: int, min_pred: int, max_pred: int,
                want_step0_logits: bool = False, want_trace: bool = False, clone: bool = True,
-               slot: int = 0) -> Dict[str, torch.Tensor]:
+               slot: int = 0, want_margins: bool = False, exact: bool = False) -> Dict[str, torch.Tensor]:
         """Beam search over pre-computed frame embeddings.  Outputs are full width; trim with
         ``sizes`` = [pred_size, best_maxlen].  ``clone=False`` returns the persistent buffers of
-        pipeline ``slot`` (two slots let the decode of batch i overlap the encode of batch i+1)."""
+        pipeline ``slot`` (two slots let the decode of batch i overlap the encode of batch i+1).
+        ``want_margins``: also ``margins`` (B, max_pred + 1), the per-decision margins of the search (include/conette_hip.h).
+        ``exact`` (certified engines only): run on the exact context."""
+        ctx = self._ctx_dec
+        if exact:
+            if self._ctx_x is None:
+                raise RuntimeError("decode(exact=True) needs a certified engine")
+            ctx = self._ctx_x
         b, t, _ = frame_embs.shape
-        buf = self._decode_buffers(b, t, int(beam), int(max_pred), want_step0_logits, want_trace, slot)
+        buf = self._decode_buffers(b, t, int(beam), int(max_pred), want_step0_logits, want_trace, slot, want_margins, exact)
         if frame_embs.data_ptr() != buf["fe"].data_ptr():
             buf["fe"].copy_(frame_embs, non_blocking=True)
         buf["lens"].copy_(frame_lens.to(torch.int32), non_blocking=True)
@@ -365,13 +417,14 @@ class Engine:
                 raise ValueError("forbid_mask must have vocab_size entries")
             buf["forbid"].copy_(forbid_mask.to(torch.uint8), non_blocking=True)
             forbid_ptr = buf["forbid"]
-        need = self.lib.conette_decode_workspace_bytes(self._ctx_dec, b, t, beam, max_pred)
-        wsb = self._workspace("dec" if slot == 0 else f"dec{slot}", need)  # per slot: decodes of different slots may run on different streams
-        st = self.lib.conette_decode(self._ctx_dec, _ptr(buf["fe"]), _ptr(buf["lens"]), _ptr(buf["bos"]), _ptr(forbid_ptr),
+        need = self.lib.conette_decode_workspace_bytes(ctx, b, t, beam, max_pred)
+        # per slot: decodes of different slots may run on different streams
+        wsb = self._workspace(("xdec" if exact else "dec") + ("" if slot == 0 else str(slot)), need)
+        st = self.lib.conette_decode(ctx, _ptr(buf["fe"]), _ptr(buf["lens"]), _ptr(buf["bos"]), _ptr(forbid_ptr),
                                      b, t, beam, min_pred, max_pred, _ptr(buf["best_preds"]), _ptr(buf["best_lprobs"]),
                                      _ptr(buf["mult_preds"]), _ptr(buf["mult_lprobs"]), _ptr(buf["sizes"]),
-                                     _ptr(buf["step0"]), _ptr(buf["trace_sel"]), _ptr(buf["trace_val"]), _ptr(wsb),
-                                     wsb.numel(), _stream())
+                                     _ptr(buf["step0"]), _ptr(buf["trace_sel"]), _ptr(buf["trace_val"]), _ptr(buf["margins"]),
+                                     _ptr(wsb), wsb.numel(), _stream())
         _check(st, "conette_decode")
         cp = (lambda x: x.clone()) if clone else (lambda x: x)
         out = {k: cp(buf[k]) for k in ("best_preds", "best_lprobs", "mult_preds", "mult_lprobs", "sizes")}
@@ -380,7 +433,80 @@ class Engine:
         if want_trace:
             out["trace_sel"] = cp(buf["trace_sel"])
             out["trace_val"] = cp(buf["trace_val"])
+        if want_margins:
+            out["margins"] = cp(buf["margins"])
         return out
+
+    # ---- the id certificate (round 6) ------------------------------------------------------------------------------------
+    def uncertified(self, margins: torch.Tensor, best_lprobs: torch.Tensor, tol: Optional[Tuple[float, float, float]] = None,
+                    beam: int = 2) -> torch.Tensor:
+        """(B,) bool, True = the 16-bit search of this clip is NOT certified to have taken an exact search's decisions:
+        some top-k call of step i has an effective margin below ``a + b * (i + 1)``, or the final best-beam choice one below
+        ``c``, or a score / margin is not finite (an fp16 residual-stream overflow ends here as NaN).  ``tol`` = (a, b, c),
+        default ``CERT_TOL[base precision]["greedy" if beam == 1 else "beam"]`` -- measured: tools/calibrate_margins.py,
+        profiles/r06_margin_calibration.txt."""
+        a, b, c = CERT_TOL[self.base_precision]["greedy" if int(beam) == 1 else "beam"] if tol is None else tol
+        max_pred = margins.shape[1] - 1
+        need = a + b * torch.arange(1, max_pred + 1, device=margins.device, dtype=torch.float32)
+        ok = (margins[:, :max_pred] >= need).all(dim=1) & (margins[:, max_pred] >= c) & torch.isfinite(best_lprobs)
+        return ~ok
+
+    def caption_sizes(self, best_preds: torch.Tensor, mult_preds: torch.Tensor) -> torch.Tensor:
+        """[pred_size, best_maxlen] (beam.py:192-194,207-211,222-225) recomputed from full-width ids -- after rows of two
+        searches have been merged.  A hypothesis ends at its first <eos>, or at max_pred when it never emitted one."""
+        max_pred = mult_preds.shape[-1]
+        pos = torch.arange(max_pred, device=mult_preds.device)
+
+        def first_eos(x):   # index of the first <eos>, max_pred where absent
+            return torch.where(x == self.eos_id, pos, max_pred).amin(dim=-1)
+
+        ps = torch.clamp(first_eos(mult_preds) + 1, max=max_pred).amax()
+        e = first_eos(best_preds)
+        ml = torch.minimum(torch.where(e < ps, e, ps).amax() + 1, ps)
+        return torch.stack([ps, ml]).to(torch.int32)
+
+    def generate_certified(self, wave: Optional[torch.Tensor], frame_embs: torch.Tensor, frame_lens: torch.Tensor,
+                           bos_ids: torch.Tensor, forbid_mask: Optional[torch.Tensor], beam: int, min_pred: int,
+                           max_pred: int, tol: Optional[Tuple[float, float, float]] = None) -> Dict[str, torch.Tensor]:
+        """The certified search: the base precision's search of every clip with margins; the clips it does not certify are
+        compacted into one batch and re-run through the exact context -- from the waveform (``wave`` (B, L), the padded batch
+        the embeddings came from: exact encoder + exact decoder) or, when ``wave`` is None (the caller gave embeddings:
+        ``preprocess=False``, BaselinePLM), from the same embeddings (exact decoder) -- and scattered back.  One host
+        round trip per BATCH (the number of such clips sizes the second launch), none per search step.
+        Returns decode()'s dict + ``recomputed`` (B,) bool."""
+        if not self.certified:
+            raise RuntimeError("generate_certified needs Engine(precision='certified[:base]')")
+        res = self.decode(frame_embs, frame_lens, bos_ids, forbid_mask, beam, min_pred, max_pred, want_margins=True)
+        flag = self.uncertified(res["margins"], res["best_lprobs"], tol, beam)
+        if wave is None and self.precision_dec == PREC_F16X2:
+            flag = torch.zeros_like(flag)   # given embeddings + an exact decoder already: nothing a re-run could change
+        idx = torch.nonzero(flag).flatten()
+        n = int(idx.numel())            # (the host round trip)
+        b = int(frame_embs.shape[0])
+        self.cert_stats["clips"] += b
+        self.cert_stats["recomputed"] += n
+        res["recomputed"] = flag
+        if n == 0:
+            return res
+        lens_d = frame_lens.to(self.device)
+        bos_d = bos_ids.to(self.device)
+        if wave is not None:
+            fe_x, _ = self.encode(wave.index_select(0, idx), exact=True)
+        else:
+            fe_x = frame_embs.to(self.device).index_select(0, idx)
+        rx = self.decode(fe_x, lens_d.index_select(0, idx), bos_d.index_select(0, idx), forbid_mask, beam, min_pred, max_pred,
+                         exact=True)
+        for k in ("best_preds", "best_lprobs", "mult_preds", "mult_lprobs"):
+            res[k].index_copy_(0, idx, rx[k])
+        res["sizes"] = self.caption_sizes(res["best_preds"], res["mult_preds"])
+        return res
+
+    def encode_nonfinite(self) -> int:
+        """(clip, frame) rows of frame embeddings that encodes of this engine wrote with non-finite values since the last call
+        (the fp16 residual stream of the 16-bit precisions overflowed); waits for the current stream."""
+        n = C.c_int32(0)
+        _check(self.lib.conette_encode_nonfinite(self._ctx, _stream(), C.byref(n)), "conette_encode_nonfinite")
+        return int(n.value)
 
     def forcing(self, frame_embs: torch.Tensor, frame_lens: torch.Tensor, caps_in: torch.Tensor) -> torch.Tensor:
         """Teacher forcing (forcing.py:12-71): frame_embs (B, T, 768), caps_in (B, cap_len) ids right-padded with
@@ -417,9 +543,11 @@ class Engine:
         ps = int(sizes[0].item())
         return {"logits": logits[:, :ps].contiguous(), "preds": preds[:, :ps].contiguous()}
 
-    def decode_input_buffer(self, b: int, t: int, beam: int, max_pred: int, slot: int = 0) -> torch.Tensor:
-        """The persistent (B, T, 768) input of decode(): encode straight into it to skip a copy."""
-        return self._decode_buffers(b, t, int(beam), int(max_pred), False, False, slot)["fe"]
+    def decode_input_buffer(self, b: int, t: int, beam: int, max_pred: int, slot: int = 0, margins: bool = False,
+                            exact: bool = False) -> torch.Tensor:
+        """The persistent (B, T, 768) input of decode() (of the call with the same ``want_margins`` / ``exact``): encode
+        straight into it to skip a copy."""
+        return self._decode_buffers(b, t, int(beam), int(max_pred), False, False, slot, margins, exact)["fe"]
 
     # ---- options / profiling ------------------------------------------------------------------
     def set_decode_graph(self, enabled: bool) -> None:

@@ -20,13 +20,17 @@ import torch
 from torch import Size, Tensor
 
 from .config import CoNeTTEConfig
-from .engine import Engine
+from .engine import Engine, PREC_BF16, PREC_F16
 from .preprocessor import CoNeTTEPreprocessor
 from .tokenizer import AACTokenizer, ENGLISH_STOPWORDS, unpickle_extra_state
 
 pylog = logging.getLogger(__name__)
 
 FORBID_MODES = ("none", "all", "content_words")
+# What `CoNeTTEModel.from_pretrained(dir)(x)` runs when the caller names no precision (round 6): the fp16 pipeline with the
+# device-side id certificate -- clips whose search margins do not certify their token ids are re-run through the exact context,
+# so the ids are the reference's (fp32) ids.  "bf16" is the benchmark's throughput mode (BASELINE configs[1-3]).
+DEFAULT_PRECISION = "certified"
 
 
 def load_audioset_idx_to_name(offline: bool = False, cache_path: Union[str, Path, None] = None) -> Dict[int, str]:
@@ -72,7 +76,7 @@ class CoNeTTEModel:
 
     def __init__(self, config: CoNeTTEConfig, device: Union[str, torch.device, None] = "cuda_if_available",
                  inference: bool = True, offline: bool = False, model_override: Any = None, *,
-                 state_dict: Optional[Dict[str, Tensor]] = None, precision: str = "bf16",
+                 state_dict: Optional[Dict[str, Tensor]] = None, precision: str = DEFAULT_PRECISION,
                  audioset_idx_to_name: Optional[Dict[int, str]] = None,
                  stopwords: Optional[Iterable[str]] = None) -> None:
         if model_override is not None:
@@ -89,17 +93,31 @@ class CoNeTTEModel:
             raise RuntimeError("conette_amd runs on a ROCm GPU only; there is no CPU fallback.")
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        state_dict = dict(state_dict)
+        self.precision = precision
+        self._stopwords = list(ENGLISH_STOPWORDS if stopwords is None else stopwords)
+        self.audioset_idx_to_name = (load_audioset_idx_to_name(offline=offline) if audioset_idx_to_name is None
+                                     else dict(audioset_idx_to_name))
+        self.training = False
+        self.last_recomputed: Optional[Tensor] = None
+        self._build(dict(state_dict))
+
+    def _build(self, state_dict: Dict[str, Tensor]) -> None:
+        """module construction + load_state_dict of the reference (model.py:41-107,126-163): tokenizer from the pickled extra
+        state, task tokens, forbid mask, then the packed weights inside the HIP contexts on ``self.device``."""
+        config = self.config
         # non-tensor state: pickled dict in `_extra_state_` (model.py:126-139)
         tok_state = None
         if "_extra_state_" in state_dict:
             extra = unpickle_extra_state(state_dict.pop("_extra_state_"))
             tok_state = extra.get("model.tokenizers.0._extra_state")
         if tok_state is None:
+            tok_state = state_dict.pop("model.tokenizers.0._extra_state", None)   # an already-unpacked state dict
+        if tok_state is None:
             tok_state = config.tokenizer_state
         if tok_state is None:
             raise RuntimeError("Cannot build the model from state_dict. (tokenizer is not fit)")
         self.tokenizer = AACTokenizer.from_txt_state(tok_state)
+        self._tok_state = tok_state
         # task tokens (conette.py:103-129); present in a trained tokenizer, appended otherwise
         self.task_name_to_token_id: Dict[str, int] = {}
         if config.task_mode in ("ds", "ds_src"):
@@ -123,16 +141,15 @@ class CoNeTTEModel:
         if config.acti_name != "gelu" or config.proj_name != "lin768":
             raise ValueError(f"Unsupported config for the MI355X path: acti_name={config.acti_name!r}, "
                              f"proj_name={config.proj_name!r} (expected 'gelu' and 'lin768').")
-        self._stopwords = list(ENGLISH_STOPWORDS if stopwords is None else stopwords)
-        self.audioset_idx_to_name = (load_audioset_idx_to_name(offline=offline) if audioset_idx_to_name is None
-                                     else dict(audioset_idx_to_name))
         with torch.cuda.device(self.device):
-            self.engine = Engine(state_dict, precision=precision, d_model=config.d_model, nhead=config.nhead,
+            self.engine = Engine(state_dict, precision=self.precision, d_model=config.d_model, nhead=config.nhead,
                                  n_layers=config.num_decoder_layers, d_ff=config.dim_feedforward,
                                  pad_id=self.tokenizer.pad_token_id, bos_id=self.tokenizer.bos_token_id,
                                  eos_id=self.tokenizer.eos_token_id, device=self.device)
         self.preprocessor = CoNeTTEPreprocessor(self.engine, verbose=config.verbose)
-        self.training = False
+        # the tensors the contexts were packed from, kept by reference (host memory the caller already holds) so that
+        # state_dict() / save_pretrained() round-trip the reference layout (model.py:163-183)
+        self._weights: Dict[str, Tensor] = {k: v for k, v in state_dict.items() if isinstance(v, Tensor)}
 
     # ---- construction -----------------------------------------------------------------------
     @classmethod
@@ -145,6 +162,59 @@ class CoNeTTEModel:
         if config is None:
             config = CoNeTTEConfig.from_pretrained(path)
         return cls(config, *args, state_dict=_read_state_dict(path), **kwargs)
+
+    # ---- PreTrainedModel surface (model.py:38,126-183): the checkpoint round trip -------------------------------------------
+    def state_dict(self) -> Dict[str, Tensor]:
+        """model.py:163-183: every tensor of the checkpoint the contexts were packed from (reference key names) + the non-tensor
+        states -- the fitted tokenizer -- pickled into the uint8 tensor ``_extra_state_``; tensors contiguous."""
+        import pickle
+        out = {k: v.contiguous() for k, v in self._weights.items()}
+        non_tensor = {"model.tokenizers.0._extra_state": self._tok_state}
+        out["_extra_state_"] = torch.frombuffer(bytearray(pickle.dumps(non_tensor)), dtype=torch.uint8)
+        return out
+
+    def load_state_dict(self, state_dict: Dict[str, Tensor], strict: bool = True) -> "CoNeTTEModel":
+        """Re-packs the HIP contexts from another checkpoint of the same layout (the pre-hook of model.py:126-161 unpickles
+        ``_extra_state_`` and re-fits the tokenizer first: same here).  ``strict``: missing tensors are an error either way --
+        ``conette_create`` names the first one it cannot find."""
+        old = getattr(self, "engine", None)
+        self._build(dict(state_dict))
+        del old
+        return self
+
+    def save_pretrained(self, save_directory: str, safe_serialization: bool = True, **kwargs) -> None:
+        """``config.json`` + ``model.safetensors`` (or ``pytorch_model.bin``) readable by ``from_pretrained`` here AND by the
+        reference's ``CoNeTTEModel.from_pretrained`` (transformers' PreTrainedModel layout; key names are the reference's)."""
+        os.makedirs(save_directory, exist_ok=True)
+        self.config.save_pretrained(save_directory)
+        sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
+        if safe_serialization:
+            from safetensors.torch import save_file
+            # (safetensors refuses aliased storage: `.contiguous().clone()` for tensors that share memory)
+            save_file({k: v.clone() for k, v in sd.items()}, osp.join(save_directory, "model.safetensors"), metadata={"format": "pt"})
+        else:
+            torch.save(sd, osp.join(save_directory, "pytorch_model.bin"))
+
+    def to(self, device: Union[str, torch.device, None] = None, *args, **kwargs) -> "CoNeTTEModel":
+        """nn.Module.to for devices: the device the contexts live on is a no-op, another ROCm GPU re-packs the weights there,
+        a CPU is refused (the path has no CPU fallback); dtype arguments are ignored -- ``precision`` is chosen at construction."""
+        if device is None or isinstance(device, torch.dtype):
+            return self
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("conette_amd runs on a ROCm GPU only; there is no CPU fallback.")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        if dev != self.device:
+            self.device = dev
+            self._build(self.state_dict())
+        return self
+
+    def cuda(self, device: Union[int, torch.device, None] = None) -> "CoNeTTEModel":
+        return self.to("cuda" if device is None else (f"cuda:{device}" if isinstance(device, int) else device))
+
+    def cpu(self) -> "CoNeTTEModel":
+        return self.to("cpu")
 
     # ---- reference properties / methods (model.py:109-124) -------------------------------------
     @property
@@ -217,6 +287,7 @@ class CoNeTTEModel:
                 assert isinstance(x, Tensor) and isinstance(x_shapes, Tensor)
                 batch = {"audio": x.to(self.device), "audio_shape": x_shapes.to(self.device)}
                 clip_probs, tags = None, None
+            wave = batch.pop("_wave", None)
 
             bsize = len(batch["audio"])
             if task is None:
@@ -241,7 +312,15 @@ class CoNeTTEModel:
 
             outs = self._generate(batch["audio"], batch["audio_shape"], dataset_lst, source_lst,
                                   beam_size=beam_size, min_pred_size=min_pred_size, max_pred_size=max_pred_size,
-                                  forbid_rep_mode=forbid_rep_mode)
+                                  forbid_rep_mode=forbid_rep_mode, wave=wave)
+            if preprocess and self.engine.precision in (PREC_BF16, PREC_F16):
+                # the fp16 residual stream of the 16-bit encoders holds |x| <= 65504; beyond it the embeddings are NaN.  The
+                # certified precision has re-run such clips through the exact context (fp32 stream); the others fail loudly.
+                bad = self.engine.encode_nonfinite()
+                if bad and not self.engine.certified:
+                    raise RuntimeError(
+                        f"precision={self.engine.precision_name!r}: the encoder's fp16 residual stream overflowed ({bad} frame "
+                        "rows of non-finite embeddings); use precision='certified', 'exact' or 'fp32' for this checkpoint")
             outs["tasks"] = tasks
             if clip_probs is not None and tags is not None:
                 outs["tags_probs"] = clip_probs
@@ -340,15 +419,21 @@ class CoNeTTEModel:
             beam = cfg.beam_size if kwargs.get("beam_size") is None else int(kwargs["beam_size"])
             min_pred = cfg.min_pred_size if kwargs.get("min_pred_size") is None else int(kwargs["min_pred_size"])
             max_pred = cfg.max_pred_size if kwargs.get("max_pred_size") is None else int(kwargs["max_pred_size"])
-            res = self.engine.decode(audio, audio_shape[:, 1].to(torch.int32), bos.contiguous(),
-                                     self.get_forbid_rep_mask(kwargs.get("forbid_rep_mode")), beam, min_pred, max_pred)
+            if self.engine.certified:
+                res = self.engine.generate_certified(None, audio, audio_shape[:, 1].to(torch.int32), bos.contiguous(),
+                                                     self.get_forbid_rep_mask(kwargs.get("forbid_rep_mode")), beam, min_pred,
+                                                     max_pred)
+            else:
+                res = self.engine.decode(audio, audio_shape[:, 1].to(torch.int32), bos.contiguous(),
+                                         self.get_forbid_rep_mask(kwargs.get("forbid_rep_mode")), beam, min_pred, max_pred)
             pred_size, best_maxlen = (int(v) for v in res["sizes"].tolist())
             return (res["best_preds"][:, :best_maxlen].to(torch.long).contiguous(), res["best_lprobs"],
                     res["mult_preds"][:, :, :pred_size].to(torch.long).contiguous(), res["mult_lprobs"])
         raise ValueError(f"Unknown argument {decode_method=}. (expected one of ('forcing', 'greedy', 'generate'))")
 
     def _generate(self, audio: Tensor, audio_shape: Tensor, datasets: List[str], sources: List[Optional[str]], *,
-                  beam_size=None, min_pred_size=None, max_pred_size=None, forbid_rep_mode=None) -> Dict[str, Any]:
+                  beam_size=None, min_pred_size=None, max_pred_size=None, forbid_rep_mode=None,
+                  wave: Optional[Tensor] = None) -> Dict[str, Any]:
         """CoNeTTEPLM.forward("generate") = encode_audio + decode_audio + decode_text (conette.py:352-450)."""
         if audio.ndim == 4:  # FrameIdentEncoder (nn/encoders/ident.py:19-21)
             audio = audio.squeeze(dim=1)
@@ -359,7 +444,12 @@ class CoNeTTEModel:
         assert beam > 0 and min_pred >= 0
         lens = audio_shape[:, 1].to(torch.int32)
         bos = self.batch_to_task_token_ids(datasets, sources)
-        res = self.engine.decode(audio, lens, bos, self.get_forbid_rep_mask(forbid_rep_mode), beam, min_pred, max_pred)
+        if self.engine.certified:   # base-precision search + margins; uncertified clips re-run through the exact context
+            res = self.engine.generate_certified(wave, audio, lens, bos, self.get_forbid_rep_mask(forbid_rep_mode), beam,
+                                                 min_pred, max_pred)
+        else:
+            res = self.engine.decode(audio, lens, bos, self.get_forbid_rep_mask(forbid_rep_mode), beam, min_pred, max_pred)
+        self.last_recomputed = res.get("recomputed")   # certified: (B,) bool, the clips the exact context re-ran
         pred_size, best_maxlen = (int(v) for v in res["sizes"].tolist())  # the one host sync of the path
         preds = res["best_preds"][:, :best_maxlen].to(torch.long).contiguous()
         mult_preds = res["mult_preds"][:, :, :pred_size].to(torch.long).contiguous()

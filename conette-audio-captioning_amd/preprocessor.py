@@ -118,7 +118,10 @@ class CoNeTTEPreprocessor:
         frame_embs, clip_probs = self.engine.encode(wave)
         lens = frame_embs_lens(shapes[:, -1], wave.shape[-1], frame_embs.shape[1])
         audio_shape = torch.stack([torch.full_like(lens, self.feat_size), lens], dim=1).to(self.device)
-        return {"audio": frame_embs, "audio_shape": audio_shape, "clip_probs": clip_probs}
+        out = {"audio": frame_embs, "audio_shape": audio_shape, "clip_probs": clip_probs}
+        if getattr(self.engine, "certified", False):
+            out["_wave"] = wave   # the padded batch: what the exact context re-encodes for clips the margins do not certify
+        return out
 
     def _load_resample(self, x, sr=None, x_shapes=None) -> Tuple[Tensor, Tensor]:
         """preprocessor.py:82-154 (same accepted forms, same error behaviour)."""

@@ -24,7 +24,9 @@
 extern "C" {
 #endif
 
-#define CONETTE_ABI_VERSION 2 /* 2: conette_encode_taps carries its size; CONETTE_PREC_F16X2 / _FP8 / _F16; conette_decode_graph_nodes */
+#define CONETTE_ABI_VERSION 3 /* 2: conette_encode_taps carries its size; CONETTE_PREC_F16X2 / _FP8 / _F16; conette_decode_graph_nodes
+                                 3: conette_decode's `margins` output (the id certificate of the 16-bit precisions), beams up to 16,
+                                    conette_encode_nonfinite */
 
 /* precision of GEMM operands / intermediate activations.  Accumulation is always fp32 and the decoder's residual stream is
  * always fp32; the ENCODER's residual stream is IEEE fp16 in the two 16-bit precisions (BF16, F16) since round 5 -- 11
@@ -116,6 +118,14 @@ int conette_encode(conette_ctx* ctx, const float* wave, int32_t batch, int32_t n
                    float* clip_probs, const conette_encode_taps* taps, void* workspace, size_t workspace_bytes,
                    void* stream);
 
+/* The 16-bit precisions keep the encoder's residual stream in IEEE fp16 (|x| <= 65504).  A value beyond that becomes inf, NaN
+ * after the next LayerNorm (convnext.py:61-66), and reaches frame_embs; conette_encode counts the (clip, frame) rows of
+ * frame_embs it wrote with a non-finite value.  This call waits for `stream`, returns the count accumulated by the encodes of
+ * this context since the previous call in *count and resets it.  Non-zero = at least one clip's embeddings are unusable in
+ * this precision: run it through a CONETTE_PREC_F16X2 / _F32 context (fp32 stream).  The ONE blocking entry point besides
+ * conette_create; a host that never calls it loses nothing but the diagnosis (NaN scores still mark the clip). */
+int conette_encode_nonfinite(conette_ctx* ctx, void* stream, int32_t* count);
+
 /* a9-a14: CoNeTTEPLM.encode_audio + decode_audio("generate") = nn/decoding/beam.py:22-227 with
  * the decoder of nn/decoders/aac_tfmer.py:71-118, KV-cached, whole search loop on device.
  *   frame_embs  : dev (B, T, 768) fp32           frame_lens : dev (B) int32 valid frames
@@ -128,13 +138,23 @@ int conette_encode(conette_ctx* ctx, const float* wave, int32_t batch, int32_t n
  *   trace_sel   : optional dev (max_pred, B, beam, 2) int32 = (parent row, token) picked by the
  *                 per-clip top-k of each step in descending order, -1 where unused; or NULL
  *   trace_val   : optional dev (max_pred, B, beam) fp32 running log-prob sums of those picks
- * With identical arguments (pointers included) the launch sequence is replayed from a cached
+ *   margins     : optional dev (B, max_pred + 1) fp32, or NULL -- how far each decision of the search is from any other outcome:
+ *                 [b][i], i < max_pred = the effective margin of clip b's top-k call of step i (_select_k_next_toks,
+ *                 beam.py:230-269): min(gap between the last pick and the first rejected candidate, gaps between consecutive
+ *                 picks -- their order assigns the slots, beam.py:165-169), +inf for steps the clip no longer takes;
+ *                 [b][max_pred] = best averaged log-prob minus the second best (the final choice, beam.py:214-217), +inf for
+ *                 beam 1.  A search whose margins all exceed twice the precision's candidate error took the decisions an exact
+ *                 search takes: the certificate behind the host's precision "certified" (conette_amd/engine.py), which re-runs
+ *                 only the other clips through a CONETTE_PREC_F16X2 context.  NaN = fewer finite candidates than picks.
+ * beam <= 16 (1..8 on the register-resident step kernel, 9..16 -- BaselinePLM's default is 10, pl_modules/baseline.py:47 -- on
+ * the generic one), max_pred <= 64.  With identical arguments (pointers included) the launch sequence is replayed from a cached
  * hipGraph from the third call on (see conette_set_option). */
 int conette_decode(conette_ctx* ctx, const float* frame_embs, const int32_t* frame_lens, const int32_t* bos_ids,
                    const uint8_t* forbid_mask, int32_t batch, int32_t t_audio, int32_t beam,
                    int32_t min_pred, int32_t max_pred, int32_t* best_preds, float* best_lprobs,
                    int32_t* mult_preds, float* mult_lprobs, int32_t* out_sizes, float* step0_logits,
-                   int32_t* trace_sel, float* trace_val, void* workspace, size_t workspace_bytes, void* stream);
+                   int32_t* trace_sel, float* trace_val, float* margins, void* workspace, size_t workspace_bytes,
+                   void* stream);
 
 /* teacher forcing (nn/decoding/forcing.py:12-71 as called by CoNeTTEPLM.decode_audio(..., "forcing",
  * caps_in=...), pl_modules/conette.py:392-417, after the projection of conette.py:457): the logits of every position of

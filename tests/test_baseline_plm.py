@@ -107,3 +107,49 @@ def test_decoder_only_context_refuses_encode(baseline_sd):
         plm.decode_audio({"frame_embs": torch.zeros((1, 4, 768)), "frame_embs_lens": torch.tensor([4])}, "forcing")
     with pytest.raises(ValueError, match="Unknown argument"):
         plm.decode_audio({"frame_embs": torch.zeros((1, 4, 768)), "frame_embs_lens": torch.tensor([4])}, "sample")
+
+
+# decode hyper-parameters of the reference's BaselinePLM.__init__ (pl_modules/baseline.py:36-52)
+REFERENCE_DEFAULTS = {"proj_name": "lin768", "min_pred_size": 3, "max_pred_size": None, "beam_size": 10, "nhead": 8, "d_model": 256,
+                      "num_decoder_layers": 6, "dim_feedforward": 2048, "acti_name": "gelu"}
+
+
+def test_constructor_defaults_are_the_references():
+    """a BaselinePLM built without decode hyper-parameters must search like the reference's (beam_size 10, not 2)."""
+    import ast
+    import inspect
+    from conette_amd.baseline import BaselinePLM
+    sig = inspect.signature(BaselinePLM.__init__)
+    ours = {k: sig.parameters[k].default for k in REFERENCE_DEFAULTS}
+    assert ours == REFERENCE_DEFAULTS
+    ref_file = "/root/reference/src/conette/pl_modules/baseline.py"
+    if os.path.isfile(ref_file):      # (this container only: the golden list above against the reference's own source)
+        tree = ast.parse(open(ref_file).read())
+        init = next(f for c in tree.body if isinstance(c, ast.ClassDef) and c.name == "BaselinePLM"
+                    for f in c.body if isinstance(f, ast.FunctionDef) and f.name == "__init__")
+        names = [a.arg for a in init.args.args][1:]
+        vals = [ast.literal_eval(d) for d in init.args.defaults]
+        ref = dict(zip(names[len(names) - len(vals):], vals))
+        assert {k: ref[k] for k in REFERENCE_DEFAULTS} == REFERENCE_DEFAULTS
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["exact", "certified:f16"])
+def test_default_constructed_baseline_plm_searches_with_beam_10(prec, baseline_sd, fixture):
+    """No decode hyper-parameters given: beam 10 (the generic search-step kernel: the register-resident one holds 8 rows),
+    max_pred_size from the tokenizer -- ids equal the oracle's run with the reference's defaults."""
+    from conette_amd.baseline import BaselinePLM
+    g, fe, shape = fixture
+    plm = BaselinePLM(baseline_sd, precision=prec)
+    assert plm.hp["beam_size"] == 10 and plm.hp["min_pred_size"] == 3
+    out = plm({"audio": fe[:, None], "audio_shape": shape}, "generate")
+    w, forbid = _oracle_weights(baseline_sd)
+    v = w["model.decoder.classifier.weight"].shape[0]
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    with torch.no_grad():
+        mem, mask = O.encode_audio(w, fe, shape)
+        preds, lprobs, mult_preds, mult_lprobs = O.generate(w, mem, mask, torch.ones(fe.shape[0], dtype=torch.long), vocab_size=v, beam_size=10,
+                                                            min_pred_size=3, max_pred_size=plm.hp["max_pred_size"], forbid_rep_mask=forbid)
+    assert out["preds"].cpu().tolist() == preds.tolist()
+    assert out["mult_preds"].cpu().tolist() == mult_preds.tolist()
+    np.testing.assert_allclose(out["lprobs"].cpu().numpy(), lprobs.numpy(), atol=2e-4 if prec == "exact" else 0.05)

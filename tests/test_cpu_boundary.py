@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(engine.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.conette_abi_version() == 2
+    assert lib.conette_abi_version() == 3
 
 
 def test_geometry_helpers(lib):

@@ -396,10 +396,10 @@ def test_c_abi_error_behaviour(engines):
 
     def dec(beam, max_pred, ws_bytes, fe_ptr=p(fe)):
         return lib.conette_decode(ctx, fe_ptr, p(lens), p(bos), None, b, t, beam, 3, max_pred, p(out_i), p(out_f), p(out_i),
-                                  p(out_f), p(sizes), None, None, None, p(ws), ws_bytes, None)
+                                  p(out_f), p(sizes), None, None, None, None, p(ws), ws_bytes, None)
 
     assert dec(3, 20, need) == 0
-    assert dec(9, 20, need) == 1 and b"beam" in lib.conette_last_error()          # CN_MAX_BEAM = 8
+    assert dec(17, 20, need) == 1 and b"beam" in lib.conette_last_error()         # CN_MAX_BEAM = 16
     assert dec(3, 65, need) == 1                                                     # CN_MAX_PRED = 64
     assert dec(3, 20, need - 1) == 4 and b"workspace" in lib.conette_last_error()
     assert dec(3, 20, need, fe_ptr=None) == 1
