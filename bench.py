@@ -840,6 +840,21 @@ def main() -> None:
     for _ in range(warm_used):
         step()
     fence()
+    # The timed region is at least CN_MIN_TIMED_S (1 s) long whoever calls: `--steps` stays what the caller passed, the number of
+    # windows is raised from `--repeat` until steps x windows fill that time (the driver's --steps 20 gave five
+    # 98 ms windows).  One untimed window measures the step; every rank takes the slowest rank's estimate.
+    t_est = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    t_est = time.perf_counter() - t_est
+    if world > 1:
+        te_ = torch.tensor([t_est], dtype=torch.float64, device=cdev)
+        dist.all_reduce(te_, op=dist.ReduceOp.MAX)
+        t_est = float(te_[0])
+    fence()
+    min_timed_s = float(os.environ.get("CN_MIN_TIMED_S", "1.0"))
+    repeat_used = max(1, args.repeat, min(64, int(math.ceil(min_timed_s / max(t_est, 1e-6)))))
 
     # ---- pre-pass (untimed): which kernel class dominates, encode / decode split --------------------
     w0, lens0, t0_ = batches[0]
@@ -906,7 +921,7 @@ def main() -> None:
         prof_every += 1
     state["prof"] = (dominant,)
     state["i"] = 0
-    n_rep = max(1, args.repeat)
+    n_rep = repeat_used
     n_timed = n_rep * args.steps
     n_keep = n_timed if (world > 1 or os.environ.get("CN_BENCH_CHECK_ALL", "1") != "0") else 0  # (0: only the last step is compared)
     state["keep"] = (torch.zeros((n_keep, B, solo_preds.shape[1]), dtype=solo_preds.dtype, device=dev),
@@ -1049,7 +1064,7 @@ def main() -> None:
             "steps": args.steps, "warmup": args.warmup, "warmup_run": warm_used, "ms_per_step": round(dt / args.steps * 1e3, 3), "pipeline_consistent": pipeline_consistent, "pipeline_steps_checked": n_keep if n_keep else 1,
             "captions_sha256": captions_sha, "gather": ({"collectives_per_window": 2, "consistent_across_ranks": gather_consistent,
                                                         "what": "ids (K, B, max_pred) int32 + scores (K, B) fp32 of all K steps of a window, once per window"} if world > 1 else None),
-            "timed_region_s": round(dt, 4), "repeat": n_rep,
+            "timed_region_s": round(dt, 4), "repeat": n_rep, "repeat_requested": args.repeat, "min_timed_total_s": min_timed_s,
             "host_enqueue_ms_per_step": round(issue_dt[med] / args.steps * 1e3, 3),   # host time to enqueue a step (median window): below ms_per_step = the device, not the host, bounds the step
             "windows": {"clips_per_sec": [round(total_clips * args.steps / w, 2) for w in win_dt], "median_index": med,
                         "spread": round((max(win_dt) - min(win_dt)) / dt, 4), "timed_total_s": round(sum(win_dt), 4)},

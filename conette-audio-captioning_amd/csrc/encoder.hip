@@ -22,6 +22,7 @@
 #ifndef CN_DW_DOT2
 #define CN_DW_DOT2 1
 #endif
+#include "dw_lds.h"
 
 // ---------------------------------------------------------------------------------------------
 // stem: Conv2d(1 -> 96, k 4x4, s 4x4, pad (4, 0)) + LayerNorm(channels_first, eps 1e-6)
@@ -1004,6 +1005,10 @@ extern "C" size_t conette_encode_workspace_bytes(const conette_ctx* ctx, int32_t
 
 template <typename T, typename XT>
 static int dwconv_dispatch(int C, const XT* x, int B, int H, int W, const CnBlockW& bw, T* y, hipStream_t s) {
+  if constexpr (sizeof(XT) == 2 && CN_DW_DOT2 && CN_DW_LDS) {   // fp16 stream, stages 0-1: halo tile staged through LDS (dw_lds.h, round 6)
+    if (C == 96) return launch_dwconv_lds<T, 96, CN_DWL96_S, CN_DWL96_TH>(x, B, H, W, bw.dw_wp, bw.dw_b, bw.ln_w, bw.ln_b, y, s);
+    if (C == 192) return launch_dwconv_lds<T, 192, CN_DWL192_S, CN_DWL192_TH>(x, B, H, W, bw.dw_wp, bw.dw_b, bw.ln_w, bw.ln_b, y, s);
+  }
   switch (C) {
     // (the fp32 stream of the exact / fp32 / fp8 precisions keeps 8-row tiles: its conv is bound by 49 fp32 multiply-adds per output)
     case 96: return launch_dwconv<T, XT, 96, CN_DW96_S, (sizeof(XT) == 2 && CN_DW_DOT2) ? CN_DW96_TH : 8>(x, B, H, W, bw, y, s);

@@ -181,14 +181,15 @@ def test_tolerance_zero_recomputes_nothing_and_infinity_everything(models):
 
 
 def test_fp16_stream_overflow_is_loud_and_certified_recovers(models):
-    """ADVICE r05 / VERDICT r05 weak 9: a residual stream beyond 65504 (here: the stem's LayerNorm scaled by 2e5) is inf in the
-    fp16 stream of the 16-bit encoders and NaN from the next LayerNorm on.  The 16-bit precisions now say so
+    """ADVICE r05 / VERDICT r05 weak 9: a residual stream beyond 65504 (here: the LayerScale of stage 1's first block times 3e5 --
+    the fused MLP's packed conversion does not saturate) is inf in the fp16 stream of the 16-bit encoders and NaN from the next
+    LayerNorm on.  The 16-bit precisions now say so
     (conette_encode_nonfinite); the certified precision re-runs those clips through the exact context (fp32 stream) and returns
     the exact precision's ids."""
     from conette_amd import CoNeTTEConfig
     from conette_amd.model import CoNeTTEModel
     sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict().items()}
-    sd["preprocessor.encoder.downsample_layers.0.1.weight"] = sd["preprocessor.encoder.downsample_layers.0.1.weight"] * 2e5
+    sd["preprocessor.encoder.stages.1.0.scale_layer"] = sd["preprocessor.encoder.stages.1.0.scale_layer"] * 3e5
     sd["_extra_state_"] = torch.from_numpy(synth.extra_state_tensor())
     mk = lambda p: CoNeTTEModel(CoNeTTEConfig(**synth.synth_config_dict()), device="cuda:0", state_dict=dict(sd), precision=p,
                                 audioset_idx_to_name=TAGS)
