@@ -47,9 +47,6 @@ if os.environ.get("CN_STEM_MFMA"):  # A/B build: 0 = the VALU stem kernel
 for _k in ("CN_DW96_S", "CN_DW96_TH", "CN_DW192_S", "CN_DW192_TH"):   # A/B builds: tile of the depthwise kernel of stages 0 / 1 (encoder.hip)
     if os.environ.get(_k):
         FLAGS.append(f"-D{_k}=" + os.environ[_k])
-for _k in ("CN_DW_LDS", "CN_DWL96_S", "CN_DWL96_TH", "CN_DWL192_S", "CN_DWL192_TH", "CN_FW_SLIDE"):   # A/B builds: the LDS-staged depthwise kernels of round 6 (dw_lds.h)
-    if os.environ.get(_k):
-        FLAGS.append(f"-D{_k}=" + os.environ[_k])
 if os.environ.get("CN_DW_DOT2"):    # A/B build: 0 = the depthwise conv of the fp16 stream with one v_fma_mix_f32 per tap (encoder.hip)
     FLAGS.append("-DCN_DW_DOT2=" + os.environ["CN_DW_DOT2"])
 if os.environ.get("CN_FW_SPLIT"):   # A/B build: threads per channel of the full-width depthwise kernel at C = 384 (encoder.hip: 2)

@@ -315,8 +315,6 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
   bool has_encoder = false;
   for (int i = 0; i < n_tensors && !has_encoder; ++i) has_encoder = strncmp(names[i], E.c_str(), E.size()) == 0;
   ctx->no_encoder = has_encoder ? 0 : 1;
-  ctx->nonfinite = (int*)B.alloc(256);
-  (void)hipMemset(ctx->nonfinite, 0, 256);
 
   if (has_encoder) {
   // ---- frontend tables ----

@@ -114,7 +114,6 @@ struct conette_ctx {
   int n_cu;  // compute units of the device the context lives on (persistent-kernel grids)
   int enc_reserved_cus;  // CONETTE_OPT_ENCODE_RESERVED_CUS
   int forcing_stepwise;  // CONETTE_OPT_FORCING_STEPWISE
-  int* nonfinite;        // device counter: (clip, frame) rows of frame_embs written with a non-finite value (conette_encode_nonfinite)
   // arena
   char* arena;
   size_t arena_bytes;

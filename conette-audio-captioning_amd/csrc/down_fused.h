@@ -15,6 +15,7 @@
 //     like the fused MLP's epilogue (mlp_rc2.h).
 // Packed stream: fragment (s, t), s < K/16, t < N/32: lane l holds W'[32 t + cn_rc2_chan(l & 31)][16 s + 8 (l >> 5) .. + 8]; then bias'[N] fp32.
 #pragma once
+__device__ void cn_watch_stat(float v);   // the fp16 stream's overflow watch: defined in encoder.hip, the only file that instantiates these kernels
 #include "mlp_rc2.h"
 
 template <int CP> struct DownGeom {
@@ -101,6 +102,7 @@ static __device__ __forceinline__ void cn_down_operand(const XT* __restrict__ X,
       float q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
       q += __shfl_xor(q, 32);
       const float rstd = 1.0f / sqrtf(q * (1.0f / CP) + 1e-6f);
+      if (lane < 32) cn_watch_stat(q);   // (the fp16 stream's overflow watch, encoder.hip)
 #pragma unroll
       for (int j = 0; j < CH; ++j) {
         const f32x4 lo = d[j][0] * rstd, hi = d[j][1] * rstd;

@@ -10,6 +10,16 @@
 #include "ctx.h"
 #include <type_traits>
 
+// Overflow watch of the fp16 residual stream (round 6).  A stream value beyond 65504 is inf where the fused MLP stored it; the
+// saturating conversions further down the encoder then turn the NaNs of the next LayerNorm back into finite garbage, so the
+// frame embeddings cannot be trusted to show it.  Every LayerNorm that reads the stream -- through the 7 x 7 windows of the next
+// block's depthwise conv, in the downsample layers, and the frame-mean head -- counts the positions whose statistics are not
+// finite in this per-device counter; conette_encode_nonfinite() reads and resets it.  (Rare path: one compare per position.)
+__device__ int g_cn_nonfinite;
+__device__ __forceinline__ void cn_watch_stat(float v) {
+  if (!(__builtin_fabsf(v) <= 3.0e38f)) atomicAdd(&g_cn_nonfinite, 1);
+}
+
 #include "gemm2.h"
 #include "mlp_rc2.h"
 #include "mlp_rs.h"
@@ -22,7 +32,6 @@
 #ifndef CN_DW_DOT2
 #define CN_DW_DOT2 1
 #endif
-#include "dw_lds.h"
 
 // ---------------------------------------------------------------------------------------------
 // stem: Conv2d(1 -> 96, k 4x4, s 4x4, pad (4, 0)) + LayerNorm(channels_first, eps 1e-6)
@@ -474,6 +483,7 @@ __global__ __launch_bounds__((C > 384 ? 384 : C) * S) void cn_dwconv_ln_kernel(c
       for (int j = 0; j < PARTS; ++j) var += s_ps[j * NPOS + pos];
       s_mean[pos] = mean;
       s_rstd[pos] = 1.0f / sqrtf(var * (1.0f / C) + 1e-6f);
+      cn_watch_stat(var);
     }
     __syncthreads();
   }
@@ -734,6 +744,7 @@ __global__ __launch_bounds__(C* SPLIT > 384 ? 768 : 384) void cn_dwconv_ln_fw_ke
       s_rstd[p0] = 1.0f / sqrtf(q0 * (1.0f / C) + 1e-6f);
       s_mean[p1] = m1;
       s_rstd[p1] = 1.0f / sqrtf(q1 * (1.0f / C) + 1e-6f);
+      cn_watch_stat(q0 + q1);
     }
   }
   __syncthreads();
@@ -852,6 +863,7 @@ __global__ __launch_bounds__(256) void cn_ln_patchify_kernel(const XT* __restric
       }
     const float rstd = 1.0f / sqrtf(group_sum(s2) * (1.0f / C) + 1e-6f);
     if (pos >= n_pos || !act) continue;
+    if (ll == 0) cn_watch_stat(rstd);
     const int w = (int)(pos % W);
     const long t = pos / W;
     const int h = (int)(t % H);
@@ -868,13 +880,10 @@ __global__ __launch_bounds__(256) void cn_ln_patchify_kernel(const XT* __restric
 }
 
 // frame_embs[b][t][c] = mean over the W freq positions (convnext.py:306); also an operand-type copy
-// + the overflow check of the fp16 residual stream (round 6): a value beyond 65504 anywhere in the stream is inf there, NaN after
-// the next LayerNorm, and reaches this kernel through the residual adds, the 7 x 7 windows and the downsampling -- one test per
-// output value here, one atomic per (clip, frame) row that holds any (conette_encode_nonfinite reads the counter)
+// + the last post of the overflow watch (g_cn_nonfinite above): the output of the encoder's last block has no LayerNorm behind it
 template <typename T, typename XT>
 __global__ __launch_bounds__(256) void cn_frame_mean_kernel(const XT* __restrict__ x, int W, int C,
-                                                            float* __restrict__ fe, T* __restrict__ fe_t,
-                                                            int* __restrict__ nonfinite) {
+                                                            float* __restrict__ fe, T* __restrict__ fe_t) {
   const size_t bt = blockIdx.x;
   bool bad = false;
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -885,7 +894,7 @@ __global__ __launch_bounds__(256) void cn_frame_mean_kernel(const XT* __restrict
     fe[bt * C + c] = m;
     if (fe_t) fe_t[bt * C + c] = cn_from_f32<T>(m);
   }
-  if (__syncthreads_or(bad ? 1 : 0) && threadIdx.x == 0) atomicAdd(nonfinite, 1);
+  if (__syncthreads_or(bad ? 1 : 0) && threadIdx.x == 0) atomicAdd(&g_cn_nonfinite, 1);
 }
 
 // clip head input: max_t + mean_t -> nn.LayerNorm(768, eps 1e-6) (convnext.py:324-330)
@@ -1005,10 +1014,6 @@ extern "C" size_t conette_encode_workspace_bytes(const conette_ctx* ctx, int32_t
 
 template <typename T, typename XT>
 static int dwconv_dispatch(int C, const XT* x, int B, int H, int W, const CnBlockW& bw, T* y, hipStream_t s) {
-  if constexpr (sizeof(XT) == 2 && CN_DW_DOT2 && CN_DW_LDS) {   // fp16 stream, stages 0-1: halo tile staged through LDS (dw_lds.h, round 6)
-    if (C == 96) return launch_dwconv_lds<T, 96, CN_DWL96_S, CN_DWL96_TH>(x, B, H, W, bw.dw_wp, bw.dw_b, bw.ln_w, bw.ln_b, y, s);
-    if (C == 192) return launch_dwconv_lds<T, 192, CN_DWL192_S, CN_DWL192_TH>(x, B, H, W, bw.dw_wp, bw.dw_b, bw.ln_w, bw.ln_b, y, s);
-  }
   switch (C) {
     // (the fp32 stream of the exact / fp32 / fp8 precisions keeps 8-row tiles: its conv is bound by 49 fp32 multiply-adds per output)
     case 96: return launch_dwconv<T, XT, 96, CN_DW96_S, (sizeof(XT) == 2 && CN_DW_DOT2) ? CN_DW96_TH : 8>(x, B, H, W, bw, y, s);
@@ -1187,7 +1192,7 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
   const int Tn = g.H[3];
   CnProfScope ps_heads(ctx, CONETTE_PROF_HEADS, s);
   hipLaunchKernelGGL((cn_frame_mean_kernel<T, XT>), dim3((unsigned)(B * Tn)), dim3(256), 0, s, xc, g.W[3], CN_FEAT,
-                     frame_embs, (T*)nullptr, ctx->nonfinite);
+                     frame_embs, (T*)nullptr);
   CN_LAUNCH_CHECK();
   if (clip_probs) {
     hipLaunchKernelGGL((cn_clip_pool_ln_kernel<T>), dim3((unsigned)B), dim3(256), 0, s, frame_embs, Tn, ctx->norm_w,
@@ -1206,9 +1211,13 @@ extern "C" int conette_encode_nonfinite(conette_ctx* ctx, void* stream, int32_t*
   }
   hipStream_t s = (hipStream_t)stream;
   int32_t host = 0;
-  CN_HIP(hipMemcpyAsync(&host, ctx->nonfinite, sizeof(host), hipMemcpyDeviceToHost, s));
+  CN_HIP(hipMemcpyFromSymbolAsync(&host, HIP_SYMBOL(g_cn_nonfinite), sizeof(host), 0, hipMemcpyDeviceToHost, s));
   CN_HIP(hipStreamSynchronize(s));
-  if (host != 0) CN_HIP(hipMemsetAsync(ctx->nonfinite, 0, sizeof(host), s));
+  if (host != 0) {
+    const int32_t zero = 0;
+    CN_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_cn_nonfinite), &zero, sizeof(zero), 0, hipMemcpyHostToDevice, s));
+    CN_HIP(hipStreamSynchronize(s));
+  }
   *count = host;
   return CN_OK;
 }

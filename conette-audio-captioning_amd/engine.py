@@ -491,7 +491,8 @@ class Engine:
         lens_d = frame_lens.to(self.device)
         bos_d = bos_ids.to(self.device)
         if wave is not None:
-            fe_x, _ = self.encode(wave.index_select(0, idx), exact=True)
+            fe_x, clip_x = self.encode(wave.index_select(0, idx), exact=True)
+            res["recomputed_idx"], res["recomputed_clip_probs"] = idx, clip_x    # (the exact encoder's tag probabilities of those clips)
         else:
             fe_x = frame_embs.to(self.device).index_select(0, idx)
         rx = self.decode(fe_x, lens_d.index_select(0, idx), bos_d.index_select(0, idx), forbid_mask, beam, min_pred, max_pred,
@@ -502,8 +503,8 @@ class Engine:
         return res
 
     def encode_nonfinite(self) -> int:
-        """(clip, frame) rows of frame embeddings that encodes of this engine wrote with non-finite values since the last call
-        (the fp16 residual stream of the 16-bit precisions overflowed); waits for the current stream."""
+        """Positions whose LayerNorm statistics were not finite in the encodes of this process since the last call (the fp16
+        residual stream of the 16-bit precisions overflowed: include/conette_hip.h); waits for the current stream."""
         n = C.c_int32(0)
         _check(self.lib.conette_encode_nonfinite(self._ctx, _stream(), C.byref(n)), "conette_encode_nonfinite")
         return int(n.value)

@@ -282,7 +282,7 @@ class CoNeTTEModel:
             if preprocess:
                 batch = self.preprocessor(x, sr, x_shapes)
                 clip_probs = batch.pop("clip_probs")
-                tags = probs_to_names(clip_probs, threshold, self.audioset_idx_to_name)
+                tags = True   # (names from the probabilities below, once the certified precision has patched re-run clips)
             else:
                 assert isinstance(x, Tensor) and isinstance(x_shapes, Tensor)
                 batch = {"audio": x.to(self.device), "audio_shape": x_shapes.to(self.device)}
@@ -310,21 +310,28 @@ class CoNeTTEModel:
                 if len(parts) >= 2:
                     source_lst[i] = "_".join(parts[1:])
 
-            outs = self._generate(batch["audio"], batch["audio_shape"], dataset_lst, source_lst,
-                                  beam_size=beam_size, min_pred_size=min_pred_size, max_pred_size=max_pred_size,
-                                  forbid_rep_mode=forbid_rep_mode, wave=wave)
+            overflow = False
             if preprocess and self.engine.precision in (PREC_BF16, PREC_F16):
-                # the fp16 residual stream of the 16-bit encoders holds |x| <= 65504; beyond it the embeddings are NaN.  The
-                # certified precision has re-run such clips through the exact context (fp32 stream); the others fail loudly.
+                # the fp16 residual stream of the 16-bit encoders holds |x| <= 65504; beyond it the embeddings are garbage
+                # (include/conette_hip.h: conette_encode_nonfinite).  The certified precision re-runs the whole batch through
+                # the exact context (fp32 stream) then; the others fail loudly.
                 bad = self.engine.encode_nonfinite()
                 if bad and not self.engine.certified:
                     raise RuntimeError(
-                        f"precision={self.engine.precision_name!r}: the encoder's fp16 residual stream overflowed ({bad} frame "
-                        "rows of non-finite embeddings); use precision='certified', 'exact' or 'fp32' for this checkpoint")
+                        f"precision={self.engine.precision_name!r}: the encoder's fp16 residual stream overflowed ({bad} "
+                        "positions with non-finite LayerNorm statistics); use precision='certified', 'exact' or 'fp32' for "
+                        "this checkpoint")
+                overflow = bad > 0
+            outs = self._generate(batch["audio"], batch["audio_shape"], dataset_lst, source_lst,
+                                  beam_size=beam_size, min_pred_size=min_pred_size, max_pred_size=max_pred_size,
+                                  forbid_rep_mode=forbid_rep_mode, wave=wave, recompute_all=overflow)
             outs["tasks"] = tasks
+            patch = outs.pop("_clip_probs_patch", None)
             if clip_probs is not None and tags is not None:
+                if patch is not None:    # certified: clips the exact context re-encoded carry its tag probabilities too
+                    clip_probs.index_copy_(0, patch[0], patch[1])
                 outs["tags_probs"] = clip_probs
-                outs["tags"] = tags
+                outs["tags"] = probs_to_names(clip_probs, threshold, self.audioset_idx_to_name)
             return outs
 
     def __call__(self, x, sr=None, x_shapes=None, preprocess: bool = True, threshold=0.3, task=None, beam_size=None,
@@ -433,7 +440,7 @@ class CoNeTTEModel:
 
     def _generate(self, audio: Tensor, audio_shape: Tensor, datasets: List[str], sources: List[Optional[str]], *,
                   beam_size=None, min_pred_size=None, max_pred_size=None, forbid_rep_mode=None,
-                  wave: Optional[Tensor] = None) -> Dict[str, Any]:
+                  wave: Optional[Tensor] = None, recompute_all: bool = False) -> Dict[str, Any]:
         """CoNeTTEPLM.forward("generate") = encode_audio + decode_audio + decode_text (conette.py:352-450)."""
         if audio.ndim == 4:  # FrameIdentEncoder (nn/encoders/ident.py:19-21)
             audio = audio.squeeze(dim=1)
@@ -446,15 +453,18 @@ class CoNeTTEModel:
         bos = self.batch_to_task_token_ids(datasets, sources)
         if self.engine.certified:   # base-precision search + margins; uncertified clips re-run through the exact context
             res = self.engine.generate_certified(wave, audio, lens, bos, self.get_forbid_rep_mask(forbid_rep_mode), beam,
-                                                 min_pred, max_pred)
+                                                 min_pred, max_pred, tol=(float("inf"), 0.0, 0.0) if recompute_all else None)
         else:
             res = self.engine.decode(audio, lens, bos, self.get_forbid_rep_mask(forbid_rep_mode), beam, min_pred, max_pred)
         self.last_recomputed = res.get("recomputed")   # certified: (B,) bool, the clips the exact context re-ran
         pred_size, best_maxlen = (int(v) for v in res["sizes"].tolist())  # the one host sync of the path
         preds = res["best_preds"][:, :best_maxlen].to(torch.long).contiguous()
         mult_preds = res["mult_preds"][:, :, :pred_size].to(torch.long).contiguous()
-        return {
+        out = {
             "cands": self.tokenizer.decode_rec(preds), "preds": preds, "lprobs": res["best_lprobs"],
             "mult_cands": self.tokenizer.decode_rec(mult_preds), "mult_preds": mult_preds,
             "mult_lprobs": res["mult_lprobs"],
         }
+        if "recomputed_clip_probs" in res:
+            out["_clip_probs_patch"] = (res["recomputed_idx"], res["recomputed_clip_probs"])   # (popped by forward)
+        return out

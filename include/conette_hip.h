@@ -118,12 +118,14 @@ int conette_encode(conette_ctx* ctx, const float* wave, int32_t batch, int32_t n
                    float* clip_probs, const conette_encode_taps* taps, void* workspace, size_t workspace_bytes,
                    void* stream);
 
-/* The 16-bit precisions keep the encoder's residual stream in IEEE fp16 (|x| <= 65504).  A value beyond that becomes inf, NaN
- * after the next LayerNorm (convnext.py:61-66), and reaches frame_embs; conette_encode counts the (clip, frame) rows of
- * frame_embs it wrote with a non-finite value.  This call waits for `stream`, returns the count accumulated by the encodes of
- * this context since the previous call in *count and resets it.  Non-zero = at least one clip's embeddings are unusable in
- * this precision: run it through a CONETTE_PREC_F16X2 / _F32 context (fp32 stream).  The ONE blocking entry point besides
- * conette_create; a host that never calls it loses nothing but the diagnosis (NaN scores still mark the clip). */
+/* The 16-bit precisions keep the encoder's residual stream in IEEE fp16 (|x| <= 65504).  A value beyond that is inf where the
+ * fused MLP stored it and NaN after the next LayerNorm (convnext.py:61-66) -- and the saturating conversions further down the
+ * encoder turn such NaNs back into finite garbage, so the frame embeddings do not reliably show it.  Every LayerNorm of
+ * conette_encode that reads the stream (the next block's depthwise conv + LN, the downsample layers, the frame-mean head) counts
+ * the positions whose statistics are not finite in one per-device counter.  This call waits for `stream`, returns the count
+ * accumulated by the encodes of this process on the context's device since the previous call in *count and resets it.
+ * Non-zero = some clip's embeddings are unusable in this precision: run it through a CONETTE_PREC_F16X2 / _F32 context (fp32
+ * stream).  The ONE blocking entry point besides conette_create; a host that never calls it loses the diagnosis. */
 int conette_encode_nonfinite(conette_ctx* ctx, void* stream, int32_t* count);
 
 /* a9-a14: CoNeTTEPLM.encode_audio + decode_audio("generate") = nn/decoding/beam.py:22-227 with

@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _run(extra, gpus=2):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["CN_BENCH_SHARE_GPU"] = "1"
+    env["CN_MIN_TIMED_S"] = "0"     # exactly --repeat windows (bench.py raises the count until the timed region fills 1 s otherwise)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "6", "--repeat", "2", "--warmup", "3",
                         "--cpu-clips", "0", "--parity-clips", "0", "--also", ""] + extra, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]

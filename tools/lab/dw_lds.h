@@ -1,4 +1,5 @@
-// Depthwise 7x7 + LayerNorm for the fp16 residual stream of stages 0-1 (C = 96 / 192), halo tile staged through LDS (round 6).
+// EXPERIMENT, NOT PART OF THE LIBRARY (round 6; measured slower than the shipped kernel: profiles/r06_notes.md section 2).
+// Depthwise 7x7 + LayerNorm for the fp16 residual stream of stages 0-1 (C = 96 / 192), halo tile staged through LDS.
 //
 // cn_dwconv_ln_kernel (encoder.hip) fetches its input straight from global memory, one 2-byte load per lane, tap column and halo
 // row: 3.75 loads per output with 12 x 4 patches, each a wave instruction that moves 128 bytes -- after the v_dot2 form took 40 %
@@ -13,7 +14,7 @@
 // cn_dwconv_ln_kernel.  The LayerNorm phases are that kernel's (same LDS tile, same order of every sum), on an LDS tile that
 // reuses the halo's space behind a barrier.
 #pragma once
-#include "common.h"
+#include "common.h"   // (-I conette-audio-captioning_amd/csrc)
 
 #ifndef CN_DW_LDS
 #define CN_DW_LDS 1   // 0 (A/B builds): stages 0-1 of the fp16 stream on cn_dwconv_ln_kernel
@@ -30,6 +31,10 @@
 #endif
 #ifndef CN_DWL192_TH
 #define CN_DWL192_TH 6
+#endif
+
+#ifndef CN_DWL_ABL
+#define CN_DWL_ABL 0   // lab builds (tools/lab/dwl_lab.hip): 1 = no global loads, 2 = no convolution, 4 = no LayerNorm / store
 #endif
 
 template <int C, int S, int TH> struct DwLds {
@@ -83,8 +88,12 @@ __global__ __launch_bounds__(C * S) void cn_dwconv_ln_lds_kernel(const half_t* _
     const int c8 = it % C8, q = (it / C8) % HQ, u = it / (C8 * HQ);
     const int ww = min(max(wb - 3 + q, 0), W - 1);
     const int hh0 = min(max(h0 - 3 + 2 * u, 0), H - 1), hh1 = min(max(h0 - 2 + 2 * u, 0), H - 1);
-    ra[k] = *(const u32x4*)(xb + ((size_t)hh0 * W + ww) * C + c8 * 8);
-    rb[k] = *(const u32x4*)(xb + ((size_t)hh1 * W + ww) * C + c8 * 8);
+    if constexpr (CN_DWL_ABL & 1) {
+      ra[k] = u32x4{(unsigned)it, 1u, 2u, 3u}, rb[k] = u32x4{4u, 5u, (unsigned)hh0, (unsigned)ww};
+    } else {
+      ra[k] = *(const u32x4*)(xb + ((size_t)hh0 * W + ww) * C + c8 * 8);
+      rb[k] = *(const u32x4*)(xb + ((size_t)hh1 * W + ww) * C + c8 * 8);
+    }
   }
 #pragma unroll
   for (int k = 0; k < NIT; ++k) {
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(C * S) void cn_dwconv_ln_lds_kernel(const half_t* _
     for (int e = 0; e < 4; ++e) acc[a][e] = bias;
   const unsigned* hp = s_h + (sidx * 4) * C + c;
 #pragma unroll
-  for (int u = 0; u < NPR; ++u) {
+  for (int u = 0; u < ((CN_DWL_ABL & 2) ? 1 : NPR); ++u) {
     cn_h2 p[10];
 #pragma unroll
     for (int q = 0; q < 10; ++q) p[q] = __builtin_bit_cast(cn_h2, hp[(u * HQ + q) * C]);
@@ -151,6 +160,10 @@ __global__ __launch_bounds__(C * S) void cn_dwconv_ln_lds_kernel(const half_t* _
 
   // ---- LayerNorm over C + store: the phases of cn_dwconv_ln_kernel (lane = position statistics, 8 channels per store item)
   constexpr int NPOS = L::NPOS, PARTS = L::PARTS, CPT = L::CPT;
+  if constexpr (CN_DWL_ABL & 4) {
+    if (s_v[tid] == 123.456f) y[tid] = (T)1.0f;
+    return;
+  }
   float* s_ps = s_v + NPOS * PITCH;       // [PARTS][NPOS]
   float* s_mean = s_ps + NPOS * PARTS;    // [NPOS]
   float* s_rstd = s_mean + NPOS;          // [NPOS]
