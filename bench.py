@@ -57,7 +57,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=64, help="clips per GPU (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=0, help="total clips, sharded over the GPUs (strong scaling)")
     ap.add_argument("--beam", type=int, default=3)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "bf16+f16dec", "fp8", "mixed", "mixed16", "fp32", "exact"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "bf16+f16dec", "mixed", "mixed16", "fp32", "exact"])
     ap.add_argument("--repeat", type=int, default=5,
                     help="timed windows of --steps steps each (barrier + synchronize around every window); `value` and "
                          "`ms_per_step` are the MEDIAN window's, every window's clips/s is listed under `windows`")
@@ -365,7 +365,7 @@ def parity_report(args, Engine, eng, sd, dev, w0, lens0, bos0, forbid, t_audio, 
     n = min(args.parity_clips, w0.shape[0])
     wv, ln, bs = w0[:n].contiguous(), lens0[:n].contiguous(), bos0[:n].contiguous()
     engines = {args.precision: eng}
-    for name in ("bf16", "f16", "bf16+f16dec", "fp8", "mixed", "mixed16", "exact", "fp32"):
+    for name in ("bf16", "f16", "bf16+f16dec", "mixed", "mixed16", "exact", "fp32"):
         if name not in engines:
             try:
                 engines[name] = Engine(sd, precision=name, device=dev)
@@ -1070,7 +1070,7 @@ def main() -> None:
                         "spread": round((max(win_dt) - min(win_dt)) / dt, 4), "timed_total_s": round(sum(win_dt), 4)},
             "rank_clips_per_sec": rank_rates,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "fp8": "fp8 (e4m3 pointwise convolutions of stages 0-2) + bf16", "fp32": "f32", "exact": "f16x2", "mixed": "bf16 encoder + f16x2 decoder", "f16": "f16",
+            "dtype": {"bf16": "bf16", "fp32": "f32", "exact": "f16x2", "mixed": "bf16 encoder + f16x2 decoder", "f16": "f16",
                       "mixed16": "f16 encoder + f16x2 decoder", "bf16+f16dec": "bf16 encoder + f16 decoder"}[args.precision], "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": B, "global_batch": total_clips, "beam_size": beam,
                        "parallelism": f"dp{world}", "world_size_observed": world_observed, "allreduce_of_ones": ones_sum,

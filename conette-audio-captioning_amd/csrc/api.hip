@@ -12,7 +12,6 @@
 #include "mlp_rc2.h"
 #include "mlp_rs.h"
 #include "mlp_rs16.h"
-#include "mlp_f8.h"
 #include "mlp_sp.h"
 #include "down_fused.h"
 
@@ -260,8 +259,10 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
     return CN_ERR_ARG;
   }
   if (cfg->precision != CONETTE_PREC_F32 && cfg->precision != CONETTE_PREC_BF16 && cfg->precision != CONETTE_PREC_F16X2 &&
-      cfg->precision != CONETTE_PREC_FP8 && cfg->precision != CONETTE_PREC_F16) {
-    cn_set_error("create: unknown precision %d", cfg->precision);
+      cfg->precision != CONETTE_PREC_F16) {
+    cn_set_error(cfg->precision == 3 ? "create: precision 3 (the experimental fp8 mode of ABI 2) was withdrawn in ABI 3: e4m3 operands cost the "
+                                       "frame embeddings 4 %% whatever the scaling (profiles/r06_notes.md section 3)"
+                                     : "create: unknown precision %d", cfg->precision);
     return CN_ERR_ARG;
   }
   if (cfg->n_layers < 1 || cfg->n_layers > CN_MAX_LAYERS || cfg->d_model != 256 || cfg->nhead != 8 ||
@@ -274,9 +275,8 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
   memset(ctx, 0, sizeof(*ctx));
   ctx->cfg = *cfg;
   ctx->rt = new CnRuntime();
-  ctx->esize = (cfg->precision == CONETTE_PREC_BF16 || cfg->precision == CONETTE_PREC_FP8 || cfg->precision == CONETTE_PREC_F16) ? 2 : 4;
+  ctx->esize = (cfg->precision == CONETTE_PREC_BF16 || cfg->precision == CONETTE_PREC_F16) ? 2 : 4;
   ctx->f16 = cfg->precision == CONETTE_PREC_F16 ? 1 : 0;
-  ctx->fp8 = cfg->precision == CONETTE_PREC_FP8 ? 1 : 0;
   ctx->sp16 = cfg->precision == CONETTE_PREC_F16X2 ? 1 : 0;
   {
     int dev = 0, n_cu = 0;
@@ -287,7 +287,6 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
   }
   size_t total = (1 << 20) + (size_t)CN_N_BINS * CN_N_MELS * 4;  // (+ the band-compact mel matrix, at most a dense copy)
   for (int i = 0; i < n_tensors; ++i) total += cn_align((size_t)numel[i] * 4) + 256;
-  if (cfg->precision == CONETTE_PREC_FP8) total += 16u << 20;
   if (cfg->precision == CONETTE_PREC_F16X2) {
     total += 8u << 20;   // the fp16 hi / lo streams of the 6 fused ConvNeXt blocks (~3.4 MB)
     // + per decoder layer the hi / lo fragment streams of dec_block.h (12 passes of 128 KB) and dec_ffn.h (4 per hidden chunk)
@@ -460,7 +459,7 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
         if (w) hipLaunchKernelGGL(pk_taps_last, dim3((C * 49 + 255) / 256), dim3(256), 0, 0, w, dst, C, 49);
         bw.dw_w = dst;
         bw.dw_wp = nullptr;
-        if (ctx->esize == 2 && !ctx->fp8) {   // the precisions whose encoder stream is fp16 (encoder.hip: XT = half_t)
+        if (ctx->esize == 2) {   // the precisions whose encoder stream is fp16 (encoder.hip: XT = half_t)
           unsigned* wp = (unsigned*)B.alloc((size_t)C * 42 * 4);
           if (w) hipLaunchKernelGGL(pk_dw_pairs, dim3((C * 42 + 255) / 256), dim3(256), 0, 0, w, wp, C);
           bw.dw_wp = wp;
@@ -473,20 +472,12 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
         bw.w2 = B.operand(p + "pwconv2.weight", (int64_t)4 * C * C, 0, (int64_t)4 * C * C);
         bw.b2 = B.f32(p + "pwconv2.bias", C);
         bw.mlp_stream = nullptr;
-        bw.mlp_f8 = nullptr;
         bw.mlp_sp = nullptr;
         if (ctx->sp16 && C <= 192) {
           void* ms = B.alloc(C == 96 ? SpGeom<96>::TOTAL_BYTES : SpGeom<192>::TOTAL_BYTES);
           const float* w1 = B.find(p + "pwconv1.weight", (int64_t)4 * C * C);
           const float* w2 = B.find(p + "pwconv2.weight", (int64_t)4 * C * C);
           if (w1 && w2 && bw.b1 && bw.b2 && bw.scale && cn_pack_mlp_sp(w1, bw.b1, w2, bw.b2, bw.scale, C, ms, 0) == CN_OK) bw.mlp_sp = ms;
-        }
-        if (ctx->fp8 && C <= 384) {
-          const size_t bytes = C == 96 ? Rc2F8Geom<96>::TOTAL_BYTES : C == 192 ? Rc2F8Geom<192>::TOTAL_BYTES : Rc2F8Geom<384>::TOTAL_BYTES;
-          void* ms = B.alloc(bytes);
-          const float* w1 = B.find(p + "pwconv1.weight", (int64_t)4 * C * C);
-          const float* w2 = B.find(p + "pwconv2.weight", (int64_t)4 * C * C);
-          if (w1 && w2 && bw.b1 && bw.b2 && bw.scale && cn_pack_mlp_f8(w1, bw.b1, w2, bw.b2, bw.scale, C, ms, 0) == CN_OK) bw.mlp_f8 = ms;
         }
         if (ctx->esize == 2 && C <= 384) {
           // Rc2Geom<C, 1>::TOTAL_BYTES; the role-split streams of C = 384 are [C/8][C/8 + 1] KB (mlp_rs.h) or [C/8][C/8 + 2] KB
@@ -500,7 +491,7 @@ extern "C" int conette_create(const conette_config* cfg, int32_t n_tensors, cons
             // C = 384 runs the role-split kernel (mlp_rs.h): same fragments, entry e = [W1 of chunk e | W2 of chunk e - 2]
 #ifndef CN_NO_RS
             // (with the 16-bit residual stream of the bf16 / f16 precisions: mlp_rs16.h, the same pipeline on 16x16x32 MFMAs)
-            if (C == 384 && CN_RS16 && !ctx->fp8) {
+            if (C == 384 && CN_RS16) {
               const int u16 = (C / 8) * (C / 8 + 2) * 64;
               CN_H16_CALL(ctx, hipLaunchKernelGGL(pk_mlp_rs16<HT>, dim3((u16 + 255) / 256), dim3(256), 0, 0, w1, bw.b1, w2, bw.b2, bw.scale, C, (HT*)ms));
             } else if (C == 384) CN_H16_CALL(ctx, hipLaunchKernelGGL(pk_mlp_rs<HT>, dim3((units + 255) / 256), dim3(256), 0, 0, w1, bw.b1, w2, bw.b2, bw.scale, C, (HT*)ms));

@@ -101,11 +101,6 @@ __device__ __forceinline__ float cn_sp16_value(unsigned w) {
   return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu)) + (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
 }
 
-// ---- f8: OCP e4m3 activation storage of CONETTE_PREC_FP8 (the y operand of the fp8 fused MLP, scale 1) -----------------
-struct f8_t {
-  unsigned char v;
-};
-
 #define CN_OK 0
 #define CN_ERR_ARG 1
 #define CN_ERR_HIP 2
@@ -160,9 +155,6 @@ template <typename T> __device__ __forceinline__ T cn_from_f32(float x);
 template <> __device__ __forceinline__ float cn_from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t cn_from_f32<bf16_t>(float x) { return (bf16_t)x; }
 template <> __device__ __forceinline__ half_t cn_from_f32<half_t>(float x) { return (half_t)__builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }
-template <> __device__ __forceinline__ f8_t cn_from_f32<f8_t>(float x) {
-  return f8_t{(unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(x, 0.f, 0, false) & 0xff)};
-}
 template <> __device__ __forceinline__ sp16_t cn_from_f32<sp16_t>(float x) { return __builtin_bit_cast(sp16_t, cn_sp16_bits(x)); }
 __device__ __forceinline__ float cn_to_f32(float x) { return x; }
 __device__ __forceinline__ float cn_to_f32(bf16_t x) { return (float)x; }
@@ -170,7 +162,7 @@ __device__ __forceinline__ float cn_to_f32(half_t x) { return (float)x; }
 __device__ __forceinline__ float cn_to_f32(sp16_t x) { return (float)x.hi + (float)x.lo; }
 
 // ---- the residual stream's element type XT ------------------------------------------------------------------------------
-// float in the fp32 / exact / fp8 precisions; half_t (IEEE fp16) in the 16-bit precisions since round 5: every kernel that
+// float in the fp32 / exact precisions; half_t (IEEE fp16) in the 16-bit precisions since round 5: every kernel that
 // touches the stream moves half the bytes (a ConvNeXt block: 16 C -> 10 C bytes per position), and the stream's 11 significant
 // bits cost the bf16 precision nothing measurable (frame embeddings 4.43e-3 -> 4.48e-3 rel. rms off the fp32 oracle) and the
 // f16 precision 5.4e-4 -> 8.5e-4 (oracle/rounding_study.py).  |x| <= 65504 is required of the stream (cn_from_f32<half_t>
@@ -352,12 +344,6 @@ __device__ __forceinline__ void cn_store4(half_t* p, float a, float b, float c, 
 __device__ __forceinline__ void cn_store4(sp16_t* p, float a, float b, float c, float d) {
   *(u32x4*)p = u32x4{cn_sp16_bits(a), cn_sp16_bits(b), cn_sp16_bits(c), cn_sp16_bits(d)};
 }
-__device__ __forceinline__ void cn_store4(f8_t* p, float a, float b, float c, float d) {
-  int w = 0;
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
-  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-  *(int*)p = w;
-}
 // store 8 consecutive values as T; p must be 8-element aligned (bf16: ONE 16-byte store)
 __device__ __forceinline__ void cn_store8(float* p, const float (&o)[8]) {
   *(f32x4*)p = f32x4{o[0], o[1], o[2], o[3]};
@@ -366,14 +352,6 @@ __device__ __forceinline__ void cn_store8(float* p, const float (&o)[8]) {
 __device__ __forceinline__ void cn_store8(sp16_t* p, const float (&o)[8]) {
   *(u32x4*)p = u32x4{cn_sp16_bits(o[0]), cn_sp16_bits(o[1]), cn_sp16_bits(o[2]), cn_sp16_bits(o[3])};
   *(u32x4*)(p + 4) = u32x4{cn_sp16_bits(o[4]), cn_sp16_bits(o[5]), cn_sp16_bits(o[6]), cn_sp16_bits(o[7])};
-}
-__device__ __forceinline__ void cn_store8(f8_t* p, const float (&o)[8]) {
-  int lo = 0, hi = 0;
-  lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[0], o[1], lo, false);
-  lo = __builtin_amdgcn_cvt_pk_fp8_f32(o[2], o[3], lo, true);
-  hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[4], o[5], hi, false);
-  hi = __builtin_amdgcn_cvt_pk_fp8_f32(o[6], o[7], hi, true);
-  *(int2*)p = int2{lo, hi};
 }
 __device__ __forceinline__ void cn_store8(half_t* p, const float (&o)[8]) {
   *(f16x8*)p = f16x8{cn_from_f32<half_t>(o[0]), cn_from_f32<half_t>(o[1]), cn_from_f32<half_t>(o[2]), cn_from_f32<half_t>(o[3]),

@@ -29,8 +29,6 @@ struct CnBlockW {
   // bf16, C <= 384: pwconv1 / pwconv2 (+ b1, LayerScale, b2) as the MFMA-fragment stream of mlp_rc2.h:
   // [hidden chunk C/8][fragment C/8 + 1][lane 64][8 bf16] followed by s * b2 (fp32, C)
   const void* mlp_stream;
-  // CONETTE_PREC_FP8, C <= 384: the same block as the e4m3 fragment stream + scales of mlp_f8.h (else nullptr)
-  const void* mlp_f8;
   // CONETTE_PREC_F16X2, C <= 192: the block as the fp16 hi / lo fragment stream of mlp_sp.h (else nullptr)
   const void* mlp_sp;
 };
@@ -76,7 +74,6 @@ struct conette_ctx {
   uint32_t prof_mask;
   int dec_unfused;  // CONETTE_OPT_DECODE_FUSION = 0: one launch per sub-layer (the cross-check path of the tests)
   int esize;  // operand element size (2 or 4)
-  int fp8;    // CONETTE_PREC_FP8: bf16 everywhere except the pointwise convolutions of stages 0-2 (e4m3 operands)
   int sp16;   // CONETTE_PREC_F16X2: operands are sp16_t (fp16 hi/lo pairs, 4 bytes)
   int f16;    // CONETTE_PREC_F16: operands are half_t (the bf16 kernels instantiated for fp16), esize 2
   int no_encoder;  // decoder-only context (a BaselinePLM-layout checkpoint: no "preprocessor.encoder." tensors at create)
@@ -138,13 +135,11 @@ struct CnProfScope {
 // ---- stage entry points implemented in the .hip files ---------------------------------------
 int cn_frontend(conette_ctx* ctx, const float* wave, int B, int L, float* out, hipStream_t s);
 
-// `return CALL;` with OT = the operand type of the context's precision (bf16_t also carries the fp8 mode, whose only e4m3
-// operands are those of the fused MLP)
+// `return CALL;` with OT = the operand type of the context's precision
 #define CN_BY_PRECISION(ctx, ...)                                                          \
   do {                                                                                     \
     switch ((ctx)->cfg.precision) {                                                        \
-      case CONETTE_PREC_BF16:                                                              \
-      case CONETTE_PREC_FP8: { typedef bf16_t OT; return __VA_ARGS__; }                    \
+      case CONETTE_PREC_BF16: { typedef bf16_t OT; return __VA_ARGS__; }                   \
       case CONETTE_PREC_F16: { typedef half_t OT; return __VA_ARGS__; }                    \
       case CONETTE_PREC_F16X2: { typedef sp16_t OT; return __VA_ARGS__; }                  \
       default: { typedef float OT; return __VA_ARGS__; }                                   \

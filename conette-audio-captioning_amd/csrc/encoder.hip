@@ -24,7 +24,6 @@ __device__ __forceinline__ void cn_watch_stat(float v) {
 #include "mlp_rc2.h"
 #include "mlp_rs.h"
 #include "mlp_rs16.h"
-#include "mlp_f8.h"
 #include "mlp_sp.h"
 #include "down_fused.h"
 
@@ -1015,7 +1014,7 @@ extern "C" size_t conette_encode_workspace_bytes(const conette_ctx* ctx, int32_t
 template <typename T, typename XT>
 static int dwconv_dispatch(int C, const XT* x, int B, int H, int W, const CnBlockW& bw, T* y, hipStream_t s) {
   switch (C) {
-    // (the fp32 stream of the exact / fp32 / fp8 precisions keeps 8-row tiles: its conv is bound by 49 fp32 multiply-adds per output)
+    // (the fp32 stream of the exact / fp32 precisions keeps 8-row tiles: its conv is bound by 49 fp32 multiply-adds per output)
     case 96: return launch_dwconv<T, XT, 96, CN_DW96_S, (sizeof(XT) == 2 && CN_DW_DOT2) ? CN_DW96_TH : 8>(x, B, H, W, bw, y, s);
     case 192: return launch_dwconv<T, XT, 192, CN_DW192_S, (sizeof(XT) == 2 && CN_DW_DOT2) ? CN_DW192_TH : 8>(x, B, H, W, bw, y, s);
     case 384:
@@ -1116,26 +1115,11 @@ static int encode_impl(conette_ctx* ctx, const float* wave, int B, int L, float*
     }
     for (int b = 0; b < CN_DEPTHS[st]; ++b, ++blk) {
       const CnBlockW& bw = ctx->blocks[blk];
-      const bool f8 = std::is_same<T, bf16_t>::value && std::is_same<XT, float>::value && ctx->fp8 && bw.mlp_f8 != nullptr && C <= 384;
       {
         CnProfScope ps(ctx, CONETTE_PROF_DWCONV_LN, s);
-        if constexpr (std::is_same<XT, float>::value) {
-          if (f8) CN_TRY((dwconv_dispatch<f8_t, XT>(C, xc, B, H, W, bw, (f8_t*)ws.y, s)));  // y as e4m3 (scale 1)
-          else CN_TRY((dwconv_dispatch<T, XT>(C, xc, B, H, W, bw, y, s)));
-        } else {
-          CN_TRY((dwconv_dispatch<T, XT>(C, xc, B, H, W, bw, y, s)));
-        }
+        CN_TRY((dwconv_dispatch<T, XT>(C, xc, B, H, W, bw, y, s)));
       }
       bool fused = false;
-      if constexpr (std::is_same<XT, float>::value) if (f8) {  // CONETTE_PREC_FP8: pw1 + GELU + pw2 + residual with e4m3 operands (mlp_f8.h)
-        CnProfScope ps(ctx, CONETTE_PROF_PW1_GEMM, s);
-        const unsigned char* y8 = (const unsigned char*)ws.y;
-        const int nb = ctx->n_cu - ctx->enc_reserved_cus;
-        if (C == 96) CN_TRY((cn_launch_mlp_f8_resident<96, 12>(y8, bw.mlp_f8, xc, (int)P, nb, s)));
-        else if (C == 192) CN_TRY((cn_launch_mlp_f8_ring<192, 8, 5>(y8, bw.mlp_f8, xc, (int)P, nb, s)));
-        else CN_TRY((cn_launch_mlp_f8_ring<384, 4, 4>(y8, bw.mlp_f8, xc, (int)P, nb, s)));
-        fused = true;
-      }
       if constexpr (std::is_same<T, sp16_t>::value) {
         // exact precision, stages 0-1: the same fused block with fp16 hi / lo operand pairs (mlp_sp.h); timed under PW1
         if (bw.mlp_sp != nullptr && C <= 192) {
@@ -1262,13 +1246,10 @@ extern "C" int conette_encode(conette_ctx* ctx, const float* wave, int32_t batch
     cn_set_error("encode: workspace %zu < %zu", workspace_bytes, need);
     return CN_ERR_WORKSPACE;
   }
-  // the residual stream's type: fp16 in the 16-bit precisions (round 5), fp32 in the others and in the fp8 precision, whose
-  // e4m3 kernels (mlp_f8.h) keep the fp32 stream they were written for
+  // the residual stream's type: fp16 in the 16-bit precisions (round 5), fp32 in the others
   switch (ctx->cfg.precision) {
     case CONETTE_PREC_BF16:
       return encode_impl<bf16_t, half_t>(ctx, wave, batch, n_samples, frame_embs, clip_probs, taps, (char*)workspace, (hipStream_t)stream);
-    case CONETTE_PREC_FP8:
-      return encode_impl<bf16_t, float>(ctx, wave, batch, n_samples, frame_embs, clip_probs, taps, (char*)workspace, (hipStream_t)stream);
     case CONETTE_PREC_F16:
       return encode_impl<half_t, half_t>(ctx, wave, batch, n_samples, frame_embs, clip_probs, taps, (char*)workspace, (hipStream_t)stream);
     case CONETTE_PREC_F16X2:

@@ -18,7 +18,8 @@ LIB_PATH = os.path.join(_HERE, "libconette_hip.so")
 PREC_F32 = 0
 PREC_BF16 = 1
 PREC_F16X2 = 2   # "exact": fp16 hi/lo operand pairs, three MFMAs per product (include/conette_hip.h)
-PREC_FP8 = 3     # bf16 mode with the stage 0-2 pointwise convolutions on fp8 (e4m3) MFMAs
+# (3 was the experimental fp8 precision of ABI 2: withdrawn in round 6 -- e4m3 operands cost the frame embeddings 4 % whatever
+#  the scaling, block-scaled MX included: profiles/r06_notes.md section 3)
 PREC_F16 = 4     # the bf16 mode's kernels with IEEE fp16 operands: 8x less operand rounding error at the same speed
 N_MELS = 224
 FEAT = 768
@@ -212,7 +213,7 @@ class Engine:
             raise RuntimeError("conette_amd.Engine needs a ROCm GPU (no CPU fallback)")
         self.lib = load_library()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        table = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "exact": PREC_F16X2, "f16x2": PREC_F16X2, "fp8": PREC_FP8,
+        table = {"fp32": PREC_F32, "f32": PREC_F32, "bf16": PREC_BF16, "exact": PREC_F16X2, "f16x2": PREC_F16X2,
                  "f16": PREC_F16, "fp16": PREC_F16}
         # "certified" (round 6): a 16-bit base precision for every clip + the device-side margins of its search (conette_decode's
         # `margins`); clips whose margins do not certify their ids are re-run through an exact context.  "certified" alone picks
@@ -231,9 +232,13 @@ class Engine:
         elif base == "bf16+f16dec":  # bf16 encoder (the throughput mode's) + fp16 decoder: the decoder's operands flip the most captions
             self.precision, self.precision_dec = PREC_BF16, PREC_F16
         else:
+            if base not in table:
+                raise ValueError(f"unknown precision {precision!r}" + (" (the experimental fp8 precision was withdrawn in round 6: "
+                                 "profiles/r06_notes.md section 3)" if base == "fp8" else f" (expected one of {sorted(table)}, mixed, mixed16, "
+                                 "bf16+f16dec, certified[:base])"))
             self.precision = self.precision_dec = table[base]
         self.precision_name = precision if (self.certified or base in ("mixed", "mixed16", "bf16+f16dec")) else {
-            PREC_BF16: "bf16", PREC_F32: "fp32", PREC_F16X2: "exact", PREC_FP8: "fp8", PREC_F16: "f16"}[self.precision]
+            PREC_BF16: "bf16", PREC_F32: "fp32", PREC_F16X2: "exact", PREC_F16: "f16"}[self.precision]
         self.eos_id, self.pad_id = int(eos_id), int(pad_id)
         vocab = int(state_dict["model.decoder.classifier.weight"].shape[0])
         self.vocab_size = vocab

@@ -2,7 +2,7 @@
 (reference src/conette/predict.py:27-232).
 
     python -m conette_amd.predict --audio a.wav b.wav --task clotho --model_name DIR_OR_HUB_NAME \
-        [--csv_export out.csv] [--precision bf16|bf16+f16dec|f16|fp8|mixed|mixed16|exact|fp32]
+        [--csv_export out.csv] [--precision certified|certified:BASE|bf16|bf16+f16dec|f16|mixed|mixed16|exact|fp32]
 
 ``--model_path`` (a Lightning training log directory with hydra/config.yaml + checkpoints/best.ckpt, predict.py:123-178) is
 accepted when the audio encoder's weights come with it: the reference builds its HF wrapper around the Lightning module and leaves
@@ -51,7 +51,7 @@ def get_predict_args(argv: Optional[List[str]] = None) -> Namespace:
     parser.add_argument("--verbose", type=int, help="Verbose level.", default=1)
     parser.add_argument("--precision", type=str, default=None,
                         help="certified (default: fp16 pipeline + id certificate, uncertified clips re-run exactly), certified:<base>, "
-                             "bf16, bf16+f16dec, f16, fp8, mixed, mixed16, exact, fp32")
+                             "bf16, bf16+f16dec, f16, mixed, mixed16, exact, fp32")
     return parser.parse_args(argv)
 
 

@@ -38,13 +38,11 @@ extern "C" {
                                 v_mfma_f32_16x16x32_f16 (hi.hi + hi.lo + lo.hi): fp32-MFMA accuracy at MFMA-f16 rate,
                                 exact-erf GELU; token ids equal the fp32 mode's / the reference's */
 
-#define CONETTE_PREC_FP8 3 /* EXPERIMENTAL, not a throughput mode and NOT the "fp8 MFMA pointwise GEMMs" half of BASELINE.json
-                              configs[4]: bf16 mode (fp32 residual stream) with the pointwise convolutions of ConvNeXt stages
-                              0-2 on the NON-scaled v_mfma_f32_32x32x16_fp8_fp8 (OCP e4m3 operands, per-tensor /
-                              per-output-channel scales).  That instruction has the bf16 form's cycle count, so the mode is
-                              slower than BF16 (which also moves fewer bytes since round 5) and lossy (~5 % of a block's update
-                              off the bf16 mode per block, ~1 in 5 captions kept).  Kept as the pinned starting point of a
-                              block-scaled (v_mfma_scale_f32_32x32x64_f8f6f4) port; see DESIGN.md section 9 */
+/* 3: the experimental fp8 precision of ABI 2 (pointwise convolutions of stages 0-2 on the non-scaled e4m3 MFMA) -- WITHDRAWN in
+ * ABI 3, conette_create refuses it.  BASELINE.json configs[4]'s "fp8 MFMA pointwise GEMMs" is not offered: the block-scaled
+ * v_mfma_scale_f32_16x16x128_f8f6f4 does sustain 4.0 PFLOP/s in register-fed loops (3.5x the bf16 16x16x32 loop's 1.13), but e4m3
+ * operands -- per-tensor scaled or MX block-scaled alike -- move the frame embeddings by 4 % (MX in stage 2 alone: 3.7 %; the
+ * bf16 mode: 0.44 %), an order of magnitude beyond what keeps captions: profiles/r06_notes.md section 3, oracle/mx_study.py */
 
 #define CONETTE_PREC_F16 4 /* the bf16 mode's kernels instantiated for IEEE fp16 operands (v_mfma_f32_*_f16: the same cycles,
                               the same bytes): 11 significant bits instead of 8, i.e. an eighth of the bf16 mode's operand

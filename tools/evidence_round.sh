@@ -1,6 +1,6 @@
 #!/bin/bash
 # The bench lines DESIGN.md quotes besides the default one ("keep the evidence you quote"):
-#   bash tools/evidence_round.sh TAG   -> gpurun_out/TAG_{default,f16,mixed16,mixed_precision,b256,b16,mixedlen,shard256,soak,exact,fp8}.json (one JSON line each)
+#   bash tools/evidence_round.sh TAG   -> gpurun_out/TAG_{default,f16,mixed16,mixed_precision,b256,b16,mixedlen,shard256,soak,exact,greedy,certified*}.json (one JSON line each)
 TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
@@ -26,7 +26,6 @@ _run mixedlen --workload mixed --steps 30 --cpu-clips 0 --parity-clips 0
 _run shard256 --global-batch 256 --steps 30 --cpu-clips 0 --parity-clips 0
 _run soak --steps 300 --repeat 5 --cpu-clips 0 --parity-clips 0
 _run exact --precision exact --steps 30 --cpu-clips 0 --parity-clips 0
-_run fp8 --precision fp8 --steps 50 --cpu-clips 0 --parity-clips 0
 # the id-certified pipeline (round 6): fp16 + margins, uncertified clips re-run exactly; default and peaked synthetic checkpoint, beam 3 and greedy
 cert() { name=$1; shift; if want $name; then timeout 600 python3 bench_certified.py "$@" 2> $OUT/${TAG}_${name}.err | tail -1 > $OUT/${TAG}_${name}.json; python3 -c "
 import json
