@@ -96,6 +96,38 @@ def test_every_block_against_bf16_operand_oracle(name, eng_bf16, synth_weights):
     print("max / mean |err| per block:", {k: (round(a, 5), round(b, 7)) for k, (a, b) in worst.items()})
 
 
+# |block output - unmodified fp32 oracle's block output| on the GPU's own block input, measured in round 6 (worst of the 18 blocks,
+# b3_mixed fixture): bf16 max 0.0091 / mean 8.5e-4, f16 max 0.0024 / mean 2.4e-4 (the fp16 residual stream's store: half an fp16
+# ulp of an O(1) value, is in both); the bounds leave a factor ~2.
+FP32_BOUND = {"bf16": (0.02, 1.7e-3), "f16": (0.005, 5.0e-4)}
+
+
+def test_every_block_against_the_unmodified_fp32_oracle(eng_bf16, synth_weights):
+    """the operand oracle (bf16_ref.py) is edited together with the kernels whenever a rounding point moves, so a
+    kernel-plus-oracle co-edit could hide a regression.  This assertion does not move with the kernels: every ConvNeXt block's
+    output against oracle/cpu_ref.py's plain fp32 block (convnext.py:61-74) on the GPU's own input of that block, with explicit
+    ABSOLUTE bounds on the worst element and on the mean (activations are O(1))."""
+    from oracle import bf16_ref as Bf
+    from oracle import cpu_ref as O
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    g = G.load("b3_mixed_beam3_none")
+    prec = eng_bf16.test_prec
+    fe, clip, taps = eng_bf16.encode(_wave(g).cuda(), taps="blocks")
+    torch.cuda.synchronize()
+    worst_max = worst_mean = 0.0
+    blk = 0
+    for st, depth in enumerate((3, 3, 9, 3)):
+        for b in range(depth):
+            src = taps["stem"] if blk == 0 else (taps[f"down{st}"] if b == 0 else taps[f"block{blk - 1}"])
+            with torch.no_grad():
+                ref = O.convnext_block(synth_weights, Bf.block_prefix(blk), _nchw(src))
+            err = (_nchw(taps[f"block{blk}"]) - ref).abs()
+            worst_max, worst_mean = max(worst_max, float(err.max())), max(worst_mean, float(err.mean()))
+            assert float(err.max()) < FP32_BOUND[prec][0] and float(err.mean()) < FP32_BOUND[prec][1], (prec, blk, float(err.max()), float(err.mean()))
+            blk += 1
+    print(f"{prec}: worst block against the fp32 oracle: max {worst_max:.5f} mean {worst_mean:.6f}")
+
+
 @pytest.mark.parametrize("copies", [32, 8, 5, 13])
 def test_encoder_at_256_clips(copies, eng_bf16):
     """BASELINE config 3's encoder half: 32 copies of the b8_10s fixture batch (B = 256) -- every copy must reproduce
