@@ -72,7 +72,7 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: CPU self-test of the launcher / sharding / gather path (no GPU work, no timing)")
     ap.add_argument("--master-port", type=int, default=0)
-    ap.add_argument("--also", default="bf16:e2,bf16:g1,bf16+f16dec,f16,mixed16,exact,certified,certified@peaked",
+    ap.add_argument("--also", default="bf16:e2,bf16:g1,bf16+f16dec,f16,mixed16,exact,certified,certified@peaked,certified-best@peaked",
                     help="N = 1, fixed workload, bf16 only: after the run, the SAME pipelined benchmark at these precisions (one child "
                          "process each, 3 windows, no CPU / parity legs), reported under `also_pipelined` ('' = skip); `PREC:g1` = that "
                          "precision with one beam search per batch (CN_DEC_GROUP=1) instead of the grouped decode")
@@ -321,14 +321,14 @@ def also_pipelined(args, batch):
     import subprocess
     out = {}
     for name in [n for n in args.also.split(",") if n]:
-        if name.startswith("certified"):       # "certified[:base][@peaked]": the id-certified pipeline (bench_certified.py, round 6)
+        if name.startswith("certified"):       # "certified[-best][:base][@peaked]": the id-certified pipeline (bench_certified.py, round 6)
             spec, _, ckpt = name.partition("@")
             cmd = [sys.executable, os.path.join(ROOT, "bench_certified.py"), "--base", spec.partition(":")[2] or "f16", "--checkpoint",
-                   ckpt or "default", "--steps", str(max(4, args.steps // 4 * 4)), "--repeat", "3", "--batch", str(batch), "--beam", str(args.beam)]
+                   ckpt or "default", "--policy", "best" if spec.startswith("certified-best") else "strict", "--steps", str(max(4, args.steps // 4 * 4)), "--repeat", "3", "--batch", str(batch), "--beam", str(args.beam)]
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
                 d = json.loads(r.stdout.strip().splitlines()[-1])
-                out[name] = {k: d[k] for k in ("value", "ms_per_step", "precision", "checkpoint", "recompute_fraction",
+                out[name] = {k: d[k] for k in ("value", "ms_per_step", "precision", "policy", "checkpoint", "recompute_fraction",
                                                "rerun_fraction_with_padding", "tolerance", "pipeline_consistent", "pipeline_steps_checked",
                                                "ids_identical_to_exact")}
                 out[name]["clips_per_sec"] = out[name].pop("value")

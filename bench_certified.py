@@ -40,6 +40,9 @@ def main(argv=None) -> None:
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--beam", type=int, default=3)
     ap.add_argument("--group", type=int, default=4)
+    ap.add_argument("--policy", default="strict", choices=["strict", "best"],
+                    help="strict: ids, candidates and their slot order certified; best: the returned caption and the SET of beam hypotheses "
+                         "(precision 'certified-best': the pick-order margins are not held to the tolerance)")
     args = ap.parse_args(argv)
 
     import numpy as np
@@ -55,7 +58,7 @@ def main(argv=None) -> None:
         raise SystemExit(f"--steps {args.steps} must be a multiple of the decode group {G}")
     NB = 4
     sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.synth_state_dict(recipe=args.checkpoint).items()}
-    eng = Engine(sd, precision=f"certified:{args.base}", device=dev)
+    eng = Engine(sd, precision=("certified" if args.policy == "strict" else "certified-best") + f":{args.base}", device=dev)
     eng.set_encode_reserved_cus(24)
     forbid = sd["model.forbid_rep_mask"].to(dev)
     L = CLIP_S * SR
@@ -185,7 +188,7 @@ def main(argv=None) -> None:
     rot = steps_all % NB
     kp_s, kl_s, kf_s = kp.reshape(n_groups * G, B, max_pred), kl.reshape(n_groups * G, B), kf.reshape(n_groups * G, B)
     same_solo = bool(torch.equal(kp_s, solo_p[rot]) and torch.equal(kl_s, solo_l[rot]) and torch.equal(kf_s, solo_f[rot]))
-    same_exact_clips = int((kp_s == ex_p[rot]).all(dim=2).sum())
+    same_exact_clips = int((kp_s == ex_p[rot]).all(dim=2).sum())      # (best_preds: certified under both policies)
     torch.cuda.synchronize(dev)
 
     order = sorted(range(n_rep), key=lambda k: win_dt[k])
@@ -194,7 +197,7 @@ def main(argv=None) -> None:
         "metric": "clips_per_sec", "value": round(B * args.steps / dt, 2), "unit": "clips/s", "n_gpus": 1, "steps": args.steps,
         "warmup": warm, "repeat": n_rep, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "windows": {"clips_per_sec": [round(B * args.steps / w, 2) for w in win_dt]},
-        "precision": f"certified:{args.base}", "dtype": f"{args.base} + f16x2 re-run of uncertified clips", "checkpoint": args.checkpoint,
+        "precision": eng.precision_name, "policy": args.policy, "dtype": f"{args.base} + f16x2 re-run of uncertified clips", "checkpoint": args.checkpoint,
         "recompute_fraction": round(recompute_fraction, 4), "rerun_fraction_with_padding": round(rerun_fraction, 4),
         "tolerance": {"a_b_c": list(CERT_TOL[args.base]["greedy" if beam == 1 else "beam"]),
                       "source": "profiles/r06_margin_calibration.txt"},

@@ -56,7 +56,7 @@ __global__ void cn_init_state_kernel(int B, int beam, int maxp, const int* __res
   if (trace_val)
     for (int i = gid; i < maxp * R; i += gsz) trace_val[i] = 0.f;
   if (margins)  // a step a clip does not take (it has finished) decides nothing: +inf
-    for (int i = gid; i < B * (maxp + 1); i += gsz) margins[i] = INFINITY;
+    for (int i = gid; i < B * 2 * (maxp + 1); i += gsz) margins[i] = INFINITY;
 }
 
 // x = E[tok] * sqrt(d) + PE[step]   (aac_tfmer.py:100-106); d == 256, one wave per row
@@ -291,10 +291,15 @@ __device__ __forceinline__ ValIdx vi_wave(ValIdx x) {
 // between the last pick and the first rejected candidate, and the gaps between consecutive picks (their order decides which
 // hypothesis lands in which slot: beam.py:165-169).  A 16-bit search whose every call (and whose final best-beam choice) has a
 // margin above twice the precision's worst candidate error has taken the decisions an exact search takes.
-__device__ __forceinline__ float cn_step_margin(const float* selv, int k, float runner_up) {
-  float m = selv[k - 1] - runner_up;
+// Two planes per clip, (B, 2, max_pred + 1): plane 0 = MEMBERSHIP, the gap that decides WHICH candidates continue (and, in its last
+// column, which hypothesis is returned as the best); plane 1 = ORDER, the smallest gap between consecutive picks, which only decides
+// which slot a hypothesis lands in -- the order of mult_preds, never best_preds.
+__device__ __forceinline__ void cn_step_margin(float* margins, int b, int maxp, int step, const float* selv, int k, float runner_up) {
+  float* row = margins + (size_t)b * 2 * (maxp + 1);
+  row[step] = selv[k - 1] - runner_up;   // NaN (-inf - -inf: fewer finite candidates than picks) reads as "not certified" on the host
+  float m = INFINITY;
   for (int c = 0; c + 1 < k; ++c) m = fminf(m, selv[c] - selv[c + 1]);
-  return m;   // NaN (-inf - -inf: fewer finite candidates than picks) reads as "not certified" on the host
+  row[(maxp + 1) + step] = m;
 }
 
 __global__ __launch_bounds__(256) void cn_search_step_kernel(float* __restrict__ logits, int ldv, int V, int beam,
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(256) void cn_search_step_kernel(float* __restrict__
     }
     n_active[b] = cnt;
     if (cnt > 0) atomicAdd(&live[step + 1], cnt);  // rows that search on: gates the next step's kernels
-    if (margins) margins[(size_t)b * (maxp + 1) + step] = cn_step_margin(s_selv, k, s_selv[k]);
+    if (margins) cn_step_margin(margins, b, maxp, step, s_selv, k, s_selv[k]);
   }
   __syncthreads();
   for (int c = 0; c < k; ++c) {
@@ -650,7 +655,7 @@ __global__ __launch_bounds__(S3_T) void cn_search_step3_kernel(const float* __re
       ru = s_ru[0];
 #pragma unroll
       for (int w = 1; w < 16; ++w) ru = fmaxf(ru, s_ru[w]);
-      margins[(size_t)b * (maxp + 1) + step] = cn_step_margin(s_selv, k, ru);
+      cn_step_margin(margins, b, maxp, step, s_selv, k, ru);
     }
   }
   // bookkeeping (beam.py:164-203)
@@ -721,7 +726,7 @@ __global__ void cn_finalize_kernel(int B, int beam, int maxp, int eos_id, const 
     float second = -INFINITY;
     for (int s = 0; s < beam; ++s)
       if (s != best) second = fmaxf(second, out_avg[b * beam + s]);
-    margins[(size_t)b * (maxp + 1) + maxp] = bv - second;
+    margins[(size_t)b * 2 * (maxp + 1) + maxp] = bv - second;
   }
   int e = -1;
   for (int j = 0; j < maxp; ++j) {

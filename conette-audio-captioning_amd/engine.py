@@ -217,8 +217,13 @@ class Engine:
                  "f16": PREC_F16, "fp16": PREC_F16}
         # "certified" (round 6): a 16-bit base precision for every clip + the device-side margins of its search (conette_decode's
         # `margins`); clips whose margins do not certify their ids are re-run through an exact context.  "certified" alone picks
-        # CERT_DEFAULT_BASE; "certified:<base>" names it.
-        self.certified = precision == "certified" or precision.startswith("certified:")
+        # CERT_DEFAULT_BASE; "certified:<base>" names it; "certified-best[:<base>]" relaxes the slot order (below).
+        head = precision.split(":", 1)[0]
+        self.certified = head in ("certified", "certified-best")
+        # "certified": ids, candidates AND their slot order (mult_preds) are the exact search's; "certified-best": the returned
+        # caption (best_preds / best_lprobs) and the SET of beam hypotheses are -- the pick-order margins are not held to the
+        # tolerance, so two hypotheses of near-equal score may swap slots; far fewer clips need the exact re-run under beam search
+        self.cert_order = head != "certified-best"
         base = precision
         if self.certified:
             base = precision.split(":", 1)[1] if ":" in precision else CERT_DEFAULT_BASE
@@ -387,7 +392,7 @@ class Engine:
                 "step0": e((b * beam, ldv), torch.float32) if s0 else None,
                 "trace_sel": e((max_pred, b, beam, 2), torch.int32) if trace else None,
                 "trace_val": e((max_pred, b, beam), torch.float32) if trace else None,
-                "margins": e((b, max_pred + 1), torch.float32) if margins else None,
+                "margins": e((b, 2, max_pred + 1), torch.float32) if margins else None,
             }
             if len(self._dec_bufs) >= MAX_DECODE_GRAPHS:
                 # the evicted buffers may still be written by a decode running on another stream: drain before they are freed
@@ -403,7 +408,8 @@ class Engine:
         """Beam search over pre-computed frame embeddings.  Outputs are full width; trim with
         ``sizes`` = [pred_size, best_maxlen].  ``clone=False`` returns the persistent buffers of
         pipeline ``slot`` (two slots let the decode of batch i overlap the encode of batch i+1).
-        ``want_margins``: also ``margins`` (B, max_pred + 1), the per-decision margins of the search (include/conette_hip.h).
+        ``want_margins``: also ``margins`` (B, 2, max_pred + 1), the per-decision margins of the search -- plane 0 membership (+ the
+        final choice in its last column), plane 1 pick order (include/conette_hip.h).
         ``exact`` (certified engines only): run on the exact context."""
         ctx = self._ctx_dec
         if exact:
@@ -444,16 +450,22 @@ class Engine:
 
     # ---- the id certificate (round 6) ------------------------------------------------------------------------------------
     def uncertified(self, margins: torch.Tensor, best_lprobs: torch.Tensor, tol: Optional[Tuple[float, float, float]] = None,
-                    beam: int = 2) -> torch.Tensor:
+                    beam: int = 2, order: Optional[bool] = None) -> torch.Tensor:
         """(B,) bool, True = the 16-bit search of this clip is NOT certified to have taken an exact search's decisions:
-        some top-k call of step i has an effective margin below ``a + b * (i + 1)``, or the final best-beam choice one below
-        ``c``, or a score / margin is not finite (an fp16 residual-stream overflow ends here as NaN).  ``tol`` = (a, b, c),
-        default ``CERT_TOL[base precision]["greedy" if beam == 1 else "beam"]`` -- measured: tools/calibrate_margins.py,
+        some top-k call of step i has a margin below ``a + b * (i + 1)``, or the final best-beam choice one below ``c``, or a
+        score / margin is not finite (an fp16 residual-stream overflow ends here as NaN).  ``margins`` (B, 2, max_pred + 1) as
+        conette_decode writes them; ``order`` (default: the engine's policy -- True for "certified", False for
+        "certified-best") also holds the pick-ORDER plane to the tolerance: with it the slot tables (mult_preds / mult_lprobs,
+        in order) are certified, without it best_preds / best_lprobs and mult_preds as a SET of hypotheses.  ``tol`` = (a, b,
+        c), default ``CERT_TOL[base precision]["greedy" if beam == 1 else "beam"]`` -- measured: tools/calibrate_margins.py,
         profiles/r06_margin_calibration.txt."""
         a, b, c = CERT_TOL[self.base_precision]["greedy" if int(beam) == 1 else "beam"] if tol is None else tol
-        max_pred = margins.shape[1] - 1
+        order = self.cert_order if order is None else order
+        max_pred = margins.shape[2] - 1
         need = a + b * torch.arange(1, max_pred + 1, device=margins.device, dtype=torch.float32)
-        ok = (margins[:, :max_pred] >= need).all(dim=1) & (margins[:, max_pred] >= c) & torch.isfinite(best_lprobs)
+        ok = (margins[:, 0, :max_pred] >= need).all(dim=1) & (margins[:, 0, max_pred] >= c) & torch.isfinite(best_lprobs)
+        if order:
+            ok = ok & (margins[:, 1, :max_pred] >= need).all(dim=1)
         return ~ok
 
     def caption_sizes(self, best_preds: torch.Tensor, mult_preds: torch.Tensor) -> torch.Tensor:

@@ -138,14 +138,17 @@ int conette_encode_nonfinite(conette_ctx* ctx, void* stream, int32_t* count);
  *   trace_sel   : optional dev (max_pred, B, beam, 2) int32 = (parent row, token) picked by the
  *                 per-clip top-k of each step in descending order, -1 where unused; or NULL
  *   trace_val   : optional dev (max_pred, B, beam) fp32 running log-prob sums of those picks
- *   margins     : optional dev (B, max_pred + 1) fp32, or NULL -- how far each decision of the search is from any other outcome:
- *                 [b][i], i < max_pred = the effective margin of clip b's top-k call of step i (_select_k_next_toks,
- *                 beam.py:230-269): min(gap between the last pick and the first rejected candidate, gaps between consecutive
- *                 picks -- their order assigns the slots, beam.py:165-169), +inf for steps the clip no longer takes;
- *                 [b][max_pred] = best averaged log-prob minus the second best (the final choice, beam.py:214-217), +inf for
- *                 beam 1.  A search whose margins all exceed twice the precision's candidate error took the decisions an exact
- *                 search takes: the certificate behind the host's precision "certified" (conette_amd/engine.py), which re-runs
- *                 only the other clips through a CONETTE_PREC_F16X2 context.  NaN = fewer finite candidates than picks.
+ *   margins     : optional dev (B, 2, max_pred + 1) fp32, or NULL -- how far each decision of the search is from any other
+ *                 outcome.  Plane [b][0] = MEMBERSHIP: [i], i < max_pred = last pick minus first rejected candidate of clip b's
+ *                 top-k call of step i (_select_k_next_toks, beam.py:230-269) -- which candidates continue; [max_pred] = best
+ *                 averaged log-prob minus the second best (the final choice, beam.py:214-217), +inf for beam 1.  Plane [b][1] =
+ *                 ORDER: [i] = the smallest gap between consecutive picks of that call (their order assigns the slots,
+ *                 beam.py:165-169: the order of mult_preds, never best_preds), +inf with one pick; [max_pred] unused (+inf).
+ *                 +inf for steps the clip no longer takes; NaN = fewer finite candidates than picks.  A search whose margins
+ *                 all exceed twice the precision's candidate error took the decisions an exact search takes: the certificate
+ *                 behind the host's precision "certified" (conette_amd/engine.py), which re-runs only the other clips through a
+ *                 CONETTE_PREC_F16X2 context; with plane 0 alone ("certified-best") best_preds / best_lprobs are certified and
+ *                 mult_preds as a set of hypotheses.
  * beam <= 16 (1..8 on the register-resident step kernel, 9..16 -- BaselinePLM's default is 10, pl_modules/baseline.py:47 -- on
  * the generic one), max_pred <= 64.  With identical arguments (pointers included) the launch sequence is replayed from a cached
  * hipGraph from the third call on (see conette_set_option). */

@@ -63,6 +63,7 @@ def main():
             eng = E.Engine(sd, precision=f"certified:{base}", device=dev)
             for beam in (1, 3):
                 a, b, c = E.CERT_TOL[base]["greedy" if beam == 1 else "beam"]
+                rel = {"flagged": 0, "wrong": 0, "missed": 0}
                 unprot = []      # (step, base margin) at the first diverging call
                 unprot_final = []
                 val_err = np.zeros(max_pred)
@@ -80,15 +81,22 @@ def main():
                     fx, _ = eng.encode(w, exact=True)
                     x = eng.decode(fx, flens, bos, forbid, beam, min_pred, max_pred, want_trace=True, exact=True)
                     d = first_divergence(r["trace_sel"], x["trace_sel"])        # (nb,)
-                    m = r["margins"]
+                    m2 = r["margins"]                                          # (nb, 2, max_pred + 1)
+                    m = torch.minimum(m2[:, 0], m2[:, 1])                       # the strict certificate's margin per step
                     same_final = (r["best_preds"] == x["best_preds"]).all(dim=1)
-                    flag = eng.uncertified(m, r["best_lprobs"], beam=beam)
+                    flag = eng.uncertified(m2, r["best_lprobs"], beam=beam, order=True)
+                    # the relaxed policy ("certified-best"): membership plane only; wrong = another best caption, or another SET of hypotheses
+                    flag_b = eng.uncertified(m2, r["best_lprobs"], beam=beam, order=False)
+                    srt = lambda t: torch.sort(t.to(torch.int64).mul(torch.tensor([7919 ** j % 1000003 for j in range(t.shape[-1])], device=t.device)).sum(-1), dim=1).values
+                    same_set = (srt(r["mult_preds"]) == srt(x["mult_preds"])).all(dim=1)
+                    wrong_b = ~(same_final & same_set)
+                    rel["flagged"] += int(flag_b.sum()); rel["wrong"] += int(wrong_b.sum()); rel["missed"] += int((wrong_b & ~flag_b).sum())
                     for i in range(nb):
                         di = int(d[i])
                         if di < max_pred:
                             unprot.append((di, float(m[i, di])))
                         elif not bool(same_final[i]):
-                            unprot_final.append(float(m[i, max_pred]))
+                            unprot_final.append(float(m2[i, 0, max_pred]))
                         wrong = di < max_pred or not bool(same_final[i])
                         diverged += wrong
                         flagged += bool(flag[i])
@@ -108,6 +116,8 @@ def main():
                 say("    largest unprotecting margin by step :", " ".join(f"{v:.4f}" for v in um))
                 say(f"    tolerance a + b (i + 1), final c      : a = {a}, b = {b}, c = {c}")
                 say("    max |candidate value error| by step :", " ".join(f"{v:.4f}" for v in val_err))
+                say(f"    relaxed policy (membership plane only: best caption + set of hypotheses): flagged {rel['flagged']}/{n} "
+                    f"({rel['flagged'] / n:.3f}), clips with another best caption or hypothesis set {rel['wrong']}, MISSED {rel['missed']}")
                 if unprot_final:
                     say(f"    final best-beam choice: largest unprotecting margin {max(unprot_final):.5f} (tolerance {c})")
             del eng
