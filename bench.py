@@ -72,7 +72,7 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: CPU self-test of the launcher / sharding / gather path (no GPU work, no timing)")
     ap.add_argument("--master-port", type=int, default=0)
-    ap.add_argument("--also", default="bf16:e2,bf16:g1,bf16+f16dec,f16,mixed16,exact,certified,certified@peaked,certified-best@peaked",
+    ap.add_argument("--also", default="bf16:e2,bf16:g1,bf16+f16dec,f16,mixed16,exact,certified,certified@peaked,certified-best@peaked,certified:f16@peaked",
                     help="N = 1, fixed workload, bf16 only: after the run, the SAME pipelined benchmark at these precisions (one child "
                          "process each, 3 windows, no CPU / parity legs), reported under `also_pipelined` ('' = skip); `PREC:g1` = that "
                          "precision with one beam search per batch (CN_DEC_GROUP=1) instead of the grouped decode")
@@ -323,7 +323,7 @@ def also_pipelined(args, batch):
     for name in [n for n in args.also.split(",") if n]:
         if name.startswith("certified"):       # "certified[-best][:base][@peaked]": the id-certified pipeline (bench_certified.py, round 6)
             spec, _, ckpt = name.partition("@")
-            cmd = [sys.executable, os.path.join(ROOT, "bench_certified.py"), "--base", spec.partition(":")[2] or "f16", "--checkpoint",
+            cmd = [sys.executable, os.path.join(ROOT, "bench_certified.py"), "--base", spec.partition(":")[2] or "mixed16", "--checkpoint",
                    ckpt or "default", "--policy", "best" if spec.startswith("certified-best") else "strict", "--steps", str(max(4, args.steps // 4 * 4)), "--repeat", "3", "--batch", str(batch), "--beam", str(args.beam)]
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)

@@ -15,7 +15,7 @@ The timed windows end with a full drain, so every step's re-run lies inside its 
 ids and scores are compared with the un-pipelined `Engine.generate_certified` of its batch (bit for bit) and its ids with the
 exact precision's.
 
-    python bench_certified.py [--base f16] [--checkpoint default|peaked] [--steps 100] [--repeat 3] [--beam 3]
+    python bench_certified.py [--base mixed16|f16|bf16] [--checkpoint default|peaked] [--steps 100] [--repeat 3] [--beam 3]
 """
 from __future__ import annotations
 
@@ -32,7 +32,7 @@ SR, CLIP_S = 32000, 10
 
 def main(argv=None) -> None:
     ap = argparse.ArgumentParser()
-    ap.add_argument("--base", default="f16")
+    ap.add_argument("--base", default="mixed16", help="base precision: mixed16 (fp16 encoder + exact decoder; engine.CERT_DEFAULT_BASE), f16, bf16, bf16+f16dec")
     ap.add_argument("--checkpoint", default="default", choices=["default", "peaked"])
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)

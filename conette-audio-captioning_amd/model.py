@@ -27,9 +27,10 @@ from .tokenizer import AACTokenizer, ENGLISH_STOPWORDS, unpickle_extra_state
 pylog = logging.getLogger(__name__)
 
 FORBID_MODES = ("none", "all", "content_words")
-# What `CoNeTTEModel.from_pretrained(dir)(x)` runs when the caller names no precision (round 6): the fp16 pipeline with the
-# device-side id certificate -- clips whose search margins do not certify their token ids are re-run through the exact context,
-# so the ids are the reference's (fp32) ids.  "bf16" is the benchmark's throughput mode (BASELINE configs[1-3]).
+# What `CoNeTTEModel.from_pretrained(dir)(x)` runs when the caller names no precision (round 6): a 16-bit base pipeline (fp16
+# encoder + exact decoder: engine.CERT_DEFAULT_BASE) with the device-side id certificate -- clips whose search margins do not
+# certify their token ids are re-run through the exact context from the waveform, so the ids are the reference's (fp32) ids.
+# "bf16" is the benchmark's throughput mode (BASELINE configs[1-3]).
 DEFAULT_PRECISION = "certified"
 
 

@@ -1,6 +1,6 @@
 """GPU: precision "certified" (round 6) -- the ids of the reference at 16-bit speed, asserted as IDENTITY.
 
-The certified precision runs the base 16-bit pipeline (default fp16) for every clip, reads the device-side margins of its search
+The certified precision runs the base 16-bit pipeline (default: fp16 encoder + exact decoder; also plain f16 and bf16) for every clip, reads the device-side margins of its search
 (conette_decode's ``margins``: how far every top-k call and the final best-beam choice are from any other outcome) and re-runs the
 clips whose margins do not certify their ids through the exact context (fp16 hi / lo operand pairs, fp32 residual stream), from the
 waveform.  The bar of the exact precision applies unchanged: token ids, candidates and their order identical to the reference's
@@ -24,7 +24,7 @@ TAGS = {i: f"tag{i}" for i in range(527)}
 LP_TOL = {"certified": 0.05, "certified-best": 0.05, "certified:f16": 0.05, "certified:mixed16": 0.03, "certified:bf16": 0.3}
 PK_DIR = os.path.join(G.GOLDEN, "peaked")
 PK = sorted(f[:-4] for f in os.listdir(PK_DIR) if f.endswith(".npz"))
-PRECS = ["certified", "certified:bf16", "certified:mixed16"]
+PRECS = ["certified", "certified:bf16", "certified:f16"]
 
 
 def _model(prec, recipe="default"):
@@ -50,7 +50,7 @@ def models():
 def test_default_precision_is_certified():
     from conette_amd import engine
     from conette_amd.model import DEFAULT_PRECISION
-    assert DEFAULT_PRECISION == "certified" and engine.CERT_DEFAULT_BASE == "f16"
+    assert DEFAULT_PRECISION == "certified" and engine.CERT_DEFAULT_BASE == "mixed16"
 
 
 def _check_ids(out, g, prec, what):

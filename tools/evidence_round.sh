@@ -35,6 +35,6 @@ cert certified
 cert certified_peaked --checkpoint peaked
 cert certified_greedy --beam 1
 cert certified_peaked_greedy --checkpoint peaked --beam 1
-cert certified_mixed16_peaked --base mixed16 --checkpoint peaked
+cert certified_f16_peaked --base f16 --checkpoint peaked
 cert certified_best --policy best
 cert certified_best_peaked --policy best --checkpoint peaked
