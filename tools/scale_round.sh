@@ -15,9 +15,12 @@ line() { name=$1; shift; timeout 1200 python3 bench.py "$@" --cpu-clips 0 --pari
 for n in 1 2 4 8; do
   if [ $n -le $NGPU ]; then line n$n --gpus $n --steps 100 --warmup 5; fi
 done
+# (CN_BENCH_ROTATE=1: one input batch instead of four rotating ones -- 2048 synthetic clips take minutes to generate on the host; both lines alike)
+export CN_BENCH_ROTATE=1
 if [ 8 -le $NGPU ]; then line g2048_n8 --gpus 8 --global-batch 2048 --steps 8 --warmup 2; fi
 # the same 2048 clips on ONE GPU: the reference hash of the sharded job (captions_sha256 = the trimmed ids of the last step, clip order)
 line g2048_n1 --gpus 1 --global-batch 2048 --steps 8 --warmup 2
+unset CN_BENCH_ROTATE
 python3 - <<PY
 import glob, json, os
 rows = {}
