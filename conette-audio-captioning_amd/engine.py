@@ -53,9 +53,9 @@ CERT_TOL = {
     "bf16+f16dec": {"greedy": (0.20, 0.0, 0.0), "beam": (0.37, 0.0, 0.026)},
     "bf16": {"greedy": (0.39, 0.0, 0.0), "beam": (0.58, 0.0, 0.04)},
 }
-# The default base: fp16 encoder + EXACT decoder.  Measured against the f16 base in one call (profiles/r06_b_certified_*.json): the exact
-# decoder costs every step 0.35 ms, its tighter tolerance spares more exact-ENCODER re-runs than that -- greedy 10.6 k against 9.8 k
-# clips/s on the peaked checkpoint (4 % against 8 % of the clips re-run), 7.8 k against 6.8 k on the default one; beam 3 5.1 k against 4.6 k.
+# The default base: fp16 encoder + EXACT decoder.  Measured against the f16 base in one call (profiles/r06_c_certified_*.json): the exact
+# decoder costs every step 0.35 ms, its tighter tolerance spares more exact-ENCODER re-runs than that -- greedy 9.6 k against 8.8 k
+# clips/s on the peaked checkpoint (8 % against 16 % of the clips re-run), 6.1 k against 5.1 k on the default one; beam 3 4.8 k against 4.1 k.
 CERT_DEFAULT_BASE = "mixed16"
 OPT_DECODE_GRAPH = 1
 OPT_DECODE_FUSION = 2
