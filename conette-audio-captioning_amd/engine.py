@@ -210,6 +210,37 @@ def make_masked_stream(device: torch.device, n_share: int, n_cus: int = 256, off
         return torch.cuda.ExternalStream(h.value, device=device)
 
 
+def uncertified_mask(margins: torch.Tensor, best_lprobs: torch.Tensor, tol: Tuple[float, float, float], order: bool = True) -> torch.Tensor:
+    """(B,) bool, True = the 16-bit search of this clip is NOT certified to have taken an exact search's decisions: some top-k call of
+    step i has a margin below ``a + b * (i + 1)``, or the final best-beam choice one below ``c``, or a score / margin is not finite
+    (NaN: fewer finite candidates than picks, or an fp16 residual-stream overflow).  ``margins`` (B, 2, max_pred + 1) as conette_decode
+    writes them (include/conette_hip.h): plane 0 membership (+ the final choice in its last column), plane 1 pick order; ``order`` also
+    holds the ORDER plane to the tolerance: with it the slot tables (mult_preds / mult_lprobs, in order) are certified, without it
+    best_preds / best_lprobs and mult_preds as a SET of hypotheses.  ``tol`` = (a, b, c).  Pure tensor logic (CPU-testable)."""
+    a, b, c = tol
+    max_pred = margins.shape[2] - 1
+    need = a + b * torch.arange(1, max_pred + 1, device=margins.device, dtype=torch.float32)
+    ok = (margins[:, 0, :max_pred] >= need).all(dim=1) & (margins[:, 0, max_pred] >= c) & torch.isfinite(best_lprobs)
+    if order:
+        ok = ok & (margins[:, 1, :max_pred] >= need).all(dim=1)
+    return ~ok
+
+
+def caption_sizes(best_preds: torch.Tensor, mult_preds: torch.Tensor, eos_id: int) -> torch.Tensor:
+    """[pred_size, best_maxlen] (beam.py:192-194,207-211,222-225) recomputed from full-width ids -- after rows of two searches have
+    been merged.  A hypothesis ends at its first <eos>, or at max_pred when it never emitted one.  Pure tensor logic (CPU-testable)."""
+    max_pred = mult_preds.shape[-1]
+    pos = torch.arange(max_pred, device=mult_preds.device)
+
+    def first_eos(x):   # index of the first <eos>, max_pred where absent
+        return torch.where(x == eos_id, pos, max_pred).amin(dim=-1)
+
+    ps = torch.clamp(first_eos(mult_preds) + 1, max=max_pred).amax()
+    e = first_eos(best_preds)
+    ml = torch.minimum(torch.where(e < ps, e, ps).amax() + 1, ps)
+    return torch.stack([ps, ml]).to(torch.int32)
+
+
 class Engine:
     """Opaque context (packed weights) + caller-owned workspaces for one device."""
 
@@ -458,36 +489,14 @@ class Engine:
     # ---- the id certificate (round 6) ------------------------------------------------------------------------------------
     def uncertified(self, margins: torch.Tensor, best_lprobs: torch.Tensor, tol: Optional[Tuple[float, float, float]] = None,
                     beam: int = 2, order: Optional[bool] = None) -> torch.Tensor:
-        """(B,) bool, True = the 16-bit search of this clip is NOT certified to have taken an exact search's decisions:
-        some top-k call of step i has a margin below ``a + b * (i + 1)``, or the final best-beam choice one below ``c``, or a
-        score / margin is not finite (an fp16 residual-stream overflow ends here as NaN).  ``margins`` (B, 2, max_pred + 1) as
-        conette_decode writes them; ``order`` (default: the engine's policy -- True for "certified", False for
-        "certified-best") also holds the pick-ORDER plane to the tolerance: with it the slot tables (mult_preds / mult_lprobs,
-        in order) are certified, without it best_preds / best_lprobs and mult_preds as a SET of hypotheses.  ``tol`` = (a, b,
-        c), default ``CERT_TOL[base precision]["greedy" if beam == 1 else "beam"]`` -- measured: tools/calibrate_margins.py,
-        profiles/r06_margin_calibration.txt."""
-        a, b, c = CERT_TOL[self.base_precision]["greedy" if int(beam) == 1 else "beam"] if tol is None else tol
-        order = self.cert_order if order is None else order
-        max_pred = margins.shape[2] - 1
-        need = a + b * torch.arange(1, max_pred + 1, device=margins.device, dtype=torch.float32)
-        ok = (margins[:, 0, :max_pred] >= need).all(dim=1) & (margins[:, 0, max_pred] >= c) & torch.isfinite(best_lprobs)
-        if order:
-            ok = ok & (margins[:, 1, :max_pred] >= need).all(dim=1)
-        return ~ok
+        """``uncertified_mask`` with the engine's defaults: ``tol`` = ``CERT_TOL[base precision]["greedy" if beam == 1 else
+        "beam"]`` (measured: tools/calibrate_margins.py, profiles/r06_margin_calibration*.txt), ``order`` = the engine's policy
+        (True for "certified", False for "certified-best")."""
+        tol = CERT_TOL[self.base_precision]["greedy" if int(beam) == 1 else "beam"] if tol is None else tol
+        return uncertified_mask(margins, best_lprobs, tol, self.cert_order if order is None else order)
 
     def caption_sizes(self, best_preds: torch.Tensor, mult_preds: torch.Tensor) -> torch.Tensor:
-        """[pred_size, best_maxlen] (beam.py:192-194,207-211,222-225) recomputed from full-width ids -- after rows of two
-        searches have been merged.  A hypothesis ends at its first <eos>, or at max_pred when it never emitted one."""
-        max_pred = mult_preds.shape[-1]
-        pos = torch.arange(max_pred, device=mult_preds.device)
-
-        def first_eos(x):   # index of the first <eos>, max_pred where absent
-            return torch.where(x == self.eos_id, pos, max_pred).amin(dim=-1)
-
-        ps = torch.clamp(first_eos(mult_preds) + 1, max=max_pred).amax()
-        e = first_eos(best_preds)
-        ml = torch.minimum(torch.where(e < ps, e, ps).amax() + 1, ps)
-        return torch.stack([ps, ml]).to(torch.int32)
+        return caption_sizes(best_preds, mult_preds, self.eos_id)
 
     def generate_certified(self, wave: Optional[torch.Tensor], frame_embs: torch.Tensor, frame_lens: torch.Tensor,
                            bos_ids: torch.Tensor, forbid_mask: Optional[torch.Tensor], beam: int, min_pred: int,

@@ -162,3 +162,53 @@ def test_unsupported_architecture_config_is_refused():
         with pytest.raises((ValueError, RuntimeError)) as e:
             CoNeTTEModel(CoNeTTEConfig(**kw), state_dict={})
         assert "Unsupported config" in str(e.value) or "GPU" in str(e.value) or "missing" in str(e.value).lower()
+
+
+def test_certificate_mask_logic():
+    """engine.uncertified_mask (the host half of precision "certified", round 6): tolerances per plane, the final choice, +inf for steps a
+    clip no longer takes, NaN / non-finite scores read as "not certified", and the relaxed policy ignoring the pick-order plane."""
+    from conette_amd.engine import CERT_DEFAULT_BASE, CERT_TOL, uncertified_mask
+    inf, nan = float("inf"), float("nan")
+    max_pred = 4
+    m = torch.full((6, 2, max_pred + 1), inf)
+    lp = torch.zeros(6)
+    m[0, 0, :3] = torch.tensor([0.5, 0.2, 0.3])                       # clip 0: every margin wide
+    m[0, 1, :3] = torch.tensor([0.4, 0.6, 0.2])
+    m[0, 0, max_pred] = 0.1
+    m[1] = m[0]; m[1, 0, 1] = 0.01                                   # clip 1: a membership margin below a
+    m[2] = m[0]; m[2, 1, 2] = 0.01                                   # clip 2: only a pick-ORDER margin below a
+    m[3] = m[0]; m[3, 0, max_pred] = 0.001                           # clip 3: the final choice below c
+    m[4] = m[0]; m[4, 0, 0] = nan                                    # clip 4: NaN margin
+    m[5] = m[0]; lp[5] = -inf                                        # clip 5: non-finite score
+    tol = (0.05, 0.0, 0.004)
+    assert uncertified_mask(m, lp, tol, order=True).tolist() == [False, True, True, True, True, True]
+    assert uncertified_mask(m, lp, tol, order=False).tolist() == [False, True, False, True, True, True]
+    # a tolerance that grows with the step: b * (i + 1)
+    assert uncertified_mask(m[:1], lp[:1], (0.0, 0.11, 0.0), order=True).tolist() == [True]      # step 1 needs 0.22 > 0.2
+    assert uncertified_mask(m[:1], lp[:1], (0.0, 0.06, 0.0), order=True).tolist() == [False]
+    # zero tolerance certifies everything finite, an infinite one nothing that decided anything
+    assert uncertified_mask(m[:4], lp[:4], (0.0, 0.0, 0.0)).tolist() == [False] * 4
+    assert uncertified_mask(m[:4], lp[:4], (inf, 0.0, 0.0)).tolist() == [True] * 4
+    # the shipped table: every base has both kinds of search, greedy tolerances below beam tolerances, and a default base
+    assert CERT_DEFAULT_BASE in CERT_TOL
+    for base, t in CERT_TOL.items():
+        assert set(t) == {"greedy", "beam"} and t["greedy"][0] <= t["beam"][0] and t["greedy"][2] == 0.0 and t["beam"][2] > 0.0, base
+
+
+def test_caption_sizes_of_merged_searches():
+    """engine.caption_sizes recomputes [pred_size, best_maxlen] (beam.py:192-194,207-211,222-225) from full-width ids: on every committed
+    fixture it must return the widths the reference's own outputs have."""
+    from conette_amd.engine import caption_sizes
+    from tests import golden_util as G
+    for name in G.SCENARIOS:
+        g = G.load(name)
+        preds, mult = torch.from_numpy(g["preds"]), torch.from_numpy(g["mult_preds"])
+        max_pred = 30
+        full_b = torch.zeros((preds.shape[0], max_pred), dtype=torch.long); full_b[:, : preds.shape[1]] = preds
+        full_m = torch.zeros((mult.shape[0], mult.shape[1], max_pred), dtype=torch.long); full_m[:, :, : mult.shape[2]] = mult
+        ps, ml = caption_sizes(full_b, full_m, eos_id=2).tolist()
+        kw = __import__("json").loads(str(g["kw"]))
+        if kw.get("max_pred_size", 20) <= max_pred and mult.shape[2] < kw.get("max_pred_size", 20):
+            assert (ps, ml) == (mult.shape[2], preds.shape[1]), name
+        else:   # (a hypothesis that ran to max_pred_size without <eos>: the padded table cannot tell -- the merge keeps the searches' width)
+            assert ml <= ps
