@@ -234,3 +234,18 @@ def test_fp16_stream_overflow_is_loud_and_certified_recovers(models):
     assert bool(mc.last_recomputed.all())
     assert out["preds"].cpu().tolist() == ref["preds"].cpu().tolist() and out["cands"] == ref["cands"]
     assert torch.equal(out["lprobs"].cpu(), ref["lprobs"].cpu())
+
+
+def test_pipelined_certified_benchmark_runs_and_checks_itself():
+    """bench_certified.py (what `also_pipelined["certified*"]` of the bench line runs) at a small size: it must finish, every timed step
+    must equal the un-pipelined certified search of its batch bit for bit, and every clip-step's ids the exact precision's."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in (["--checkpoint", "peaked", "--beam", "1"], ["--policy", "best", "--checkpoint", "peaked"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench_certified.py"), "--steps", "8", "--repeat", "2", "--batch", "16"] + extra,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        assert d["pipeline_consistent"] is True and d["ids_identical_to_exact"][0] == d["ids_identical_to_exact"][1] == 2 * 8 * 16
+        assert 0.0 <= d["recompute_fraction"] <= 1.0 and d["value"] > 0 and d["precision"].startswith("certified")
