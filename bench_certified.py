@@ -49,7 +49,7 @@ def main(argv=None) -> None:
     import torch
     import conette_amd  # noqa: F401
     from conette_amd import synth
-    from conette_amd.engine import CERT_TOL, Engine
+    from conette_amd.engine import CERT_TOL, Engine, cert_kind
 
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -199,7 +199,7 @@ def main(argv=None) -> None:
         "windows": {"clips_per_sec": [round(B * args.steps / w, 2) for w in win_dt]},
         "precision": eng.precision_name, "policy": args.policy, "dtype": f"{args.base} + f16x2 re-run of uncertified clips", "checkpoint": args.checkpoint,
         "recompute_fraction": round(recompute_fraction, 4), "rerun_fraction_with_padding": round(rerun_fraction, 4),
-        "tolerance": {"a_b_c": list(CERT_TOL[args.base]["greedy" if beam == 1 else "beam"]),
+        "tolerance": {"a_b_c": list(CERT_TOL[args.base][cert_kind(beam)]),
                       "source": "profiles/r06_margin_calibration.txt"},
         "pipeline_consistent": same_solo, "pipeline_steps_checked": int(n_groups * G),
         "ids_identical_to_exact": [same_exact_clips, int(n_groups * G * B)],

@@ -191,8 +191,11 @@ def test_certificate_mask_logic():
     assert uncertified_mask(m[:4], lp[:4], (inf, 0.0, 0.0)).tolist() == [True] * 4
     # the shipped table: every base has both kinds of search, greedy tolerances below beam tolerances, and a default base
     assert CERT_DEFAULT_BASE in CERT_TOL
+    from conette_amd.engine import cert_kind
+    assert [cert_kind(k) for k in (1, 2, 3, 5, 6, 8, 10, 16)] == ["greedy", "beam", "beam", "beam", "wide", "wide", "wide", "wide"]
     for base, t in CERT_TOL.items():
-        assert set(t) == {"greedy", "beam"} and t["greedy"][0] <= t["beam"][0] and t["greedy"][2] == 0.0 and t["beam"][2] > 0.0, base
+        assert set(t) == {"greedy", "beam", "wide"} and t["greedy"][0] <= t["beam"][0] <= t["wide"][0], base
+        assert t["greedy"][2] == 0.0 and 0.0 < t["beam"][2] <= t["wide"][2], base
 
 
 def test_caption_sizes_of_merged_searches():

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--clips", type=int, default=512)
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--beams", default="1,3", help="beam sizes, comma separated")
     ap.add_argument("--bases", default="f16,mixed16,bf16+f16dec,bf16")
     ap.add_argument("--seed0", type=int, default=900000, help="clip i is generated from seed0 + i; lengths from default_rng(seed0 % 1000 + 7)")
     args = ap.parse_args()
@@ -62,8 +63,8 @@ def main():
         vocab = int(sd["model.decoder.classifier.weight"].shape[0])
         for base in args.bases.split(","):
             eng = E.Engine(sd, precision=f"certified:{base}", device=dev)
-            for beam in (1, 3):
-                a, b, c = E.CERT_TOL[base]["greedy" if beam == 1 else "beam"]
+            for beam in [int(v) for v in args.beams.split(",")]:
+                a, b, c = E.CERT_TOL[base][E.cert_kind(beam)]
                 rel = {"flagged": 0, "wrong": 0, "missed": 0}
                 unprot = []      # (step, base margin) at the first diverging call
                 unprot_final = []

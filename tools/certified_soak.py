@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--bases", default="mixed16,f16")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--beams", default="1,3", help="beam sizes, comma separated")
     ap.add_argument("--seed0", type=int, default=3000000)
     args = ap.parse_args()
     import conette_amd  # noqa: F401
@@ -55,7 +56,7 @@ def main():
             for policy in ("certified", "certified-best"):
                 eng = E.Engine(sd, precision=f"{policy}:{base}", device=dev)
                 t = eng.lib.conette_num_audio_frames(L)
-                for beam in (1, 3):
+                for beam in [int(v) for v in args.beams.split(",")]:
                     if policy == "certified-best" and beam == 1:
                         continue            # (greedy has no pick order: the two policies coincide)
                     bad_best = bad_mult = bad_set = rec = 0
