@@ -49,13 +49,15 @@ EXPORTS = (
 # what the tolerances cost is the share of clips whose closest decision is nearer than that: `recompute_fraction` of the bench line.
 # Other beam sizes (profiles/r06_margin_calibration_beams.txt, base mixed16, 2 048 clips per checkpoint): beams 2 and 5 stay inside the
 # beam-3 maxima (0.021 / 0.022; final choice 0.0024), beam 8 reached 0.0385 -- more rows, more chances of a large deviation -- hence a
-# third class, "wide" (beam >= 6), at 2 x that; for the other bases the wide tolerances are the beam-3 ones scaled by the same 1.77.
+# third class, "wide" (beam >= 6), at 2 x that; for the other bases the wide tolerances are the beam-3 ones scaled by the same 1.77 and
+# were then held to their own runs at beams 2 / 5 / 8 (profiles/r06_margin_calibration_beams_other.txt: f16 reached 0.0405 at beam 2 -- its
+# beam tolerance is 2 x that --, bf16 0.024 on the final choice).
 # A certificate at beam >= 5 flags 93-100 % of the clips of either synthetic checkpoint anyway.
 CERT_TOL = {
     "mixed16": {"greedy": (0.032, 0.0, 0.0), "beam": (0.045, 0.0, 0.005), "wide": (0.08, 0.0, 0.005)},
-    "f16": {"greedy": (0.063, 0.0, 0.0), "beam": (0.075, 0.0, 0.008), "wide": (0.13, 0.0, 0.008)},
+    "f16": {"greedy": (0.063, 0.0, 0.0), "beam": (0.082, 0.0, 0.008), "wide": (0.13, 0.0, 0.008)},
     "bf16+f16dec": {"greedy": (0.20, 0.0, 0.0), "beam": (0.37, 0.0, 0.026), "wide": (0.65, 0.0, 0.05)},
-    "bf16": {"greedy": (0.39, 0.0, 0.0), "beam": (0.58, 0.0, 0.04), "wide": (1.0, 0.0, 0.08)},
+    "bf16": {"greedy": (0.39, 0.0, 0.0), "beam": (0.58, 0.0, 0.05), "wide": (1.0, 0.0, 0.08)},
 }
 
 
