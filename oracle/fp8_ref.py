@@ -1,7 +1,8 @@
 """ORACLE -- test infrastructure only.  NOT the product, never shipped, never the thing measured.
 
-fp8-operand restatement of the ConvNeXt block as CONETTE_PREC_FP8 runs it at stages 0-2 (csrc/mlp_f8.h; BASELINE.json
-configs[4] "fp8 MFMA pointwise GEMMs"): the algorithm of ``cpu_ref.convnext_block`` (nn/encoders/convnext.py:61-74) with
+fp8-operand restatement of the ConvNeXt block as the experimental fp8 precision of rounds 3-5 ran it at stages 0-2 (now
+tools/lab/mlp_f8.h: the precision was WITHDRAWN in round 6, profiles/r06_notes.md section 3; BASELINE.json configs[4] "fp8 MFMA
+pointwise GEMMs").  Kept as the per-tensor-scaled arm of oracle/mx_study.py: the algorithm of ``cpu_ref.convnext_block`` (nn/encoders/convnext.py:61-74) with
 the kernel's quantisation points, fp32 accumulation and fp32 everything else:
 
   y8   = e4m3(LN(dwconv(x)))                                   (scale 1; the depthwise-conv kernel stores y as e4m3)

@@ -7,7 +7,7 @@ operands at the four points a fused kernel would quantise (y = LN output, W1, ge
 everything else runs as the bf16 throughput mode does (bf16 operands, fp16 residual stream: oracle/bf16_ref.py).
     python -m oracle.mx_study [n_clips]
 prints the frame embeddings' rel. rms against the fp32 oracle for: the bf16 mode, MX-e4m3 in stage 2 only, in stages 0-2, and the
-per-tensor-scaled e4m3 of the existing CONETTE_PREC_FP8 (oracle/fp8_ref.py) in stages 0-2.
+per-tensor-scaled e4m3 of the withdrawn fp8 precision (oracle/fp8_ref.py) in stages 0-2.
 """
 import importlib
 import sys
@@ -78,7 +78,7 @@ def main():
         rows = [("bf16 mode (bf16 operands, fp16 stream)", encode(sd, wave)),
                 ("MX-e4m3 pointwise, stage 2 only", encode(sd, wave, mx_stages=(2,))),
                 ("MX-e4m3 pointwise, stages 0-2", encode(sd, wave, mx_stages=(0, 1, 2))),
-                ("per-tensor e4m3 pointwise (CONETTE_PREC_FP8's points), stages 0-2", encode(sd, wave, f8_stages=(0, 1, 2)))]
+                ("per-tensor e4m3 pointwise (the withdrawn fp8 precision's points), stages 0-2", encode(sd, wave, f8_stages=(0, 1, 2)))]
     for name, fe in rows:
         rel = float((fe - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
         print(f"{name:70s} frame_embs rel rms {rel:.3e}", flush=True)
